@@ -1,0 +1,310 @@
+"""Python plumbing for the MI355X-native flow2d hot path (ctypes over the C-ABI).
+
+The product is the HIP library (csrc/ -> libflow2d_hip.so, include/flow2d_c_abi.h) and the C++ host
+layer (host/ -> libflow2d_host.so, `flow2d` CLI) that mirrors the reference's OpticalFlow2D /
+CudaOperation* interface.  This module only loads those libraries for tests/ and bench.py; it holds
+no algorithm and has NO CPU fallback: a missing library or a failing call raises.
+
+The directory name carries a hyphen, so import it with
+    importlib.import_module("cuda-flow2d_amd")
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(_HERE)
+HIP_LIB_PATH = os.path.join(_HERE, "csrc", "libflow2d_hip.so")
+HOST_LIB_PATH = os.path.join(_HERE, "host", "libflow2d_host.so")
+CLI_PATH = os.path.join(_HERE, "host", "flow2d")
+
+GREY, GRADIENT = 0, 1
+SOLVER_AUTO, SOLVER_PER_SWEEP, SOLVER_FUSED = 0, 1, 2
+
+STATUS = {0: "ok", 1: "invalid argument", 2: "no usable HIP device", 3: "HIP runtime error",
+          4: "out of device memory", 5: "unsupported parameter"}
+
+
+class Flow2DError(RuntimeError):
+    def __init__(self, status, where, detail=""):
+        self.status = status
+        super().__init__("%s failed: status %d (%s)%s" % (where, status, STATUS.get(status, "?"),
+                                                          (": " + detail) if detail else ""))
+
+
+def build(jobs=8):
+    """Compile every native piece in-tree: HIP kernels + C-ABI (hipcc, gfx950) and the C++ host layer."""
+    subprocess.check_call(["make", "-s", "-j%d" % jobs, "-C", os.path.join(_HERE, "csrc")])
+    subprocess.check_call(["make", "-s", "-j%d" % jobs, "-C", os.path.join(_HERE, "host")])
+
+
+class SolveParams(C.Structure):
+    _fields_ = [
+        ("width", C.c_size_t), ("height", C.c_size_t), ("pitch_bytes", C.c_size_t),
+        ("container_height", C.c_size_t), ("hx", C.c_float), ("hy", C.c_float),
+        ("equation_alpha", C.c_float), ("equation_smoothness", C.c_float), ("equation_data", C.c_float),
+        ("outer_iterations_count", C.c_size_t), ("inner_iterations_count", C.c_size_t),
+        ("data_constancy", C.c_int), ("algorithm", C.c_int),
+    ]
+
+
+class TimingRecord(C.Structure):
+    _fields_ = [
+        ("width", C.c_size_t), ("height", C.c_size_t), ("outer", C.c_size_t), ("inner", C.c_size_t),
+        ("data_constancy", C.c_int), ("algorithm", C.c_int), ("kernel_launches", C.c_int),
+        ("elapsed_ms", C.c_float),
+    ]
+
+
+_hip = None
+
+
+def hip_lib():
+    """The C-ABI library.  Raises if it has not been built -- there is no fallback."""
+    global _hip
+    if _hip is None:
+        if not os.path.exists(HIP_LIB_PATH):
+            raise ImportError("%s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                              "(the HIP extension is mandatory, there is no CPU path)" % HIP_LIB_PATH)
+        L = C.CDLL(HIP_LIB_PATH, mode=C.RTLD_GLOBAL)
+        vp, sz, f, i = C.c_void_p, C.c_size_t, C.c_float, C.c_int
+        L.flow2d_abi_version.restype = i
+        L.flow2d_status_string.restype = C.c_char_p
+        L.flow2d_status_string.argtypes = [i]
+        L.flow2d_last_error.restype = C.c_char_p
+        L.flow2d_device_count.argtypes = [C.POINTER(i)]
+        L.flow2d_context_create.argtypes = [i, C.POINTER(vp)]
+        L.flow2d_context_create_on_stream.argtypes = [i, vp, C.POINTER(vp)]
+        L.flow2d_context_destroy.argtypes = [vp]
+        L.flow2d_context_device.argtypes = [vp, C.POINTER(i)]
+        L.flow2d_context_stream.argtypes = [vp, C.POINTER(vp)]
+        L.flow2d_synchronize.argtypes = [vp]
+        L.flow2d_mem_info.argtypes = [vp, C.POINTER(sz), C.POINTER(sz)]
+        L.flow2d_device_name.argtypes = [vp, C.c_char_p, sz]
+        L.flow2d_plane_pitch_bytes.restype = sz
+        L.flow2d_plane_pitch_bytes.argtypes = [sz]
+        L.flow2d_plane_alloc.argtypes = [vp, sz, sz, C.POINTER(vp), C.POINTER(sz)]
+        L.flow2d_plane_free.argtypes = [vp, vp]
+        L.flow2d_memset_2d.argtypes = [vp, vp, sz, i, sz, sz]
+        L.flow2d_copy_h2d_2d.argtypes = [vp, vp, sz, vp, sz, sz, sz]
+        L.flow2d_copy_d2h_2d.argtypes = [vp, vp, sz, vp, sz, sz, sz]
+        L.flow2d_copy_d2d.argtypes = [vp, vp, vp, sz]
+        L.flow2d_event_create.argtypes = [vp, C.POINTER(vp)]
+        L.flow2d_event_record.argtypes = [vp, vp]
+        L.flow2d_event_synchronize.argtypes = [vp, vp]
+        L.flow2d_event_elapsed_ms.argtypes = [vp, vp, vp, C.POINTER(f)]
+        L.flow2d_event_destroy.argtypes = [vp, vp]
+        L.flow2d_add_2d.argtypes = [vp, vp, vp, sz, sz, sz]
+        L.flow2d_gaussian_kernel.argtypes = [f, C.POINTER(f), C.POINTER(i)]
+        L.flow2d_convolution_rows.argtypes = [vp, vp, vp, sz, sz, sz, C.POINTER(f), i]
+        L.flow2d_convolution_columns.argtypes = [vp, vp, vp, sz, sz, sz, C.POINTER(f), i]
+        L.flow2d_median_2d.argtypes = [vp, vp, sz, sz, sz, sz, vp]
+        L.flow2d_registration_2d.argtypes = [vp, vp, vp, vp, vp, sz, sz, sz, f, f, vp]
+        L.flow2d_resample_x.argtypes = [vp, vp, vp, sz, sz, sz, sz]
+        L.flow2d_resample_y.argtypes = [vp, vp, vp, sz, sz, sz, sz]
+        L.flow2d_compute_phi_ksi.argtypes = [vp] * 7 + [sz, sz, sz, f, f, f, f, vp, vp]
+        L.flow2d_solve_2d.argtypes = [vp] * 9 + [sz, sz, sz, f, f, f, vp, vp]
+        L.flow2d_solve_2d_grad.argtypes = [vp] * 9 + [sz, sz, sz, f, f, f, vp, vp]
+        L.flow2d_solve_level.argtypes = [vp] * 11 + [C.POINTER(SolveParams), C.POINTER(i)]
+        L.flow2d_timing_enable.argtypes = [vp, i]
+        L.flow2d_timing_count.argtypes = [vp, C.POINTER(sz)]
+        L.flow2d_timing_get.argtypes = [vp, sz, C.POINTER(TimingRecord)]
+        L.flow2d_timing_reset.argtypes = [vp]
+        for name in dir(L):
+            pass
+        _hip = L
+    return _hip
+
+
+def _check(status, where):
+    if status != 0:
+        raise Flow2DError(status, where, hip_lib().flow2d_last_error().decode(errors="replace"))
+
+
+def device_count():
+    n = C.c_int(0)
+    st = hip_lib().flow2d_device_count(C.byref(n))
+    return n.value if st == 0 else 0
+
+
+def gaussian_kernel(sigma):
+    taps = (C.c_float * 51)()
+    r = C.c_int(0)
+    _check(hip_lib().flow2d_gaussian_kernel(sigma, taps, C.byref(r)), "flow2d_gaussian_kernel")
+    return np.array(taps[: 2 * r.value + 1], np.float32), r.value
+
+
+class Plane:
+    """A pitched fp32 container in HBM (reference: one of the 12 cuMemAllocPitch planes)."""
+
+    def __init__(self, ctx, width, height):
+        self.ctx = ctx
+        self.width, self.height = width, height
+        ptr, pitch = C.c_void_p(), C.c_size_t()
+        _check(hip_lib().flow2d_plane_alloc(ctx.handle, width, height, C.byref(ptr), C.byref(pitch)),
+               "flow2d_plane_alloc")
+        self.ptr, self.pitch = ptr.value, pitch.value
+
+    def upload(self, array):
+        a = np.ascontiguousarray(array, np.float32)
+        h, w = a.shape
+        assert w <= self.width and h <= self.height
+        _check(hip_lib().flow2d_copy_h2d_2d(self.ctx.handle, self.ptr, self.pitch, a.ctypes.data, w * 4, w * 4, h),
+               "flow2d_copy_h2d_2d")
+        self.ctx.synchronize()
+        return self
+
+    def download(self, width=None, height=None):
+        w = self.width if width is None else width
+        h = self.height if height is None else height
+        out = np.empty((h, w), np.float32)
+        _check(hip_lib().flow2d_copy_d2h_2d(self.ctx.handle, out.ctypes.data, w * 4, self.ptr, self.pitch, w * 4, h),
+               "flow2d_copy_d2h_2d")
+        self.ctx.synchronize()
+        return out
+
+    def fill_bytes(self, value=0):
+        _check(hip_lib().flow2d_memset_2d(self.ctx.handle, self.ptr, self.pitch, value, self.width * 4, self.height),
+               "flow2d_memset_2d")
+        return self
+
+    def free(self):
+        if self.ptr:
+            hip_lib().flow2d_plane_free(self.ctx.handle, self.ptr)
+            self.ptr = None
+
+
+class Context:
+    """One device + stream (reference: the CUcontext of main.cpp:51 plus the NULL stream)."""
+
+    def __init__(self, device=0, stream=None):
+        h = C.c_void_p()
+        if stream is None:
+            _check(hip_lib().flow2d_context_create(device, C.byref(h)), "flow2d_context_create")
+        else:
+            _check(hip_lib().flow2d_context_create_on_stream(device, stream, C.byref(h)),
+                   "flow2d_context_create_on_stream")
+        self.handle = h
+        self._planes = []
+
+    # -- memory ---------------------------------------------------------------------------------
+    def plane(self, width, height, data=None):
+        p = Plane(self, width, height)
+        self._planes.append(p)
+        if data is not None:
+            p.fill_bytes(0)
+            p.upload(data)
+        return p
+
+    def synchronize(self):
+        _check(hip_lib().flow2d_synchronize(self.handle), "flow2d_synchronize")
+
+    def mem_info(self):
+        a, b = C.c_size_t(), C.c_size_t()
+        _check(hip_lib().flow2d_mem_info(self.handle, C.byref(a), C.byref(b)), "flow2d_mem_info")
+        return a.value, b.value
+
+    def device_name(self):
+        buf = C.create_string_buffer(256)
+        _check(hip_lib().flow2d_device_name(self.handle, buf, 256), "flow2d_device_name")
+        return buf.value.decode()
+
+    def close(self):
+        if self.handle:
+            for p in self._planes:
+                p.free()
+            self._planes = []
+            hip_lib().flow2d_context_destroy(self.handle)
+            self.handle = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    # -- events ---------------------------------------------------------------------------------
+    def event(self):
+        e = C.c_void_p()
+        _check(hip_lib().flow2d_event_create(self.handle, C.byref(e)), "flow2d_event_create")
+        return e
+
+    def record(self, ev):
+        _check(hip_lib().flow2d_event_record(self.handle, ev), "flow2d_event_record")
+
+    def elapsed_ms(self, start, stop):
+        _check(hip_lib().flow2d_event_synchronize(self.handle, stop), "flow2d_event_synchronize")
+        ms = C.c_float()
+        _check(hip_lib().flow2d_event_elapsed_ms(self.handle, start, stop, C.byref(ms)), "flow2d_event_elapsed_ms")
+        return ms.value
+
+    # -- kernels (thin 1:1 wrappers of the C-ABI launchers) --------------------------------------
+    def add(self, op0, op1, w, h):
+        _check(hip_lib().flow2d_add_2d(self.handle, op0.ptr, op1.ptr, w, h, op0.pitch), "flow2d_add_2d")
+
+    def convolution_rows(self, dst, src, w, h, taps, radius):
+        t = np.ascontiguousarray(taps, np.float32)
+        _check(hip_lib().flow2d_convolution_rows(self.handle, dst.ptr, src.ptr, w, h, src.pitch,
+                                                 t.ctypes.data_as(C.POINTER(C.c_float)), radius),
+               "flow2d_convolution_rows")
+
+    def convolution_columns(self, dst, src, w, h, taps, radius):
+        t = np.ascontiguousarray(taps, np.float32)
+        _check(hip_lib().flow2d_convolution_columns(self.handle, dst.ptr, src.ptr, w, h, src.pitch,
+                                                    t.ctypes.data_as(C.POINTER(C.c_float)), radius),
+               "flow2d_convolution_columns")
+
+    def median(self, src, w, h, window, dst):
+        _check(hip_lib().flow2d_median_2d(self.handle, src.ptr, w, h, src.pitch, window, dst.ptr), "flow2d_median_2d")
+
+    def registration(self, f0, f1, u, v, w, h, hx, hy, out):
+        _check(hip_lib().flow2d_registration_2d(self.handle, f0.ptr, f1.ptr, u.ptr, v.ptr, w, h, f0.pitch, hx, hy,
+                                                out.ptr), "flow2d_registration_2d")
+
+    def resample_x(self, src, dst, out_w, out_h, in_w):
+        _check(hip_lib().flow2d_resample_x(self.handle, src.ptr, dst.ptr, out_w, out_h, in_w, src.pitch),
+               "flow2d_resample_x")
+
+    def resample_y(self, src, dst, out_w, out_h, in_h):
+        _check(hip_lib().flow2d_resample_y(self.handle, src.ptr, dst.ptr, out_w, out_h, in_h, src.pitch),
+               "flow2d_resample_y")
+
+    def compute_phi_ksi(self, f0, f1, u, v, du, dv, w, h, hx, hy, e_smooth, e_data, phi, ksi):
+        _check(hip_lib().flow2d_compute_phi_ksi(self.handle, f0.ptr, f1.ptr, u.ptr, v.ptr, du.ptr, dv.ptr, w, h,
+                                                f0.pitch, hx, hy, e_smooth, e_data, phi.ptr, ksi.ptr),
+               "flow2d_compute_phi_ksi")
+
+    def solve_sweep(self, f0, f1, u, v, du, dv, phi, ksi, w, h, hx, hy, alpha, tdu, tdv, constancy=GREY):
+        fn = hip_lib().flow2d_solve_2d_grad if constancy == GRADIENT else hip_lib().flow2d_solve_2d
+        _check(fn(self.handle, f0.ptr, f1.ptr, u.ptr, v.ptr, du.ptr, dv.ptr, phi.ptr, ksi.ptr, w, h, f0.pitch, hx, hy,
+                  alpha, tdu.ptr, tdv.ptr), "flow2d_solve_2d*")
+
+    def solve_level(self, f0, f1, u, v, du, dv, phi, ksi, tdu, tdv, w, h, hx, hy, alpha, e_smooth, e_data, outer,
+                    inner, constancy=GREY, algorithm=SOLVER_AUTO, container_height=None):
+        """Returns (du_plane, dv_plane) holding the result (the library owns the ping-pong)."""
+        p = SolveParams(w, h, f0.pitch, container_height or f0.height, hx, hy, alpha, e_smooth, e_data, outer, inner,
+                        constancy, algorithm)
+        flag = C.c_int(0)
+        _check(hip_lib().flow2d_solve_level(self.handle, f0.ptr, f1.ptr, u.ptr, v.ptr, du.ptr, dv.ptr, phi.ptr,
+                                            ksi.ptr, tdu.ptr, tdv.ptr, C.byref(p), C.byref(flag)),
+               "flow2d_solve_level")
+        return (tdu, tdv) if flag.value else (du, dv)
+
+    # -- timing -----------------------------------------------------------------------------------
+    def timing_enable(self, on=True):
+        _check(hip_lib().flow2d_timing_enable(self.handle, int(on)), "flow2d_timing_enable")
+
+    def timing_records(self):
+        n = C.c_size_t()
+        _check(hip_lib().flow2d_timing_count(self.handle, C.byref(n)), "flow2d_timing_count")
+        out = []
+        for k in range(n.value):
+            r = TimingRecord()
+            _check(hip_lib().flow2d_timing_get(self.handle, k, C.byref(r)), "flow2d_timing_get")
+            out.append(r)
+        return out
+
+    def timing_reset(self):
+        _check(hip_lib().flow2d_timing_reset(self.handle), "flow2d_timing_reset")

@@ -1,0 +1,70 @@
+// Shared declarations of the HIP side of the flow2d C-ABI (gfx950 only).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstddef>
+#include <cstdint>
+#include <vector>
+
+#include "flow2d_c_abi.h"
+
+struct flow2d_timing_slot {
+    flow2d_timing_record rec;
+    hipEvent_t start;
+    hipEvent_t stop;
+};
+
+struct flow2d_context {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool owns_stream = false;
+    bool timing = false;
+    std::vector<flow2d_timing_slot> timings;
+    int num_cus = 256;
+};
+
+namespace flow2d {
+
+void set_last_error(const char* what, hipError_t err);
+void set_last_error_text(const char* what);
+
+// Makes ctx->device current for the calling thread for the duration of a call.
+struct DeviceGuard {
+    explicit DeviceGuard(const flow2d_context* ctx);
+    bool ok() const { return ok_; }
+    bool ok_ = true;
+};
+
+inline bool plane_args_ok(const void* p, size_t w, size_t h, size_t pitch_bytes)
+{
+    return p != nullptr && w > 0 && h > 0 && (pitch_bytes % 16) == 0 && pitch_bytes >= w * sizeof(float) &&
+           (reinterpret_cast<uintptr_t>(p) % 16) == 0 && w < (1u << 30) && h < (1u << 30);
+}
+
+inline unsigned div_up(size_t a, size_t b) { return static_cast<unsigned>((a + b - 1) / b); }
+
+}  // namespace flow2d
+
+#define FLOW2D_HIP_TRY(expr)                              \
+    do {                                                  \
+        hipError_t flow2d_e_ = (expr);                    \
+        if (flow2d_e_ != hipSuccess) {                    \
+            ::flow2d::set_last_error(#expr, flow2d_e_);   \
+            return (flow2d_e_ == hipErrorOutOfMemory) ? FLOW2D_ERR_OUT_OF_MEMORY : FLOW2D_ERR_DEVICE; \
+        }                                                 \
+    } while (0)
+
+#define FLOW2D_ENTER(ctx)                                               \
+    if ((ctx) == nullptr) return FLOW2D_ERR_INVALID_ARGUMENT;           \
+    ::flow2d::DeviceGuard flow2d_guard_(ctx);                           \
+    if (!flow2d_guard_.ok()) return FLOW2D_ERR_DEVICE
+
+#define FLOW2D_CHECK_LAUNCH() FLOW2D_HIP_TRY(hipGetLastError())
+
+// Reflect-without-repeat index of the solver / median halos: -k -> k, n-1+k -> n-1-k.
+__device__ __forceinline__ int mirror_index(int i, int n)
+{
+    i = i < 0 ? -i : i;
+    return i >= n ? 2 * n - i - 2 : i;
+}

@@ -1,0 +1,274 @@
+// Device / context / pitched memory / events of the flow2d C-ABI.
+// Replaces the CUDA driver calls of src/utils/cuda_utils.cpp:26-105 and
+// src/optical_flow/optical_flow_2d.cpp:84-140,309-312,574-577 of the reference.
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+
+#include "common.hpp"
+
+namespace {
+thread_local std::string g_last_error;
+}
+
+namespace flow2d {
+
+void set_last_error(const char* what, hipError_t err)
+{
+    g_last_error = std::string(what) + ": " + hipGetErrorString(err);
+}
+
+void set_last_error_text(const char* what) { g_last_error = what; }
+
+DeviceGuard::DeviceGuard(const flow2d_context* ctx)
+{
+    int cur = -1;
+    if (hipGetDevice(&cur) != hipSuccess || cur != ctx->device) {
+        hipError_t e = hipSetDevice(ctx->device);
+        if (e != hipSuccess) {
+            set_last_error("hipSetDevice", e);
+            ok_ = false;
+        }
+    }
+}
+
+}  // namespace flow2d
+
+extern "C" {
+
+int flow2d_abi_version(void) { return FLOW2D_ABI_VERSION; }
+
+const char* flow2d_status_string(int status)
+{
+    switch (status) {
+        case FLOW2D_OK: return "ok";
+        case FLOW2D_ERR_INVALID_ARGUMENT: return "invalid argument";
+        case FLOW2D_ERR_NO_DEVICE: return "no usable HIP device";
+        case FLOW2D_ERR_DEVICE: return "HIP runtime error";
+        case FLOW2D_ERR_OUT_OF_MEMORY: return "out of device memory";
+        case FLOW2D_ERR_UNSUPPORTED: return "unsupported parameter";
+        default: return "unknown status";
+    }
+}
+
+const char* flow2d_last_error(void) { return g_last_error.c_str(); }
+
+int flow2d_device_count(int* count)
+{
+    if (!count) return FLOW2D_ERR_INVALID_ARGUMENT;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) {
+        flow2d::set_last_error("hipGetDeviceCount", e);
+        *count = 0;
+        return FLOW2D_ERR_NO_DEVICE;
+    }
+    *count = n;
+    return FLOW2D_OK;
+}
+
+static int create_context(int device_ordinal, void* stream, bool adopt, flow2d_context** out_ctx)
+{
+    if (!out_ctx) return FLOW2D_ERR_INVALID_ARGUMENT;
+    *out_ctx = nullptr;
+    int n = 0;
+    int st = flow2d_device_count(&n);
+    if (st != FLOW2D_OK) return st;
+    if (device_ordinal < 0 || device_ordinal >= n) return FLOW2D_ERR_NO_DEVICE;
+    FLOW2D_HIP_TRY(hipSetDevice(device_ordinal));
+    flow2d_context* ctx = new (std::nothrow) flow2d_context();
+    if (!ctx) return FLOW2D_ERR_OUT_OF_MEMORY;
+    ctx->device = device_ordinal;
+    if (adopt) {
+        ctx->stream = static_cast<hipStream_t>(stream);
+        ctx->owns_stream = false;
+    } else {
+        hipError_t e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+        if (e != hipSuccess) {
+            flow2d::set_last_error("hipStreamCreateWithFlags", e);
+            delete ctx;
+            return FLOW2D_ERR_DEVICE;
+        }
+        ctx->owns_stream = true;
+    }
+    int cus = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device_ordinal) == hipSuccess && cus > 0)
+        ctx->num_cus = cus;
+    *out_ctx = ctx;
+    return FLOW2D_OK;
+}
+
+int flow2d_context_create(int device_ordinal, flow2d_context** out_ctx)
+{
+    return create_context(device_ordinal, nullptr, false, out_ctx);
+}
+
+int flow2d_context_create_on_stream(int device_ordinal, void* hip_stream, flow2d_context** out_ctx)
+{
+    return create_context(device_ordinal, hip_stream, true, out_ctx);
+}
+
+int flow2d_context_destroy(flow2d_context* ctx)
+{
+    FLOW2D_ENTER(ctx);
+    (void)hipStreamSynchronize(ctx->stream);
+    for (auto& s : ctx->timings) {
+        (void)hipEventDestroy(s.start);
+        (void)hipEventDestroy(s.stop);
+    }
+    if (ctx->owns_stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return FLOW2D_OK;
+}
+
+int flow2d_context_device(const flow2d_context* ctx, int* device_ordinal)
+{
+    if (!ctx || !device_ordinal) return FLOW2D_ERR_INVALID_ARGUMENT;
+    *device_ordinal = ctx->device;
+    return FLOW2D_OK;
+}
+
+int flow2d_context_stream(const flow2d_context* ctx, void** hip_stream)
+{
+    if (!ctx || !hip_stream) return FLOW2D_ERR_INVALID_ARGUMENT;
+    *hip_stream = ctx->stream;
+    return FLOW2D_OK;
+}
+
+int flow2d_synchronize(flow2d_context* ctx)
+{
+    FLOW2D_ENTER(ctx);
+    FLOW2D_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return FLOW2D_OK;
+}
+
+int flow2d_mem_info(flow2d_context* ctx, size_t* free_bytes, size_t* total_bytes)
+{
+    FLOW2D_ENTER(ctx);
+    if (!free_bytes || !total_bytes) return FLOW2D_ERR_INVALID_ARGUMENT;
+    FLOW2D_HIP_TRY(hipMemGetInfo(free_bytes, total_bytes));
+    return FLOW2D_OK;
+}
+
+int flow2d_device_name(flow2d_context* ctx, char* buf, size_t buf_len)
+{
+    FLOW2D_ENTER(ctx);
+    if (!buf || buf_len == 0) return FLOW2D_ERR_INVALID_ARGUMENT;
+    hipDeviceProp_t prop;
+    FLOW2D_HIP_TRY(hipGetDeviceProperties(&prop, ctx->device));
+    std::snprintf(buf, buf_len, "%s (%s)", prop.name, prop.gcnArchName);
+    return FLOW2D_OK;
+}
+
+size_t flow2d_plane_pitch_bytes(size_t width)
+{
+    const size_t align = 256;
+    return (width * sizeof(float) + align - 1) / align * align;
+}
+
+int flow2d_plane_alloc(flow2d_context* ctx, size_t width, size_t height, void** out_dev_ptr, size_t* out_pitch_bytes)
+{
+    FLOW2D_ENTER(ctx);
+    if (!out_dev_ptr || !out_pitch_bytes || width == 0 || height == 0) return FLOW2D_ERR_INVALID_ARGUMENT;
+    size_t pitch = flow2d_plane_pitch_bytes(width);
+    void* p = nullptr;
+    FLOW2D_HIP_TRY(hipMalloc(&p, pitch * height));
+    *out_dev_ptr = p;
+    *out_pitch_bytes = pitch;
+    return FLOW2D_OK;
+}
+
+int flow2d_plane_free(flow2d_context* ctx, void* dev_ptr)
+{
+    FLOW2D_ENTER(ctx);
+    if (!dev_ptr) return FLOW2D_OK;
+    FLOW2D_HIP_TRY(hipFree(dev_ptr));
+    return FLOW2D_OK;
+}
+
+int flow2d_memset_2d(flow2d_context* ctx, void* dev_ptr, size_t pitch_bytes, int byte_value, size_t width_bytes,
+                     size_t height)
+{
+    FLOW2D_ENTER(ctx);
+    if (!dev_ptr || width_bytes > pitch_bytes) return FLOW2D_ERR_INVALID_ARGUMENT;
+    if (width_bytes == 0 || height == 0) return FLOW2D_OK;
+    FLOW2D_HIP_TRY(hipMemset2DAsync(dev_ptr, pitch_bytes, byte_value, width_bytes, height, ctx->stream));
+    return FLOW2D_OK;
+}
+
+int flow2d_copy_h2d_2d(flow2d_context* ctx, void* dst_dev, size_t dst_pitch_bytes, const void* src_host,
+                       size_t src_pitch_bytes, size_t width_bytes, size_t height)
+{
+    FLOW2D_ENTER(ctx);
+    if (!dst_dev || !src_host || width_bytes > dst_pitch_bytes || width_bytes > src_pitch_bytes)
+        return FLOW2D_ERR_INVALID_ARGUMENT;
+    FLOW2D_HIP_TRY(hipMemcpy2DAsync(dst_dev, dst_pitch_bytes, src_host, src_pitch_bytes, width_bytes, height,
+                                    hipMemcpyHostToDevice, ctx->stream));
+    return FLOW2D_OK;
+}
+
+int flow2d_copy_d2h_2d(flow2d_context* ctx, void* dst_host, size_t dst_pitch_bytes, const void* src_dev,
+                       size_t src_pitch_bytes, size_t width_bytes, size_t height)
+{
+    FLOW2D_ENTER(ctx);
+    if (!dst_host || !src_dev || width_bytes > dst_pitch_bytes || width_bytes > src_pitch_bytes)
+        return FLOW2D_ERR_INVALID_ARGUMENT;
+    FLOW2D_HIP_TRY(hipMemcpy2DAsync(dst_host, dst_pitch_bytes, src_dev, src_pitch_bytes, width_bytes, height,
+                                    hipMemcpyDeviceToHost, ctx->stream));
+    return FLOW2D_OK;
+}
+
+int flow2d_copy_d2d(flow2d_context* ctx, void* dst_dev, const void* src_dev, size_t bytes)
+{
+    FLOW2D_ENTER(ctx);
+    if (!dst_dev || !src_dev) return FLOW2D_ERR_INVALID_ARGUMENT;
+    if (bytes == 0) return FLOW2D_OK;
+    FLOW2D_HIP_TRY(hipMemcpyAsync(dst_dev, src_dev, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+    return FLOW2D_OK;
+}
+
+int flow2d_event_create(flow2d_context* ctx, void** out_event)
+{
+    FLOW2D_ENTER(ctx);
+    if (!out_event) return FLOW2D_ERR_INVALID_ARGUMENT;
+    hipEvent_t ev;
+    FLOW2D_HIP_TRY(hipEventCreate(&ev));
+    *out_event = ev;
+    return FLOW2D_OK;
+}
+
+int flow2d_event_record(flow2d_context* ctx, void* event)
+{
+    FLOW2D_ENTER(ctx);
+    if (!event) return FLOW2D_ERR_INVALID_ARGUMENT;
+    FLOW2D_HIP_TRY(hipEventRecord(static_cast<hipEvent_t>(event), ctx->stream));
+    return FLOW2D_OK;
+}
+
+int flow2d_event_synchronize(flow2d_context* ctx, void* event)
+{
+    FLOW2D_ENTER(ctx);
+    if (!event) return FLOW2D_ERR_INVALID_ARGUMENT;
+    FLOW2D_HIP_TRY(hipEventSynchronize(static_cast<hipEvent_t>(event)));
+    return FLOW2D_OK;
+}
+
+int flow2d_event_elapsed_ms(flow2d_context* ctx, void* start_event, void* stop_event, float* out_ms)
+{
+    FLOW2D_ENTER(ctx);
+    if (!start_event || !stop_event || !out_ms) return FLOW2D_ERR_INVALID_ARGUMENT;
+    FLOW2D_HIP_TRY(hipEventElapsedTime(out_ms, static_cast<hipEvent_t>(start_event),
+                                       static_cast<hipEvent_t>(stop_event)));
+    return FLOW2D_OK;
+}
+
+int flow2d_event_destroy(flow2d_context* ctx, void* event)
+{
+    FLOW2D_ENTER(ctx);
+    if (!event) return FLOW2D_OK;
+    FLOW2D_HIP_TRY(hipEventDestroy(static_cast<hipEvent_t>(event)));
+    return FLOW2D_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,253 @@
+// Pyramid-side kernels of the flow2d hot path for gfx950: flow update (add), Gaussian pre-blur,
+// area-weighted resampling and backward bilinear registration (warp).
+//
+// These are HBM-bound streaming / gather kernels that run a handful of times per pyramid level
+// (< 3 % of a level's bytes).  Layout: one wave = 64 consecutive pixels of one row so
+// every global access of a wave is one contiguous 256-byte row segment; blocks are 64x4.
+// All arithmetic follows the reference's operation order (no FMA contraction) -- see each kernel.
+#include <cmath>
+
+#include "common.hpp"
+
+namespace {
+
+constexpr int kBlockX = 64;
+constexpr int kBlockY = 4;
+
+inline dim3 grid_for(size_t w, size_t h) { return dim3(flow2d::div_up(w, kBlockX), flow2d::div_up(h, kBlockY)); }
+
+// ---- add_2d: src/kernels/add_2d.cu:33-46 --------------------------------------------------------
+// float4 body (four pixels per lane, 1 KiB per wave-instruction) + scalar tail.
+__global__ __launch_bounds__(256) void add_2d_kernel(float* __restrict__ op0, const float* __restrict__ op1, int w,
+                                                     int h, int pitch)
+{
+    const int x4 = (blockIdx.x * kBlockX + threadIdx.x) * 4;
+    const int y = blockIdx.y * kBlockY + threadIdx.y;
+    if (y >= h || x4 >= w) return;
+    const size_t off = static_cast<size_t>(y) * pitch + x4;
+    if (x4 + 3 < w) {
+        float4 a = *reinterpret_cast<const float4*>(op0 + off);
+        const float4 b = *reinterpret_cast<const float4*>(op1 + off);
+        a.x += b.x;
+        a.y += b.y;
+        a.z += b.z;
+        a.w += b.w;
+        *reinterpret_cast<float4*>(op0 + off) = a;
+    } else {
+        for (int i = 0; x4 + i < w; ++i) op0[off + i] += op1[off + i];
+    }
+}
+
+// ---- Gaussian rows / columns: src/kernels/convolution_2d.cu:74-168, 181-261 ---------------------
+// Zero padding outside the image; sum accumulated j = -r..r with tap[r - j] (fp32, no FMA).
+struct GaussTaps {
+    float t[51];
+};
+
+template <bool kRows>
+__global__ __launch_bounds__(256) void gauss_kernel(float* __restrict__ dst, const float* __restrict__ src, int w,
+                                                    int h, int pitch, int radius, GaussTaps taps)
+{
+    const int x = blockIdx.x * kBlockX + threadIdx.x;
+    const int y = blockIdx.y * kBlockY + threadIdx.y;
+    if (x >= w || y >= h) return;
+    float sum = 0.f;
+    for (int j = -radius; j <= radius; ++j) {
+        float s;
+        if (kRows) {
+            const int xx = x + j;
+            s = (xx >= 0 && xx < w) ? src[static_cast<size_t>(y) * pitch + xx] : 0.f;
+        } else {
+            const int yy = y + j;
+            s = (yy >= 0 && yy < h) ? src[static_cast<size_t>(yy) * pitch + x] : 0.f;
+        }
+        sum += taps.t[radius - j] * s;
+    }
+    dst[static_cast<size_t>(y) * pitch + x] = sum;
+}
+
+// ---- area-weighted resampling: src/kernels/resample_2d.cu:34-75 (x), :77-118 (y) ----------------
+template <bool kAlongX>
+__global__ __launch_bounds__(256) void resample_kernel(const float* __restrict__ in, float* __restrict__ out,
+                                                       int out_w, int out_h, int in_n, int pitch)
+{
+    const int x = blockIdx.x * kBlockX + threadIdx.x;
+    const int y = blockIdx.y * kBlockY + threadIdx.y;
+    if (x >= out_w || y >= out_h) return;
+    const int out_n = kAlongX ? out_w : out_h;
+    const unsigned g = kAlongX ? x : y;
+    const float delta = static_cast<float>(in_n) / static_cast<float>(out_n);
+    const float normalization = static_cast<float>(out_n) / static_cast<float>(in_n);
+    const float left_f = static_cast<float>(g) * delta;
+    const float right_f = static_cast<float>(g + 1u) * delta;
+    const int left_i = static_cast<int>(floorf(left_f));
+    const int right_i = min(in_n, static_cast<int>(ceilf(right_f)));
+    const int cells = right_i - left_i;
+    const float* base = kAlongX ? in + static_cast<size_t>(y) * pitch : in + x;
+    const size_t stride = kAlongX ? 1 : pitch;
+    float value = 0.f;
+    for (int j = 0; j < cells; ++j) {
+        float frac = 1.f;
+        if (j == 0) frac = static_cast<float>(left_i + 1) - left_f;
+        if (j == cells - 1) frac = right_f - static_cast<float>(left_i + j);
+        if (cells == 1) frac = delta;
+        value += base[static_cast<size_t>(left_i + j) * stride] * frac;
+    }
+    out[static_cast<size_t>(y) * pitch + x] = value * normalization;
+}
+
+// ---- backward registration: src/kernels/registration_2d.cu:34-73 --------------------------------
+__global__ __launch_bounds__(256) void registration_kernel(const float* __restrict__ f0, const float* __restrict__ f1,
+                                                           const float* __restrict__ u, const float* __restrict__ v,
+                                                           int w, int h, int pitch, float hx, float hy,
+                                                           float* __restrict__ out)
+{
+    const int gx = blockIdx.x * kBlockX + threadIdx.x;
+    const int gy = blockIdx.y * kBlockY + threadIdx.y;
+    if (gx >= w || gy >= h) return;
+    const size_t c = static_cast<size_t>(gy) * pitch + gx;
+    const float x_f = static_cast<float>(gx) + (u[c] * (1.f / hx));
+    const float y_f = static_cast<float>(gy) + (v[c] * (1.f / hy));
+    float value;
+    if ((x_f < 0.f) || (x_f > static_cast<float>(w - 1)) || (y_f < 0.f) || (y_f > static_cast<float>(h - 1)) ||
+        isnan(x_f) || isnan(y_f)) {
+        value = f0[c];
+    } else {
+        const int x = static_cast<int>(floorf(x_f));
+        const int y = static_cast<int>(floorf(y_f));
+        const float dx = x_f - static_cast<float>(x);
+        const float dy = y_f - static_cast<float>(y);
+        const int x1 = min(w - 1, x + 1);
+        const int y1 = min(h - 1, y + 1);
+        const float* r0 = f1 + static_cast<size_t>(y) * pitch;
+        const float* r1 = f1 + static_cast<size_t>(y1) * pitch;
+        value = (1.f - dx) * (1.f - dy) * r0[x] + (dx) * (1.f - dy) * r0[x1] + (1.f - dx) * (dy)*r1[x] +
+                (dx) * (dy)*r1[x1];
+    }
+    out[c] = value;
+}
+
+}  // namespace
+
+extern "C" {
+
+int flow2d_add_2d(flow2d_context* ctx, float* operand_0, const float* operand_1, size_t width, size_t height,
+                  size_t pitch_bytes)
+{
+    FLOW2D_ENTER(ctx);
+    if (!flow2d::plane_args_ok(operand_0, width, height, pitch_bytes) ||
+        !flow2d::plane_args_ok(operand_1, width, height, pitch_bytes))
+        return FLOW2D_ERR_INVALID_ARGUMENT;
+    dim3 grid(flow2d::div_up(width, kBlockX * 4), flow2d::div_up(height, kBlockY));
+    add_2d_kernel<<<grid, dim3(kBlockX, kBlockY), 0, ctx->stream>>>(operand_0, operand_1, (int)width, (int)height,
+                                                                   (int)(pitch_bytes / 4));
+    FLOW2D_CHECK_LAUNCH();
+    return FLOW2D_OK;
+}
+
+// CudaOperationConvolution2D::ComputeGaussianKernel(sigma, precision = 3, pixel_size = 1.0),
+// src/cuda_operations/2d/cuda_operation_convolution_2d.cpp:83-112: taps evaluated in double,
+// stored as float, normalised by a float running sum.
+int flow2d_gaussian_kernel(float sigma, float* taps, int* out_radius)
+{
+    if (!taps || !out_radius || !(sigma > 0.f)) return FLOW2D_ERR_INVALID_ARGUMENT;
+    const size_t precision = 3;
+    const float pixel_size = 1.0f;
+    const size_t radius = static_cast<size_t>(precision * sigma / pixel_size);
+    if (2 * radius + 1 > 51) return FLOW2D_ERR_UNSUPPORTED;
+    const int r = static_cast<int>(radius);
+    const double amplitude = 1.0 / (static_cast<double>(sigma) * std::sqrt(2.0 * 3.1415926));
+    const double two_sigma_sq = 2.0 * static_cast<double>(sigma) * static_cast<double>(sigma);
+    for (int i = -r; i <= r; ++i) {
+        const float neg_dist_sq = -(static_cast<float>(i * i) * pixel_size * pixel_size);  // float, as in the reference
+        taps[i + r] = static_cast<float>(amplitude * std::exp(static_cast<double>(neg_dist_sq) / two_sigma_sq));
+    }
+    float sum = 0.0;
+    for (int i = 0; i < 2 * r + 1; ++i) sum = sum + taps[i];
+    for (int i = 0; i < 2 * r + 1; ++i) taps[i] = taps[i] / sum;
+    *out_radius = r;
+    return FLOW2D_OK;
+}
+
+static int launch_gauss(flow2d_context* ctx, bool rows, float* dst, const float* src, size_t width, size_t height,
+                        size_t pitch_bytes, const float* taps, int radius)
+{
+    FLOW2D_ENTER(ctx);
+    if (!flow2d::plane_args_ok(dst, width, height, pitch_bytes) ||
+        !flow2d::plane_args_ok(src, width, height, pitch_bytes) || !taps || dst == src)
+        return FLOW2D_ERR_INVALID_ARGUMENT;
+    if (radius < 0 || 2 * radius + 1 > 51) return FLOW2D_ERR_UNSUPPORTED;
+    GaussTaps t;
+    for (int i = 0; i < 51; ++i) t.t[i] = i < 2 * radius + 1 ? taps[i] : 0.f;
+    if (rows)
+        gauss_kernel<true><<<grid_for(width, height), dim3(kBlockX, kBlockY), 0, ctx->stream>>>(
+            dst, src, (int)width, (int)height, (int)(pitch_bytes / 4), radius, t);
+    else
+        gauss_kernel<false><<<grid_for(width, height), dim3(kBlockX, kBlockY), 0, ctx->stream>>>(
+            dst, src, (int)width, (int)height, (int)(pitch_bytes / 4), radius, t);
+    FLOW2D_CHECK_LAUNCH();
+    return FLOW2D_OK;
+}
+
+int flow2d_convolution_rows(flow2d_context* ctx, float* dst, const float* src, size_t width, size_t height,
+                            size_t pitch_bytes, const float* taps, int radius)
+{
+    return launch_gauss(ctx, true, dst, src, width, height, pitch_bytes, taps, radius);
+}
+
+int flow2d_convolution_columns(flow2d_context* ctx, float* dst, const float* src, size_t width, size_t height,
+                               size_t pitch_bytes, const float* taps, int radius)
+{
+    return launch_gauss(ctx, false, dst, src, width, height, pitch_bytes, taps, radius);
+}
+
+static int launch_resample(flow2d_context* ctx, bool along_x, const float* input, float* output, size_t out_width,
+                           size_t out_height, size_t in_extent, size_t pitch_bytes)
+{
+    FLOW2D_ENTER(ctx);
+    const size_t in_w = along_x ? in_extent : out_width;
+    const size_t in_h = along_x ? out_height : in_extent;
+    if (!flow2d::plane_args_ok(input, in_w, in_h, pitch_bytes) ||
+        !flow2d::plane_args_ok(output, out_width, out_height, pitch_bytes) || input == output)
+        return FLOW2D_ERR_INVALID_ARGUMENT;
+    if (along_x)
+        resample_kernel<true><<<grid_for(out_width, out_height), dim3(kBlockX, kBlockY), 0, ctx->stream>>>(
+            input, output, (int)out_width, (int)out_height, (int)in_extent, (int)(pitch_bytes / 4));
+    else
+        resample_kernel<false><<<grid_for(out_width, out_height), dim3(kBlockX, kBlockY), 0, ctx->stream>>>(
+            input, output, (int)out_width, (int)out_height, (int)in_extent, (int)(pitch_bytes / 4));
+    FLOW2D_CHECK_LAUNCH();
+    return FLOW2D_OK;
+}
+
+int flow2d_resample_x(flow2d_context* ctx, const float* input, float* output, size_t out_width, size_t out_height,
+                      size_t in_width, size_t pitch_bytes)
+{
+    return launch_resample(ctx, true, input, output, out_width, out_height, in_width, pitch_bytes);
+}
+
+int flow2d_resample_y(flow2d_context* ctx, const float* input, float* output, size_t out_width, size_t out_height,
+                      size_t in_height, size_t pitch_bytes)
+{
+    return launch_resample(ctx, false, input, output, out_width, out_height, in_height, pitch_bytes);
+}
+
+int flow2d_registration_2d(flow2d_context* ctx, const float* frame_0, const float* frame_1, const float* flow_u,
+                           const float* flow_v, size_t width, size_t height, size_t pitch_bytes, float hx, float hy,
+                           float* output)
+{
+    FLOW2D_ENTER(ctx);
+    if (!flow2d::plane_args_ok(frame_0, width, height, pitch_bytes) ||
+        !flow2d::plane_args_ok(frame_1, width, height, pitch_bytes) ||
+        !flow2d::plane_args_ok(flow_u, width, height, pitch_bytes) ||
+        !flow2d::plane_args_ok(flow_v, width, height, pitch_bytes) ||
+        !flow2d::plane_args_ok(output, width, height, pitch_bytes) || output == frame_1 || output == frame_0 ||
+        !(hx > 0.f) || !(hy > 0.f))
+        return FLOW2D_ERR_INVALID_ARGUMENT;
+    registration_kernel<<<grid_for(width, height), dim3(kBlockX, kBlockY), 0, ctx->stream>>>(
+        frame_0, frame_1, flow_u, flow_v, (int)width, (int)height, (int)(pitch_bytes / 4), hx, hy, output);
+    FLOW2D_CHECK_LAUNCH();
+    return FLOW2D_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,277 @@
+// Per-sweep solver kernels of the flow2d hot path for gfx950: the robust weights (phi, ksi) and
+// one Jacobi sweep of the 2-field Euler-Lagrange system, brightness and gradient constancy.
+// One launch here corresponds to one launch of the reference
+// (compute_phi_ksi / solve_2d / solve_2d_grad, src/kernels/solve_2d.cu:43-198, 200-377, 683-952).
+//
+// Mapping: one wave = 64 consecutive pixels of one image row, so each of the 8 input planes is
+// read as contiguous 256-byte row segments; the x+-1 / y+-1 neighbours of a wave come from the same
+// or the adjacent rows' segments and are L1/L2 hits (HBM sees each plane once: 40 B per pixel-sweep,
+// 32 B per pixel for phi/ksi).  Arithmetic keeps the reference's order of operations; the file is
+// built with -ffp-contract=off so no multiply-add is fused.
+#include "common.hpp"
+
+namespace {
+
+constexpr int kBlockX = 64;
+constexpr int kBlockY = 4;
+
+struct Neighbourhood {
+    size_t c, l, r, u, d;  // element offsets of centre / left / right / up / down (mirrored at borders)
+};
+
+__device__ __forceinline__ Neighbourhood neighbourhood(int x, int y, int w, int h, int pitch)
+{
+    const size_t rc = static_cast<size_t>(y) * pitch;
+    const size_t ru = static_cast<size_t>(mirror_index(y - 1, h)) * pitch;
+    const size_t rd = static_cast<size_t>(mirror_index(y + 1, h)) * pitch;
+    Neighbourhood n;
+    n.c = rc + x;
+    n.l = rc + mirror_index(x - 1, w);
+    n.r = rc + mirror_index(x + 1, w);
+    n.u = ru + x;
+    n.d = rd + x;
+    return n;
+}
+
+// fx, fy, ft of solve_2d.cu:311-321 (identical in compute_phi_ksi :164-174 and solve_2d_grad :798-808)
+__device__ __forceinline__ void image_derivatives(const float* __restrict__ f0, const float* __restrict__ f1,
+                                                  const Neighbourhood& n, float hx, float hy, float& fx, float& fy,
+                                                  float& ft)
+{
+    fx = (f0[n.r] - f0[n.l] + f1[n.r] - f1[n.l]) / (4.f * hx);
+    fy = (f0[n.d] - f0[n.u] + f1[n.d] - f1[n.u]) / (4.f * hy);
+    ft = f1[n.c] - f0[n.c];
+}
+
+// ---- compute_phi_ksi: src/kernels/solve_2d.cu:43-198 ---------------------------------------------
+__global__ __launch_bounds__(256) void phi_ksi_kernel(const float* __restrict__ f0, const float* __restrict__ f1,
+                                                      const float* __restrict__ u, const float* __restrict__ v,
+                                                      const float* __restrict__ du, const float* __restrict__ dv,
+                                                      int w, int h, int pitch, float hx, float hy, float e_smooth,
+                                                      float e_data, float* __restrict__ phi, float* __restrict__ ksi)
+{
+    const int x = blockIdx.x * kBlockX + threadIdx.x;
+    const int y = blockIdx.y * kBlockY + threadIdx.y;
+    if (x >= w || y >= h) return;
+    const Neighbourhood n = neighbourhood(x, y, w, h, pitch);
+
+    const float dux = (u[n.r] - u[n.l] + du[n.r] - du[n.l]) / (2.f * hx);
+    const float duy = (u[n.d] - u[n.u] + du[n.d] - du[n.u]) / (2.f * hy);
+    const float dvx = (v[n.r] - v[n.l] + dv[n.r] - dv[n.l]) / (2.f * hx);
+    const float dvy = (v[n.d] - v[n.u] + dv[n.d] - dv[n.u]) / (2.f * hy);
+    phi[n.c] = 1.f / (2.f * sqrtf(dux * dux + duy * duy + dvx * dvx + dvy * dvy + e_smooth * e_smooth));
+
+    float fx, fy, ft;
+    image_derivatives(f0, f1, n, hx, hy, fx, fy, ft);
+    const float J11 = fx * fx, J22 = fy * fy, J33 = ft * ft, J12 = fx * fy, J13 = fx * ft, J23 = fy * ft;
+    const float a = du[n.c], b = dv[n.c];
+    float s = (J11 * a + J12 * b + J13) * a + (J12 * a + J22 * b + J23) * b + (J13 * a + J23 * b + J33);
+    s = static_cast<float>(s > 0) * s;
+    ksi[n.c] = 1.f / (2.f * sqrtf(s + e_data * e_data));
+}
+
+// The pointwise Jacobi update shared by solve_2d (solve_2d.cu:332-374) and solve_2d_grad (:889-931).
+__device__ __forceinline__ void jacobi_update(const float* __restrict__ u, const float* __restrict__ v,
+                                              const float* __restrict__ du, const float* __restrict__ dv,
+                                              const float* __restrict__ phi, const float* __restrict__ ksi,
+                                              const Neighbourhood& n, int x, int y, int w, int h, float hx, float hy,
+                                              float alpha, float J11, float J22, float J12, float J13, float J23,
+                                              float* __restrict__ tdu, float* __restrict__ tdv)
+{
+    const float hx_2 = alpha / (hx * hx);
+    const float hy_2 = alpha / (hy * hy);
+    const float xp = static_cast<float>(x < w - 1) * hx_2;
+    const float xm = static_cast<float>(x > 0) * hx_2;
+    const float yp = static_cast<float>(y < h - 1) * hy_2;
+    const float ym = static_cast<float>(y > 0) * hy_2;
+
+    const float pc = phi[n.c];
+    const float phi_xp = (phi[n.r] + pc) / 2.f;
+    const float phi_xm = (phi[n.l] + pc) / 2.f;
+    const float phi_yp = (phi[n.d] + pc) / 2.f;
+    const float phi_ym = (phi[n.u] + pc) / 2.f;
+
+    const float sumH = (xp * phi_xp + xm * phi_xm + yp * phi_yp + ym * phi_ym);
+    const float uc = u[n.c], vc = v[n.c];
+    const float sumU = phi_xp * xp * (u[n.r] + du[n.r] - uc) + phi_xm * xm * (u[n.l] + du[n.l] - uc) +
+                       phi_yp * yp * (u[n.d] + du[n.d] - uc) + phi_ym * ym * (u[n.u] + du[n.u] - uc);
+    const float sumV = phi_xp * xp * (v[n.r] + dv[n.r] - vc) + phi_xm * xm * (v[n.l] + dv[n.l] - vc) +
+                       phi_yp * yp * (v[n.d] + dv[n.d] - vc) + phi_ym * ym * (v[n.u] + dv[n.u] - vc);
+
+    const float k = ksi[n.c];
+    const float r_du = (k * (-J13 - J12 * dv[n.c]) + sumU) / (k * J11 + sumH);
+    const float r_dv = (k * (-J23 - J12 * r_du) + sumV) / (k * J22 + sumH);
+    tdu[n.c] = r_du;
+    tdv[n.c] = r_dv;
+}
+
+// ---- solve_2d: src/kernels/solve_2d.cu:200-377 ---------------------------------------------------
+__global__ __launch_bounds__(256) void sweep_grey_kernel(const float* __restrict__ f0, const float* __restrict__ f1,
+                                                         const float* __restrict__ u, const float* __restrict__ v,
+                                                         const float* __restrict__ du, const float* __restrict__ dv,
+                                                         const float* __restrict__ phi, const float* __restrict__ ksi,
+                                                         int w, int h, int pitch, float hx, float hy, float alpha,
+                                                         float* __restrict__ tdu, float* __restrict__ tdv)
+{
+    const int x = blockIdx.x * kBlockX + threadIdx.x;
+    const int y = blockIdx.y * kBlockY + threadIdx.y;
+    if (x >= w || y >= h) return;
+    const Neighbourhood n = neighbourhood(x, y, w, h, pitch);
+    float fx, fy, ft;
+    image_derivatives(f0, f1, n, hx, hy, fx, fy, ft);
+    jacobi_update(u, v, du, dv, phi, ksi, n, x, y, w, h, hx, hy, alpha, fx * fx, fy * fy, fx * fy, fx * ft, fy * ft,
+                  tdu, tdv);
+}
+
+// ---- solve_2d_grad: src/kernels/solve_2d.cu:683-952 ----------------------------------------------
+// The reference differentiates fx, fy, ft inside each 16x8 thread block with the block's own edge
+// value replicated into the halo (:816-841), so the motion tensor depends on that tiling.  A 64x8
+// workgroup here covers four such blocks; fx/fy/ft go through LDS and neighbours are taken with the
+// same replicate-at-16x8-edge rule.  Where the image edge falls inside a block the reference reads
+// an unwritten LDS slot (undefined); this kernel replicates the edge pixel there.
+constexpr int kGradTileX = 16;
+constexpr int kGradTileY = 8;
+
+__global__ __launch_bounds__(512) void sweep_grad_kernel(const float* __restrict__ f0, const float* __restrict__ f1,
+                                                         const float* __restrict__ u, const float* __restrict__ v,
+                                                         const float* __restrict__ du, const float* __restrict__ dv,
+                                                         const float* __restrict__ phi, const float* __restrict__ ksi,
+                                                         int w, int h, int pitch, float hx, float hy, float alpha,
+                                                         float* __restrict__ tdu, float* __restrict__ tdv)
+{
+    __shared__ float s_fx[kGradTileY][kBlockX];
+    __shared__ float s_fy[kGradTileY][kBlockX];
+    __shared__ float s_ft[kGradTileY][kBlockX];
+
+    const int tx = threadIdx.x, ty = threadIdx.y;
+    const int x = blockIdx.x * kBlockX + tx;
+    const int y = blockIdx.y * kGradTileY + ty;
+    const bool inside = x < w && y < h;
+    Neighbourhood n{};
+    if (inside) {
+        n = neighbourhood(x, y, w, h, pitch);
+        float fx, fy, ft;
+        image_derivatives(f0, f1, n, hx, hy, fx, fy, ft);
+        s_fx[ty][tx] = fx;
+        s_fy[ty][tx] = fy;
+        s_ft[ty][tx] = ft;
+    }
+    __syncthreads();
+    if (!inside) return;
+
+    const int xa = (tx % kGradTileX == 0) ? tx : tx - 1;
+    const int xb = (tx % kGradTileX == kGradTileX - 1 || x == w - 1) ? tx : tx + 1;
+    const int ya = (ty == 0) ? ty : ty - 1;
+    const int yb = (ty == kGradTileY - 1 || y == h - 1) ? ty : ty + 1;
+
+    const float hx_1 = 1.0 / (2.0 * hx);  // evaluated in double, rounded to float (solve_2d.cu:868-869)
+    const float hy_1 = 1.0 / (2.0 * hy);
+
+    const float fxx = (s_fx[ty][xb] - s_fx[ty][xa]) * hx_1;
+    const float fxy = (s_fx[yb][tx] - s_fx[ya][tx]) * hy_1;
+    const float fyy = (s_fy[yb][tx] - s_fy[ya][tx]) * hy_1;
+    const float fxt = (s_ft[ty][xb] - s_ft[ty][xa]) * hx_1;
+    const float fyt = (s_ft[yb][tx] - s_ft[ya][tx]) * hy_1;
+
+    const float J11 = fxx * fxx + fxy * fxy;
+    const float J22 = fxy * fxy + fyy * fyy;
+    const float J12 = fxx * fxy + fxy * fyy;
+    const float J13 = fxx * fxt + fxy * fyt;
+    const float J23 = fxy * fxt + fyy * fyt;
+    jacobi_update(u, v, du, dv, phi, ksi, n, x, y, w, h, hx, hy, alpha, J11, J22, J12, J13, J23, tdu, tdv);
+}
+
+bool solver_planes_ok(const float* const* planes, int count, size_t w, size_t h, size_t pitch_bytes)
+{
+    for (int i = 0; i < count; ++i)
+        if (!flow2d::plane_args_ok(planes[i], w, h, pitch_bytes)) return false;
+    return w >= 2 && h >= 2;
+}
+
+}  // namespace
+
+namespace flow2d {
+
+int launch_phi_ksi(flow2d_context* ctx, const float* f0, const float* f1, const float* u, const float* v,
+                   const float* du, const float* dv, size_t w, size_t h, size_t pitch_bytes, float hx, float hy,
+                   float e_smooth, float e_data, float* phi, float* ksi)
+{
+    const dim3 grid(div_up(w, kBlockX), div_up(h, kBlockY));
+    phi_ksi_kernel<<<grid, dim3(kBlockX, kBlockY), 0, ctx->stream>>>(f0, f1, u, v, du, dv, (int)w, (int)h,
+                                                                     (int)(pitch_bytes / 4), hx, hy, e_smooth, e_data,
+                                                                     phi, ksi);
+    FLOW2D_CHECK_LAUNCH();
+    return FLOW2D_OK;
+}
+
+int launch_sweep(flow2d_context* ctx, int constancy, const float* f0, const float* f1, const float* u, const float* v,
+                 const float* du, const float* dv, const float* phi, const float* ksi, size_t w, size_t h,
+                 size_t pitch_bytes, float hx, float hy, float alpha, float* tdu, float* tdv)
+{
+    if (constancy == FLOW2D_CONSTANCY_GRADIENT) {
+        const dim3 grid(div_up(w, kBlockX), div_up(h, kGradTileY));
+        sweep_grad_kernel<<<grid, dim3(kBlockX, kGradTileY), 0, ctx->stream>>>(
+            f0, f1, u, v, du, dv, phi, ksi, (int)w, (int)h, (int)(pitch_bytes / 4), hx, hy, alpha, tdu, tdv);
+    } else {
+        const dim3 grid(div_up(w, kBlockX), div_up(h, kBlockY));
+        sweep_grey_kernel<<<grid, dim3(kBlockX, kBlockY), 0, ctx->stream>>>(
+            f0, f1, u, v, du, dv, phi, ksi, (int)w, (int)h, (int)(pitch_bytes / 4), hx, hy, alpha, tdu, tdv);
+    }
+    FLOW2D_CHECK_LAUNCH();
+    return FLOW2D_OK;
+}
+
+}  // namespace flow2d
+
+extern "C" {
+
+int flow2d_compute_phi_ksi(flow2d_context* ctx, const float* frame_0, const float* frame_1, const float* flow_u,
+                           const float* flow_v, const float* flow_du, const float* flow_dv, size_t width,
+                           size_t height, size_t pitch_bytes, float hx, float hy, float equation_smoothness,
+                           float equation_data, float* phi, float* ksi)
+{
+    FLOW2D_ENTER(ctx);
+    const float* planes[] = {frame_0, frame_1, flow_u, flow_v, flow_du, flow_dv, phi, ksi};
+    if (!solver_planes_ok(planes, 8, width, height, pitch_bytes) || !(hx > 0.f) || !(hy > 0.f) || phi == ksi)
+        return FLOW2D_ERR_INVALID_ARGUMENT;
+    for (int i = 0; i < 6; ++i)
+        if (planes[i] == phi || planes[i] == ksi) return FLOW2D_ERR_INVALID_ARGUMENT;
+    return flow2d::launch_phi_ksi(ctx, frame_0, frame_1, flow_u, flow_v, flow_du, flow_dv, width, height, pitch_bytes,
+                                  hx, hy, equation_smoothness, equation_data, phi, ksi);
+}
+
+static int sweep_entry(flow2d_context* ctx, int constancy, const float* frame_0, const float* frame_1,
+                       const float* flow_u, const float* flow_v, const float* flow_du, const float* flow_dv,
+                       const float* phi, const float* ksi, size_t width, size_t height, size_t pitch_bytes, float hx,
+                       float hy, float alpha, float* temp_du, float* temp_dv)
+{
+    FLOW2D_ENTER(ctx);
+    const float* planes[] = {frame_0, frame_1, flow_u, flow_v, flow_du, flow_dv, phi, ksi, temp_du, temp_dv};
+    if (!solver_planes_ok(planes, 10, width, height, pitch_bytes) || !(hx > 0.f) || !(hy > 0.f) ||
+        temp_du == temp_dv)
+        return FLOW2D_ERR_INVALID_ARGUMENT;
+    for (int i = 0; i < 8; ++i)  // Jacobi: the sweep must not write a plane it reads
+        if (planes[i] == temp_du || planes[i] == temp_dv) return FLOW2D_ERR_INVALID_ARGUMENT;
+    return flow2d::launch_sweep(ctx, constancy, frame_0, frame_1, flow_u, flow_v, flow_du, flow_dv, phi, ksi, width,
+                                height, pitch_bytes, hx, hy, alpha, temp_du, temp_dv);
+}
+
+int flow2d_solve_2d(flow2d_context* ctx, const float* frame_0, const float* frame_1, const float* flow_u,
+                    const float* flow_v, const float* flow_du, const float* flow_dv, const float* phi,
+                    const float* ksi, size_t width, size_t height, size_t pitch_bytes, float hx, float hy,
+                    float equation_alpha, float* temp_du, float* temp_dv)
+{
+    return sweep_entry(ctx, FLOW2D_CONSTANCY_GREY, frame_0, frame_1, flow_u, flow_v, flow_du, flow_dv, phi, ksi,
+                       width, height, pitch_bytes, hx, hy, equation_alpha, temp_du, temp_dv);
+}
+
+int flow2d_solve_2d_grad(flow2d_context* ctx, const float* frame_0, const float* frame_1, const float* flow_u,
+                         const float* flow_v, const float* flow_du, const float* flow_dv, const float* phi,
+                         const float* ksi, size_t width, size_t height, size_t pitch_bytes, float hx, float hy,
+                         float equation_alpha, float* temp_du, float* temp_dv)
+{
+    return sweep_entry(ctx, FLOW2D_CONSTANCY_GRADIENT, frame_0, frame_1, flow_u, flow_v, flow_du, flow_dv, phi, ksi,
+                       width, height, pitch_bytes, hx, hy, equation_alpha, temp_du, temp_dv);
+}
+
+}  // extern "C"

@@ -1,0 +1,129 @@
+// The solver's fixed-point loop of one pyramid level and its launch timing.
+// Replaces the launch loop of CudaOperationSolve2D::Execute
+// (src/cuda_operations/2d/cuda_operation_solve_2d.cpp:229-300) without its per-sweep host
+// synchronisation (:291): everything is queued on the context's stream.
+#include <utility>
+
+#include "common.hpp"
+
+namespace flow2d {
+int launch_phi_ksi(flow2d_context* ctx, const float* f0, const float* f1, const float* u, const float* v,
+                   const float* du, const float* dv, size_t w, size_t h, size_t pitch_bytes, float hx, float hy,
+                   float e_smooth, float e_data, float* phi, float* ksi);
+int launch_sweep(flow2d_context* ctx, int constancy, const float* f0, const float* f1, const float* u, const float* v,
+                 const float* du, const float* dv, const float* phi, const float* ksi, size_t w, size_t h,
+                 size_t pitch_bytes, float hx, float hy, float alpha, float* tdu, float* tdv);
+}  // namespace flow2d
+
+extern "C" {
+
+int flow2d_solve_level(flow2d_context* ctx, const float* frame_0, const float* frame_1, const float* flow_u,
+                       const float* flow_v, float* flow_du, float* flow_dv, float* phi, float* ksi, float* temp_du,
+                       float* temp_dv, const flow2d_solve_params* p, int* result_in_temp)
+{
+    FLOW2D_ENTER(ctx);
+    if (!p || !result_in_temp) return FLOW2D_ERR_INVALID_ARGUMENT;
+    const float* planes[] = {frame_0, frame_1, flow_u, flow_v, flow_du, flow_dv, phi, ksi, temp_du, temp_dv};
+    for (int i = 0; i < 10; ++i) {
+        if (!flow2d::plane_args_ok(planes[i], p->width, p->height, p->pitch_bytes)) return FLOW2D_ERR_INVALID_ARGUMENT;
+        for (int j = 4; j < 10; ++j)  // the six written planes must be distinct from everything else
+            if (i != j && planes[i] == planes[j]) return FLOW2D_ERR_INVALID_ARGUMENT;
+    }
+    if (p->width < 2 || p->height < 2 || p->container_height < p->height || !(p->hx > 0.f) || !(p->hy > 0.f))
+        return FLOW2D_ERR_INVALID_ARGUMENT;
+    if (p->data_constancy != FLOW2D_CONSTANCY_GREY && p->data_constancy != FLOW2D_CONSTANCY_GRADIENT)
+        return FLOW2D_ERR_UNSUPPORTED;
+    if (p->algorithm < FLOW2D_SOLVER_AUTO || p->algorithm > FLOW2D_SOLVER_FUSED) return FLOW2D_ERR_INVALID_ARGUMENT;
+
+    int algorithm = FLOW2D_SOLVER_PER_SWEEP;
+
+    flow2d_timing_slot* slot = nullptr;
+    if (ctx->timing) {
+        flow2d_timing_slot s{};
+        FLOW2D_HIP_TRY(hipEventCreate(&s.start));
+        FLOW2D_HIP_TRY(hipEventCreate(&s.stop));
+        ctx->timings.push_back(s);
+        slot = &ctx->timings.back();
+        FLOW2D_HIP_TRY(hipEventRecord(slot->start, ctx->stream));
+    }
+
+    // du = dv = 0 over level width x container height (cuda_operation_solve_2d.cpp:229-232)
+    FLOW2D_HIP_TRY(hipMemset2DAsync(flow_du, p->pitch_bytes, 0, p->width * sizeof(float), p->container_height,
+                                    ctx->stream));
+    FLOW2D_HIP_TRY(hipMemset2DAsync(flow_dv, p->pitch_bytes, 0, p->width * sizeof(float), p->container_height,
+                                    ctx->stream));
+
+    float* du = flow_du;
+    float* dv = flow_dv;
+    float* tdu = temp_du;
+    float* tdv = temp_dv;
+    int launches = 0;
+    for (size_t i = 0; i < p->outer_iterations_count; ++i) {
+        int st = flow2d::launch_phi_ksi(ctx, frame_0, frame_1, flow_u, flow_v, du, dv, p->width, p->height,
+                                        p->pitch_bytes, p->hx, p->hy, p->equation_smoothness, p->equation_data, phi,
+                                        ksi);
+        if (st != FLOW2D_OK) return st;
+        for (size_t j = 0; j < p->inner_iterations_count; ++j) {
+            st = flow2d::launch_sweep(ctx, p->data_constancy, frame_0, frame_1, flow_u, flow_v, du, dv, phi, ksi,
+                                      p->width, p->height, p->pitch_bytes, p->hx, p->hy, p->equation_alpha, tdu, tdv);
+            if (st != FLOW2D_OK) return st;
+            std::swap(du, tdu);
+            std::swap(dv, tdv);
+            ++launches;
+        }
+    }
+    *result_in_temp = (du != flow_du) ? 1 : 0;
+
+    if (slot) {
+        FLOW2D_HIP_TRY(hipEventRecord(slot->stop, ctx->stream));
+        slot->rec.width = p->width;
+        slot->rec.height = p->height;
+        slot->rec.outer = p->outer_iterations_count;
+        slot->rec.inner = p->inner_iterations_count;
+        slot->rec.data_constancy = p->data_constancy;
+        slot->rec.algorithm = algorithm;
+        slot->rec.kernel_launches = launches;
+        slot->rec.elapsed_ms = -1.f;
+    }
+    return FLOW2D_OK;
+}
+
+int flow2d_timing_enable(flow2d_context* ctx, int enabled)
+{
+    if (!ctx) return FLOW2D_ERR_INVALID_ARGUMENT;
+    ctx->timing = enabled != 0;
+    return FLOW2D_OK;
+}
+
+int flow2d_timing_count(flow2d_context* ctx, size_t* count)
+{
+    if (!ctx || !count) return FLOW2D_ERR_INVALID_ARGUMENT;
+    *count = ctx->timings.size();
+    return FLOW2D_OK;
+}
+
+int flow2d_timing_get(flow2d_context* ctx, size_t index, flow2d_timing_record* out)
+{
+    FLOW2D_ENTER(ctx);
+    if (!out || index >= ctx->timings.size()) return FLOW2D_ERR_INVALID_ARGUMENT;
+    flow2d_timing_slot& s = ctx->timings[index];
+    if (s.rec.elapsed_ms < 0.f) {
+        FLOW2D_HIP_TRY(hipEventSynchronize(s.stop));
+        FLOW2D_HIP_TRY(hipEventElapsedTime(&s.rec.elapsed_ms, s.start, s.stop));
+    }
+    *out = s.rec;
+    return FLOW2D_OK;
+}
+
+int flow2d_timing_reset(flow2d_context* ctx)
+{
+    FLOW2D_ENTER(ctx);
+    for (auto& s : ctx->timings) {
+        (void)hipEventDestroy(s.start);
+        (void)hipEventDestroy(s.stop);
+    }
+    ctx->timings.clear();
+    return FLOW2D_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,209 @@
+/*
+ * flow2d_c_abi.h -- the C boundary of the MI355X (gfx950) optical-flow hot path.
+ *
+ * What it replaces.  axruff/cuda-flow2d binds its host code to device code purely by C symbol
+ * name: every operator class does cuModuleLoad("<exe>/kernels/<op>.ptx") + cuModuleGetFunction
+ * and launches through cuLaunchKernel with a void* argument array (e.g.
+ * src/cuda_operations/2d/cuda_operation_add_2d.cpp:50-55,96-103), and moves memory through the
+ * CUDA driver API (src/utils/cuda_utils.cpp:26-105, src/optical_flow/optical_flow_2d.cpp:84-140).
+ * This header is the drop-in for exactly that surface: device/context set-up, pitched plane
+ * memory, one launcher per reference kernel, the solver's fixed-point loop, events.  Plain
+ * pointers and sizes only; every function returns a flow2d_status (0 = ok) instead of printing.
+ *
+ * Conventions
+ *  - A "plane" is a row-major fp32 image inside a pitched container: element (x, y) lives at
+ *    base + y * pitch_bytes + 4 * x.  pitch_bytes is what DataSize3::pitch holds in the reference
+ *    (src/data_types/data_structs.h:31-35); it must be a multiple of 16.  A pyramid level of
+ *    w x h pixels occupies the top-left corner of a full-resolution container, as in the
+ *    reference (`container_size` module constant, IND(X,Y) macro of every .cu file).
+ *  - All launches go to the context's stream and return without synchronising.
+ *  - Device pointers are raw HIP device addresses (void* / float*), caller-owned.
+ *  - Not thread-safe per context; use one context per host thread / per GPU.
+ *  - Arithmetic is IEEE fp32 in the reference's operation order with no fused multiply-add
+ *    (kernels are built -ffp-contract=off), so results are bit-identical to the CPU oracle.
+ */
+#ifndef FLOW2D_C_ABI_H_
+#define FLOW2D_C_ABI_H_
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FLOW2D_API __attribute__((visibility("default")))
+
+#define FLOW2D_ABI_VERSION 1
+
+typedef enum flow2d_status {
+    FLOW2D_OK = 0,
+    FLOW2D_ERR_INVALID_ARGUMENT = 1, /* null pointer, bad size, in == out, misaligned pitch */
+    FLOW2D_ERR_NO_DEVICE = 2,        /* no usable HIP device / bad ordinal */
+    FLOW2D_ERR_DEVICE = 3,           /* a HIP runtime call failed; see flow2d_last_error() */
+    FLOW2D_ERR_OUT_OF_MEMORY = 4,
+    FLOW2D_ERR_UNSUPPORTED = 5       /* e.g. median window not in {3,5,7}, Gaussian longer than 51 taps */
+} flow2d_status;
+
+/* Mirrors `enum class DataConstancy` (src/data_types/data_structs.h:27). LogDerivatives (value 2)
+ * is out of scope and reported as FLOW2D_ERR_UNSUPPORTED. */
+typedef enum flow2d_constancy {
+    FLOW2D_CONSTANCY_GREY = 0,
+    FLOW2D_CONSTANCY_GRADIENT = 1
+} flow2d_constancy;
+
+typedef struct flow2d_context flow2d_context; /* opaque: device ordinal + stream + scratch */
+
+/* ---- library / errors ------------------------------------------------------------------ */
+FLOW2D_API int flow2d_abi_version(void);
+FLOW2D_API const char* flow2d_status_string(int status);
+/* Text of the last failing HIP call on this thread ("" if none). */
+FLOW2D_API const char* flow2d_last_error(void);
+
+/* ---- device / context  (replaces InitCudaContextWithFirstAvailableDevice,
+ *      src/utils/cuda_utils.cpp:26-62, and cuCtxDestroy at src/main.cpp:226) ----------------- */
+FLOW2D_API int flow2d_device_count(int* count);
+FLOW2D_API int flow2d_context_create(int device_ordinal, flow2d_context** out_ctx);
+/* Same, but launches on an existing hipStream_t owned by the caller (e.g. a PyTorch stream). */
+FLOW2D_API int flow2d_context_create_on_stream(int device_ordinal, void* hip_stream, flow2d_context** out_ctx);
+FLOW2D_API int flow2d_context_destroy(flow2d_context* ctx);
+FLOW2D_API int flow2d_context_device(const flow2d_context* ctx, int* device_ordinal);
+FLOW2D_API int flow2d_context_stream(const flow2d_context* ctx, void** hip_stream);
+FLOW2D_API int flow2d_synchronize(flow2d_context* ctx); /* cuStreamSynchronize(NULL), cuda_operation_solve_2d.cpp:291 */
+/* cuMemGetInfo, optical_flow_2d.cpp:91 */
+FLOW2D_API int flow2d_mem_info(flow2d_context* ctx, size_t* free_bytes, size_t* total_bytes);
+FLOW2D_API int flow2d_device_name(flow2d_context* ctx, char* buf, size_t buf_len);
+
+/* ---- pitched plane memory  (replaces cuMemAllocPitch / cuMemFree / cuMemsetD2D8 / cuMemcpy2D /
+ *      cuMemcpyDtoD: optical_flow_2d.cpp:114-133,309-312,574-577; cuda_utils.cpp:66-105;
+ *      cuda_operation_median_2d.cpp:100-104) -------------------------------------------------- */
+/* Row pitch this library uses for a plane of `width` floats (multiple of 256 bytes). */
+FLOW2D_API size_t flow2d_plane_pitch_bytes(size_t width);
+FLOW2D_API int flow2d_plane_alloc(flow2d_context* ctx, size_t width, size_t height, void** out_dev_ptr,
+                                  size_t* out_pitch_bytes);
+FLOW2D_API int flow2d_plane_free(flow2d_context* ctx, void* dev_ptr);
+FLOW2D_API int flow2d_memset_2d(flow2d_context* ctx, void* dev_ptr, size_t pitch_bytes, int byte_value,
+                                size_t width_bytes, size_t height);
+FLOW2D_API int flow2d_copy_h2d_2d(flow2d_context* ctx, void* dst_dev, size_t dst_pitch_bytes, const void* src_host,
+                                  size_t src_pitch_bytes, size_t width_bytes, size_t height);
+FLOW2D_API int flow2d_copy_d2h_2d(flow2d_context* ctx, void* dst_host, size_t dst_pitch_bytes, const void* src_dev,
+                                  size_t src_pitch_bytes, size_t width_bytes, size_t height);
+FLOW2D_API int flow2d_copy_d2d(flow2d_context* ctx, void* dst_dev, const void* src_dev, size_t bytes);
+
+/* ---- events  (replaces cuEventCreate/Record/Synchronize/ElapsedTime/Destroy,
+ *      optical_flow_2d.cpp:173-179,548-557; cuda_operation_solve_2d.cpp:214-220,302-313) ------- */
+FLOW2D_API int flow2d_event_create(flow2d_context* ctx, void** out_event);
+FLOW2D_API int flow2d_event_record(flow2d_context* ctx, void* event);
+FLOW2D_API int flow2d_event_synchronize(flow2d_context* ctx, void* event);
+FLOW2D_API int flow2d_event_elapsed_ms(flow2d_context* ctx, void* start_event, void* stop_event, float* out_ms);
+FLOW2D_API int flow2d_event_destroy(flow2d_context* ctx, void* event);
+
+/* ---- kernel launchers: one per `extern "C" __global__` symbol of src/kernels/ -------------- */
+
+/* add_2d (src/kernels/add_2d.cu:33-46): operand_0 += operand_1 on w x h. */
+FLOW2D_API int flow2d_add_2d(flow2d_context* ctx, float* operand_0, const float* operand_1, size_t width,
+                             size_t height, size_t pitch_bytes);
+
+/* Host-side Gaussian taps, CudaOperationConvolution2D::ComputeGaussianKernel(sigma, 3, 1.0)
+ * (src/cuda_operations/2d/cuda_operation_convolution_2d.cpp:83-112).  taps must hold 51 floats
+ * (MAX_KERNEL_LENGTH, convolution_2d.cu:49); writes 2*radius+1 of them. */
+FLOW2D_API int flow2d_gaussian_kernel(float sigma, float* taps, int* out_radius);
+
+/* convolutionRowsKernel / convolutionColumnsKernel (src/kernels/convolution_2d.cu:74-168,181-261).
+ * `taps` is a HOST array of 2*radius+1 floats (the reference uploads it to the module constant
+ * c_Kernel, cuda_operation_convolution_2d.cpp:163-164).  Zero padding outside the image. */
+FLOW2D_API int flow2d_convolution_rows(flow2d_context* ctx, float* dst, const float* src, size_t width, size_t height,
+                                       size_t pitch_bytes, const float* taps, int radius);
+FLOW2D_API int flow2d_convolution_columns(flow2d_context* ctx, float* dst, const float* src, size_t width,
+                                          size_t height, size_t pitch_bytes, const float* taps, int radius);
+
+/* median_2d (src/kernels/median_2d.cu:87-299): `window` is the window width (3, 5 or 7; the
+ * reference calls it "radius"), mirror borders. */
+FLOW2D_API int flow2d_median_2d(flow2d_context* ctx, const float* input, size_t width, size_t height,
+                                size_t pitch_bytes, size_t window, float* output);
+
+/* registration_2d (src/kernels/registration_2d.cu:34-73): backward bilinear warp of frame_1. */
+FLOW2D_API int flow2d_registration_2d(flow2d_context* ctx, const float* frame_0, const float* frame_1,
+                                      const float* flow_u, const float* flow_v, size_t width, size_t height,
+                                      size_t pitch_bytes, float hx, float hy, float* output);
+
+/* resample_x / resample_y (src/kernels/resample_2d.cu:34-75,77-118): area-weighted 1-D resample. */
+FLOW2D_API int flow2d_resample_x(flow2d_context* ctx, const float* input, float* output, size_t out_width,
+                                 size_t out_height, size_t in_width, size_t pitch_bytes);
+FLOW2D_API int flow2d_resample_y(flow2d_context* ctx, const float* input, float* output, size_t out_width,
+                                 size_t out_height, size_t in_height, size_t pitch_bytes);
+
+/* compute_phi_ksi (src/kernels/solve_2d.cu:43-198). */
+FLOW2D_API int flow2d_compute_phi_ksi(flow2d_context* ctx, const float* frame_0, const float* frame_1,
+                                      const float* flow_u, const float* flow_v, const float* flow_du,
+                                      const float* flow_dv, size_t width, size_t height, size_t pitch_bytes, float hx,
+                                      float hy, float equation_smoothness, float equation_data, float* phi,
+                                      float* ksi);
+
+/* solve_2d (src/kernels/solve_2d.cu:200-377): one Jacobi sweep, brightness constancy. */
+FLOW2D_API int flow2d_solve_2d(flow2d_context* ctx, const float* frame_0, const float* frame_1, const float* flow_u,
+                               const float* flow_v, const float* flow_du, const float* flow_dv, const float* phi,
+                               const float* ksi, size_t width, size_t height, size_t pitch_bytes, float hx, float hy,
+                               float equation_alpha, float* temp_du, float* temp_dv);
+
+/* solve_2d_grad (src/kernels/solve_2d.cu:683-952): one Jacobi sweep, gradient constancy, including
+ * the reference's 16x8 block rule for the second derivatives. */
+FLOW2D_API int flow2d_solve_2d_grad(flow2d_context* ctx, const float* frame_0, const float* frame_1,
+                                    const float* flow_u, const float* flow_v, const float* flow_du,
+                                    const float* flow_dv, const float* phi, const float* ksi, size_t width,
+                                    size_t height, size_t pitch_bytes, float hx, float hy, float equation_alpha,
+                                    float* temp_du, float* temp_dv);
+
+/* ---- the solver's fixed-point loop of one level -------------------------------------------
+ * Replaces the launch loop of CudaOperationSolve2D::Execute
+ * (src/cuda_operations/2d/cuda_operation_solve_2d.cpp:229-300): zero du/dv (level width x
+ * container_height rows), then outer x [compute_phi_ksi, inner x (sweep, swap)].  The library
+ * owns the ping-pong; *result_in_temp tells the caller which pair holds the result (0: flow_du /
+ * flow_dv, 1: temp_du / temp_dv), so a host wrapper can swap its own pointers like the reference
+ * does (:288-289).  No host synchronisation inside.  `algorithm`: see flow2d_solver_algorithm. */
+typedef enum flow2d_solver_algorithm {
+    FLOW2D_SOLVER_AUTO = 0,      /* library picks the fastest bit-exact path for the level size */
+    FLOW2D_SOLVER_PER_SWEEP = 1, /* one launch per reference kernel launch (K6, K7/K9) */
+    FLOW2D_SOLVER_FUSED = 2      /* one launch per outer iteration: phi/ksi + all inner sweeps fused */
+} flow2d_solver_algorithm;
+
+typedef struct flow2d_solve_params {
+    size_t width, height;        /* level size */
+    size_t pitch_bytes;          /* container pitch */
+    size_t container_height;     /* rows of the full-resolution container (memset extent) */
+    float hx, hy;                /* grid spacing of the level */
+    float equation_alpha;
+    float equation_smoothness;
+    float equation_data;
+    size_t outer_iterations_count;
+    size_t inner_iterations_count;
+    int data_constancy;          /* flow2d_constancy */
+    int algorithm;               /* flow2d_solver_algorithm */
+} flow2d_solve_params;
+
+FLOW2D_API int flow2d_solve_level(flow2d_context* ctx, const float* frame_0, const float* frame_1,
+                                  const float* flow_u, const float* flow_v, float* flow_du, float* flow_dv,
+                                  float* phi, float* ksi, float* temp_du, float* temp_dv,
+                                  const flow2d_solve_params* params, int* result_in_temp);
+
+/* ---- launch timing of the solver (measurement only; bench.py's roofline leg) ----------------
+ * When enabled, every flow2d_solve_level call is bracketed by a pair of events on the context's
+ * stream (no synchronisation).  After flow2d_synchronize the records can be read back. */
+typedef struct flow2d_timing_record {
+    size_t width, height;
+    size_t outer, inner;
+    int data_constancy;
+    int algorithm;          /* the algorithm actually used */
+    int kernel_launches;    /* launches of the dominant solver kernel inside the bracket */
+    float elapsed_ms;       /* event time of the whole solve call */
+} flow2d_timing_record;
+
+FLOW2D_API int flow2d_timing_enable(flow2d_context* ctx, int enabled);
+FLOW2D_API int flow2d_timing_count(flow2d_context* ctx, size_t* count);
+FLOW2D_API int flow2d_timing_get(flow2d_context* ctx, size_t index, flow2d_timing_record* out);
+FLOW2D_API int flow2d_timing_reset(flow2d_context* ctx);
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif /* FLOW2D_C_ABI_H_ */

@@ -1,0 +1,123 @@
+"""Per-kernel parity of the HIP path (through the C-ABI) against the CPU oracle: bit-exact.
+
+Each case places the level in the top-left corner of a larger container, like the reference's
+full-resolution pitched planes, and uses sizes that are not tile multiples.
+"""
+import numpy as np
+import pytest
+
+from conftest import in_container, level_fields
+
+pytestmark = pytest.mark.gpu
+
+# (level w, level h, container w, container h)
+SIZES = [(100, 70, 128, 80), (64, 64, 64, 64), (5, 4, 40, 30), (257, 33, 300, 40), (16, 8, 16, 8)]
+
+
+def up(ctx, a, cw, ch, fill=0.0):
+    return ctx.plane(cw, ch, in_container(a, cw, ch, fill))
+
+
+@pytest.mark.parametrize("w,h,cw,ch", SIZES)
+def test_add(ctx, oracle, w, h, cw, ch):
+    f0, f1, *_ = level_fields(oracle, w, h, 1)
+    a, b = up(ctx, f0, cw, ch, 7.0), up(ctx, f1, cw, ch, 9.0)
+    ctx.add(a, b, w, h)
+    got = a.download()
+    assert np.array_equal(got[:h, :w], oracle.add(f0, f1, w, h))
+    # nothing outside the level rectangle is touched
+    assert np.all(got[h:, :] == 7.0) and np.all(got[:, w:] == 7.0)
+
+
+@pytest.mark.parametrize("sigma", [0.45, 1.5, 3.0])
+@pytest.mark.parametrize("w,h,cw,ch", SIZES)
+def test_gaussian(ctx, flow2d, oracle, w, h, cw, ch, sigma):
+    f0, *_ = level_fields(oracle, w, h, 2)
+    taps, r = flow2d.gaussian_kernel(sigma)
+    otaps, orad = oracle.gaussian_taps(sigma)
+    assert r == orad and np.array_equal(taps, otaps)
+    src, tmp, dst = up(ctx, f0, cw, ch, 5.0), ctx.plane(cw, ch), ctx.plane(cw, ch)
+    ctx.convolution_rows(tmp, src, w, h, taps, r)
+    ctx.convolution_columns(dst, tmp, w, h, taps, r)
+    assert np.array_equal(dst.download(w, h), oracle.convolution(f0, w, h, sigma))
+
+
+@pytest.mark.parametrize("w,h,ow,oh", [(100, 70, 80, 64), (100, 70, 37, 20), (100, 70, 13, 9), (100, 70, 5, 4),
+                                       (37, 20, 100, 70), (64, 64, 32, 32), (33, 17, 34, 18)])
+def test_resample(ctx, oracle, w, h, ow, oh):
+    cw, ch = max(w, ow) + 3, max(h, oh) + 2
+    f0, *_ = level_fields(oracle, w, h, 3)
+    src, tmp, dst = up(ctx, f0, cw, ch), ctx.plane(cw, ch), ctx.plane(cw, ch)
+    ctx.resample_x(src, tmp, ow, h, w)
+    ctx.resample_y(tmp, dst, ow, oh, h)
+    want = oracle.resample(in_container(f0, cw, ch), w, h, ow, oh)[:oh, :ow]
+    assert np.array_equal(dst.download(ow, oh), want)
+
+
+@pytest.mark.parametrize("hx,hy", [(1.0, 1.0), (1.25, 1.1), (7.3, 5.5)])
+@pytest.mark.parametrize("w,h,cw,ch", SIZES)
+def test_registration(ctx, oracle, w, h, cw, ch, hx, hy):
+    f0, f1, u, v, *_ = level_fields(oracle, w, h, 4, flow_scale=4.0)
+    u[0, 0] = np.nan           # NaN and far out-of-range displacements fall back to frame_0
+    v[h - 1, w - 1] = 1e9
+    u[h // 2, w // 2] = -1e9
+    planes = [up(ctx, a, cw, ch) for a in (f0, f1, u, v)]
+    out = ctx.plane(cw, ch)
+    ctx.registration(*planes, w, h, hx, hy, out)
+    assert np.array_equal(out.download(w, h), oracle.registration(f0, f1, u, v, w, h, hx, hy))
+
+
+@pytest.mark.parametrize("hx,hy", [(1.0, 1.0), (1.25, 1.1)])
+@pytest.mark.parametrize("w,h,cw,ch", SIZES)
+def test_phi_ksi_and_sweeps(ctx, flow2d, oracle, w, h, cw, ch, hx, hy):
+    f0, f1, u, v, du, dv = level_fields(oracle, w, h, 5)
+    d = [up(ctx, a, cw, ch, 3.0) for a in (f0, f1, u, v, du, dv)]
+    phi, ksi, tdu, tdv = (ctx.plane(cw, ch) for _ in range(4))
+    ctx.compute_phi_ksi(*d, w, h, hx, hy, 0.001, 0.001, phi, ksi)
+    ophi, oksi = oracle.compute_phi_ksi(f0, f1, u, v, du, dv, w, h, hx, hy, 0.001, 0.001)
+    assert np.array_equal(phi.download(w, h), ophi)
+    assert np.array_equal(ksi.download(w, h), oksi)
+    for constancy in (flow2d.GREY, flow2d.GRADIENT):
+        ctx.solve_sweep(*d, phi, ksi, w, h, hx, hy, 35.0, tdu, tdv, constancy)
+        odu, odv = oracle.solve_sweep(f0, f1, u, v, du, dv, ophi, oksi, w, h, hx, hy, 35.0, constancy)
+        assert np.array_equal(tdu.download(w, h), odu), "du constancy %d" % constancy
+        assert np.array_equal(tdv.download(w, h), odv), "dv constancy %d" % constancy
+
+
+@pytest.mark.parametrize("window", [3, 5, 7])
+@pytest.mark.parametrize("w,h,cw,ch", SIZES)
+def test_median(ctx, oracle, w, h, cw, ch, window):
+    _, _, u, *_ = level_fields(oracle, w, h, 6)
+    u[::3, ::5] = 0.0  # ties
+    src, dst = up(ctx, u, cw, ch, 99.0), ctx.plane(cw, ch)
+    ctx.median(src, w, h, window, dst)
+    assert np.array_equal(dst.download(w, h), oracle.median(u, w, h, window))
+
+
+def test_median_rejects_bad_window(ctx, flow2d, oracle):
+    src, dst = ctx.plane(32, 32), ctx.plane(32, 32)
+    for bad in (0, 1, 2, 4, 9):
+        with pytest.raises(flow2d.Flow2DError) as e:
+            ctx.median(src, 32, 32, bad, dst)
+        assert e.value.status == 5
+    with pytest.raises(flow2d.Flow2DError) as e:
+        ctx.median(src, 32, 32, 5, src)  # in == out
+    assert e.value.status == 1
+
+
+@pytest.mark.parametrize("algorithm", [1, 0])
+@pytest.mark.parametrize("constancy", [0, 1])
+@pytest.mark.parametrize("outer,inner", [(2, 3), (3, 2), (1, 5)])
+@pytest.mark.parametrize("w,h,cw,ch", SIZES[:4])
+def test_solve_level(ctx, oracle, w, h, cw, ch, outer, inner, constancy, algorithm):
+    f0, f1, u, v, _, _ = level_fields(oracle, w, h, 7)
+    hx, hy = np.float32(cw / w), np.float32(ch / h)
+    d = [up(ctx, a, cw, ch) for a in (f0, f1, u, v)]
+    du, dv, phi, ksi, tdu, tdv = (ctx.plane(cw, ch).fill_bytes(0x7f) for _ in range(6))
+    rdu, rdv = ctx.solve_level(*d, du, dv, phi, ksi, tdu, tdv, w, h, hx, hy, 3.5, 0.001, 0.001, outer, inner,
+                               constancy, algorithm)
+    odu, odv, ophi, oksi = oracle.solve_level(f0, f1, u, v, w, h, hx, hy, 3.5, 0.001, 0.001, outer, inner, constancy)
+    assert np.array_equal(rdu.download(w, h), odu)
+    assert np.array_equal(rdv.download(w, h), odv)
+    # the pointer-swap contract of the reference (cuda_operation_solve_2d.cpp:288-289)
+    assert (rdu is tdu) == ((outer * inner) % 2 == 1)
