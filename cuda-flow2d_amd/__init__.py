@@ -308,3 +308,147 @@ class Context:
 
     def timing_reset(self):
         _check(hip_lib().flow2d_timing_reset(self.handle), "flow2d_timing_reset")
+
+
+# ---- C++ host layer (OpticalFlow2D & friends) through its C facade ---------------------------------
+
+class HostParams(C.Structure):
+    _fields_ = [
+        ("warp_levels_count", C.c_size_t), ("warp_scale_factor", C.c_float),
+        ("outer_iterations_count", C.c_size_t), ("inner_iterations_count", C.c_size_t),
+        ("equation_alpha", C.c_float), ("equation_smoothness", C.c_float), ("equation_data", C.c_float),
+        ("median_radius", C.c_size_t), ("gaussian_sigma", C.c_float), ("solver_algorithm", C.c_int),
+    ]
+
+
+class HostSettings(C.Structure):
+    _fields_ = [
+        ("width", C.c_int), ("height", C.c_int), ("medianRadius", C.c_int), ("iterInner", C.c_int),
+        ("iterOuter", C.c_int), ("levels", C.c_int), ("press_key", C.c_int),
+        ("sigma", C.c_float), ("alpha", C.c_float), ("e_smooth", C.c_float), ("e_data", C.c_float),
+        ("warpScale", C.c_float),
+        ("inputPath", C.c_char * 512), ("outputPath", C.c_char * 512), ("fileName1", C.c_char * 256),
+        ("fileName2", C.c_char * 256), ("imageType", C.c_char * 32), ("dataConstancy", C.c_char * 32),
+    ]
+
+
+_host = None
+
+
+def host_lib():
+    """The C++ host layer.  Raises if it has not been built."""
+    global _host
+    if _host is None:
+        hip_lib()
+        if not os.path.exists(HOST_LIB_PATH):
+            raise ImportError("%s is missing: run __graft_entry__.build()" % HOST_LIB_PATH)
+        L = C.CDLL(HOST_LIB_PATH)
+        vp, sz, f, i = C.c_void_p, C.c_size_t, C.c_float, C.c_int
+        fp = C.POINTER(C.c_float)
+        L.flow2d_host_init_device.argtypes = [i]
+        L.flow2d_host_adopt_context.argtypes = [vp]
+        L.flow2d_host_context.restype = vp
+        L.flow2d_host_flow_create.restype = vp
+        L.flow2d_host_flow_create.argtypes = [sz, sz, i, i]
+        L.flow2d_host_flow_destroy.argtypes = [vp]
+        L.flow2d_host_flow_pitch.restype = sz
+        L.flow2d_host_flow_pitch.argtypes = [vp]
+        L.flow2d_host_max_warp_level.restype = sz
+        L.flow2d_host_max_warp_level.argtypes = [vp, sz, sz, f]
+        L.flow2d_host_compute_flow.argtypes = [vp, fp, fp, fp, fp, C.POINTER(HostParams), fp]
+        L.flow2d_host_compute_flow_device.argtypes = [vp, vp, vp, vp, vp, C.POINTER(HostParams), i]
+        L.flow2d_host_level_timings.restype = sz
+        L.flow2d_host_level_timings.argtypes = [vp, fp, sz]
+        L.flow2d_host_missing_key_leaves_outputs.argtypes = [vp, C.c_char_p]
+        L.flow2d_host_read_raw.argtypes = [C.c_char_p, sz, sz, i, fp]
+        L.flow2d_host_write_outputs.argtypes = [fp, fp, sz, sz, C.c_char_p, C.c_char_p, f]
+        L.flow2d_host_convert_to_rgb.argtypes = [f, f, C.POINTER(i)]
+        L.flow2d_host_load_settings.argtypes = [C.c_char_p, C.POINTER(HostSettings)]
+        _host = L
+    return _host
+
+
+def _fptr(a):
+    return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+class OpticalFlow:
+    """OpticalFlow2D of the host layer (Initialize / ComputeFlow / ComputeFlowDevice / Destroy)."""
+
+    def __init__(self, width, height, constancy=GREY, device=0, ctx=None, silent=True):
+        L = host_lib()
+        if ctx is not None:
+            L.flow2d_host_adopt_context(ctx.handle)
+        elif L.flow2d_host_init_device(device) != 0:
+            raise Flow2DError(2, "InitDeviceContext")
+        self.width, self.height = width, height
+        self.handle = L.flow2d_host_flow_create(width, height, constancy, int(silent))
+        if not self.handle:
+            raise Flow2DError(1, "OpticalFlow2D::Initialize")
+        self.pitch = L.flow2d_host_flow_pitch(self.handle)
+
+    @staticmethod
+    def params(levels, scale, outer, inner, alpha, e_smooth, e_data, median_radius, sigma, algorithm=SOLVER_AUTO):
+        return HostParams(levels, scale, outer, inner, alpha, e_smooth, e_data, median_radius, sigma, algorithm)
+
+    def max_warp_level(self, width, height, scale):
+        return host_lib().flow2d_host_max_warp_level(self.handle, width, height, scale)
+
+    def compute_flow(self, frame_0, frame_1, params):
+        """Host images in, host flow out (upload + pyramid + download).  Returns (u, v, device_ms)."""
+        f0 = np.ascontiguousarray(frame_0, np.float32)
+        f1 = np.ascontiguousarray(frame_1, np.float32)
+        assert f0.shape == (self.height, self.width) and f1.shape == f0.shape
+        u = np.empty_like(f0)
+        v = np.empty_like(f0)
+        ms = C.c_float()
+        rc = host_lib().flow2d_host_compute_flow(self.handle, _fptr(f0), _fptr(f1), _fptr(u), _fptr(v),
+                                                 C.byref(params), C.byref(ms))
+        if rc:
+            raise Flow2DError(rc, "OpticalFlow2D::ComputeFlow")
+        return u, v, ms.value
+
+    def compute_flow_device(self, dev_f0, dev_f1, dev_u, dev_v, params, collect_level_timings=False):
+        """Device-resident pair (raw device addresses of pitched containers); queued, not synchronised."""
+        rc = host_lib().flow2d_host_compute_flow_device(self.handle, dev_f0, dev_f1, dev_u, dev_v, C.byref(params),
+                                                        int(collect_level_timings))
+        if rc:
+            raise Flow2DError(rc, "OpticalFlow2D::ComputeFlowDevice")
+
+    def level_timings(self):
+        buf = np.zeros(3 * 64, np.float32)
+        n = host_lib().flow2d_host_level_timings(self.handle, _fptr(buf), 64)
+        return [(int(buf[3 * i]), int(buf[3 * i + 1]), float(buf[3 * i + 2])) for i in range(min(n, 64))]
+
+    def missing_key_leaves_outputs(self, key):
+        return host_lib().flow2d_host_missing_key_leaves_outputs(self.handle, key.encode())
+
+    def close(self):
+        if self.handle:
+            host_lib().flow2d_host_flow_destroy(self.handle)
+            self.handle = None
+
+
+def read_raw(path, width, height, u8):
+    out = np.empty((height, width), np.float32)
+    rc = host_lib().flow2d_host_read_raw(path.encode(), width, height, int(u8), _fptr(out))
+    return out if rc == 0 else None
+
+
+def write_outputs(u, v, ppm_path, amp_path, flow_max_scale=10.0):
+    u = np.ascontiguousarray(u, np.float32)
+    v = np.ascontiguousarray(v, np.float32)
+    host_lib().flow2d_host_write_outputs(_fptr(u), _fptr(v), u.shape[1], u.shape[0], ppm_path.encode(),
+                                         amp_path.encode(), flow_max_scale)
+
+
+def convert_to_rgb(x, y):
+    rgb = (C.c_int * 3)()
+    host_lib().flow2d_host_convert_to_rgb(x, y, rgb)
+    return tuple(rgb)
+
+
+def load_settings(path):
+    s = HostSettings()
+    rc = host_lib().flow2d_host_load_settings(path.encode(), C.byref(s))
+    return s if rc == 0 else None

@@ -1,0 +1,216 @@
+// C facade over the C++ host layer, for the Python tests and bench.py (plumbing only).
+// It drives the same OpticalFlow2D / OperationParameters objects a C++ caller would.
+#include <cstdint>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "device_utils.h"
+#include "io_utils.h"
+#include "optical_flow_2d.h"
+#include "settings.h"
+
+#define HOST_API extern "C" __attribute__((visibility("default")))
+
+struct flow2d_host_params {
+    size_t warp_levels_count;
+    float warp_scale_factor;
+    size_t outer_iterations_count;
+    size_t inner_iterations_count;
+    float equation_alpha;
+    float equation_smoothness;
+    float equation_data;
+    size_t median_radius;
+    float gaussian_sigma;
+    int solver_algorithm;
+};
+
+struct flow2d_host_flow {
+    OpticalFlow2D flow;
+    size_t width = 0, height = 0;
+};
+
+namespace {
+void FillBag(OperationParameters& bag, flow2d_host_params& p)
+{
+    bag.PushValuePtr("warp_levels_count", &p.warp_levels_count);
+    bag.PushValuePtr("warp_scale_factor", &p.warp_scale_factor);
+    bag.PushValuePtr("outer_iterations_count", &p.outer_iterations_count);
+    bag.PushValuePtr("inner_iterations_count", &p.inner_iterations_count);
+    bag.PushValuePtr("equation_alpha", &p.equation_alpha);
+    bag.PushValuePtr("equation_smoothness", &p.equation_smoothness);
+    bag.PushValuePtr("equation_data", &p.equation_data);
+    bag.PushValuePtr("median_radius", &p.median_radius);
+    bag.PushValuePtr("gaussian_sigma", &p.gaussian_sigma);
+    bag.PushValuePtr("solver_algorithm", &p.solver_algorithm);
+}
+}  // namespace
+
+// Process-wide context on `device` (InitDeviceContext).  0 on success.
+HOST_API int flow2d_host_init_device(int device) { return InitDeviceContext(device) ? 0 : 1; }
+HOST_API void flow2d_host_adopt_context(flow2d_context* ctx) { AdoptDeviceContext(ctx); }
+HOST_API flow2d_context* flow2d_host_context(void) { return CurrentDeviceContext(); }
+HOST_API void flow2d_host_shutdown(void) { DestroyDeviceContext(); }
+
+// constancy: 0 Grey, 1 Gradient, 2 LogDerivatives (refused).  Returns nullptr on failure.
+HOST_API flow2d_host_flow* flow2d_host_flow_create(size_t width, size_t height, int constancy, int silent)
+{
+    flow2d_host_flow* h = new (std::nothrow) flow2d_host_flow();
+    if (!h) return nullptr;
+    h->flow.silent = silent != 0;
+    DataSize3 size = {width, height, 1};
+    if (!h->flow.Initialize(size, static_cast<DataConstancy>(constancy))) {
+        delete h;
+        return nullptr;
+    }
+    h->width = width;
+    h->height = height;
+    return h;
+}
+
+HOST_API void flow2d_host_flow_destroy(flow2d_host_flow* h)
+{
+    if (!h) return;
+    h->flow.Destroy();
+    delete h;
+}
+
+HOST_API size_t flow2d_host_flow_pitch(flow2d_host_flow* h) { return h ? h->flow.ContainerSize().pitch : 0; }
+
+HOST_API size_t flow2d_host_max_warp_level(flow2d_host_flow* h, size_t width, size_t height, float scale)
+{
+    return h ? h->flow.GetMaxWarpLevel(width, height, scale) : 0;
+}
+
+// OpticalFlow2D::ComputeFlow on tight host images (width*height floats each).  0 on success.
+HOST_API int flow2d_host_compute_flow(flow2d_host_flow* h, const float* frame_0, const float* frame_1, float* flow_u,
+                                      float* flow_v, const flow2d_host_params* params, float* total_ms)
+{
+    if (!h || !frame_0 || !frame_1 || !flow_u || !flow_v || !params) return 1;
+    const size_t n = h->width * h->height;
+    Data2D f0(h->width, h->height), f1(h->width, h->height), u(h->width, h->height), v(h->width, h->height);
+    std::memcpy(f0.DataPtr(), frame_0, n * sizeof(float));
+    std::memcpy(f1.DataPtr(), frame_1, n * sizeof(float));
+    // poison the outputs so that an aborted run (missing key, bad parameter) is visible to the caller
+    for (size_t i = 0; i < n; ++i) u.DataPtr()[i] = v.DataPtr()[i] = -12345.f;
+    flow2d_host_params p = *params;
+    OperationParameters bag;
+    FillBag(bag, p);
+    h->flow.ComputeFlow(f0, f1, u, v, bag);
+    std::memcpy(flow_u, u.DataPtr(), n * sizeof(float));
+    std::memcpy(flow_v, v.DataPtr(), n * sizeof(float));
+    if (total_ms) *total_ms = h->flow.LastTotalMs();
+    return 0;
+}
+
+// OpticalFlow2D::ComputeFlowDevice: frames and flow already in pitched device containers.  Queued on
+// the context's stream, no synchronisation.  0 on success.
+HOST_API int flow2d_host_compute_flow_device(flow2d_host_flow* h, void* dev_frame_0, void* dev_frame_1,
+                                             void* dev_flow_u, void* dev_flow_v, const flow2d_host_params* params,
+                                             int collect_level_timings)
+{
+    if (!h || !params) return 1;
+    flow2d_host_params p = *params;
+    OperationParameters bag;
+    FillBag(bag, p);
+    h->flow.collect_level_timings = collect_level_timings != 0;
+    auto dp = [](void* q) { return static_cast<DevicePtr>(reinterpret_cast<uintptr_t>(q)); };
+    return h->flow.ComputeFlowDevice(dp(dev_frame_0), dp(dev_frame_1), dp(dev_flow_u), dp(dev_flow_v), bag) ? 0 : 2;
+}
+
+// Per-level solve times of the last run (needs collect_level_timings and a synchronised context).
+// Writes up to `capacity` triples (width, height, ms) and returns the number of levels.
+HOST_API size_t flow2d_host_level_timings(flow2d_host_flow* h, float* triples, size_t capacity)
+{
+    if (!h) return 0;
+    std::vector<FlowLevelTiming> t = h->flow.LastLevelTimings();
+    for (size_t i = 0; i < t.size() && i < capacity; ++i) {
+        triples[3 * i + 0] = static_cast<float>(t[i].width);
+        triples[3 * i + 1] = static_cast<float>(t[i].height);
+        triples[3 * i + 2] = t[i].solve_ms;
+    }
+    return t.size();
+}
+
+// Omitting a bag key must make ComputeFlow print and return with the outputs untouched
+// (optical_flow_2d.cpp:160-168).  Returns 1 if the outputs were left untouched.
+HOST_API int flow2d_host_missing_key_leaves_outputs(flow2d_host_flow* h, const char* omitted_key)
+{
+    if (!h) return -1;
+    Data2D f0(h->width, h->height), f1(h->width, h->height), u(h->width, h->height), v(h->width, h->height);
+    const size_t n = h->width * h->height;
+    for (size_t i = 0; i < n; ++i) u.DataPtr()[i] = v.DataPtr()[i] = 77.f;
+    flow2d_host_params p = {3, 0.5f, 1, 1, 3.5f, 0.001f, 0.001f, 5, 0.45f, 0};
+    OperationParameters full, bag;
+    FillBag(full, p);
+    const char* keys[] = {"warp_levels_count", "warp_scale_factor", "outer_iterations_count",
+                          "inner_iterations_count", "equation_alpha", "equation_smoothness",
+                          "equation_data", "median_radius", "gaussian_sigma"};
+    for (const char* k : keys)
+        if (std::strcmp(k, omitted_key) != 0) bag.PushValuePtr(k, full.GetValuePtr(k));
+    h->flow.ComputeFlow(f0, f1, u, v, bag);
+    for (size_t i = 0; i < n; ++i)
+        if (u.DataPtr()[i] != 77.f || v.DataPtr()[i] != 77.f) return 0;
+    return 1;
+}
+
+// ---- small helpers so the tests can reach Data2D / Settings / IOUtils ---------------------------------
+HOST_API int flow2d_host_read_raw(const char* path, size_t width, size_t height, int u8, float* out)
+{
+    Data2D d;
+    const bool ok = u8 ? d.ReadRAWFromFileU8(path, width, height) : d.ReadRAWFromFileF32(path, width, height);
+    if (!ok) return 1;
+    std::memcpy(out, d.DataPtr(), width * height * sizeof(float));
+    return 0;
+}
+
+HOST_API int flow2d_host_write_outputs(const float* u, const float* v, size_t width, size_t height,
+                                       const char* ppm_path, const char* amp_path, float flow_max_scale)
+{
+    Data2D du(width, height), dv(width, height);
+    std::memcpy(du.DataPtr(), u, width * height * sizeof(float));
+    std::memcpy(dv.DataPtr(), v, width * height * sizeof(float));
+    IOUtils::WriteFlowToImageRGB(du, dv, flow_max_scale, ppm_path);
+    IOUtils::WriteMagnitudeToFileF32(du, dv, amp_path);
+    return 0;
+}
+
+HOST_API void flow2d_host_convert_to_rgb(float x, float y, int* rgb)
+{
+    const IOUtils::RGBColor c = IOUtils::ConvertToRGB(x, y);
+    rgb[0] = c.r;
+    rgb[1] = c.g;
+    rgb[2] = c.b;
+}
+
+struct flow2d_host_settings {
+    int width, height, medianRadius, iterInner, iterOuter, levels, press_key;
+    float sigma, alpha, e_smooth, e_data, warpScale;
+    char inputPath[512], outputPath[512], fileName1[256], fileName2[256], imageType[32], dataConstancy[32];
+};
+
+HOST_API int flow2d_host_load_settings(const char* path, flow2d_host_settings* out)
+{
+    OpticFlow::Settings s;
+    const int rc = s.LoadSettings(path);
+    if (rc != 0) return rc;
+    out->width = s.width;
+    out->height = s.height;
+    out->medianRadius = s.medianRadius;
+    out->iterInner = s.iterInner;
+    out->iterOuter = s.iterOuter;
+    out->levels = s.levels;
+    out->press_key = s.press_key;
+    out->sigma = s.sigma;
+    out->alpha = s.alpha;
+    out->e_smooth = s.e_smooth;
+    out->e_data = s.e_data;
+    out->warpScale = s.warpScale;
+    std::snprintf(out->inputPath, sizeof(out->inputPath), "%s", s.inputPath.c_str());
+    std::snprintf(out->outputPath, sizeof(out->outputPath), "%s", s.outputPath.c_str());
+    std::snprintf(out->fileName1, sizeof(out->fileName1), "%s", s.fileName1.c_str());
+    std::snprintf(out->fileName2, sizeof(out->fileName2), "%s", s.fileName2.c_str());
+    std::snprintf(out->imageType, sizeof(out->imageType), "%s", s.imageType.c_str());
+    std::snprintf(out->dataConstancy, sizeof(out->dataConstancy), "%s", s.dataConstancy.c_str());
+    return 0;
+}

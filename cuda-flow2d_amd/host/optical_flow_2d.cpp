@@ -1,0 +1,423 @@
+#include "optical_flow_2d.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+
+#include "device_utils.h"
+
+// ---- base ------------------------------------------------------------------------------------------
+size_t OpticalFlowBase2D::GetMaxWarpLevel(size_t width, size_t height, float scale_factor) const
+{
+    // Level n is usable while ceil(W * s^n) >= 4 and ceil(H * s^n) >= 4, all in float
+    // (optical_flow_base_2d.cpp:36-59).
+    size_t level_w = 1, level_h = 1, levels = 1;
+    for (; scale_factor < 1.f; ++levels) {
+        const float s = std::pow(scale_factor, static_cast<float>(levels));
+        level_w = static_cast<size_t>(std::ceil(width * s));
+        level_h = static_cast<size_t>(std::ceil(height * s));
+        if (level_w < 4 || level_h < 4) break;
+    }
+    if (level_w == 1 || level_h == 1) --levels;
+    return levels;
+}
+
+bool OpticalFlowBase2D::IsInitialized() const
+{
+    if (!initialized_) std::printf("Error: '%s' was not initialized.\n", name_);
+    return initialized_;
+}
+
+void OpticalFlowBase2D::ComputeFlow(Data2D&, Data2D&, Data2D&, Data2D&, OperationParameters&)
+{
+    std::printf("Warning: '%s' ComputeFlow() was not defined.\n", name_);
+}
+
+void OpticalFlowBase2D::Destroy() { initialized_ = false; }
+
+OpticalFlowBase2D::~OpticalFlowBase2D() = default;
+
+// ---- OpticalFlow2D ---------------------------------------------------------------------------------
+OpticalFlow2D::OpticalFlow2D() : OpticalFlowBase2D("Optical Flow 2D MI355X") {}
+
+OpticalFlow2D::~OpticalFlow2D() { Destroy(); }
+
+bool OpticalFlow2D::Initialize(const DataSize3& data_size, DataConstancy data_constancy)
+{
+    if (initialized_) Destroy();
+    context_ = CurrentDeviceContext();
+    if (!context_) {
+        std::printf("Error: '%s': no device context, call InitDeviceContext() first.\n", GetName());
+        return false;
+    }
+    if (data_size.width < 4 || data_size.height < 4) {
+        std::printf("Error: '%s': frames must be at least 4 x 4.\n", GetName());
+        return false;
+    }
+    dev_container_size_ = data_size;
+    dev_container_size_.pitch = 0;
+    data_constancy_ = data_constancy;
+    initialized_ = InitMemory() && InitOperations();
+    if (!initialized_) Destroy();
+    return initialized_;
+}
+
+bool OpticalFlow2D::InitMemory()
+{
+    if (!silent) std::printf("Allocating memory on the device...\n");
+    size_t free_bytes = 0, total_bytes = 0;
+    if (CheckFlow2DError(flow2d_mem_info(context_, &free_bytes, &total_bytes), "flow2d_mem_info")) return false;
+    const size_t pitch = flow2d_plane_pitch_bytes(dev_container_size_.width);
+    const size_t needed = pitch * dev_container_size_.height * kContainersCount;
+    if (!silent)
+        std::printf("Available\t:\t%.0fMB / %.0fMB\nNeeded\t\t:\t%.0fMB\n", free_bytes / 1048576.f,
+                    total_bytes / 1048576.f, needed / 1048576.f);
+    if (needed >= free_bytes) return false;  // same silent refusal as optical_flow_2d.cpp:109-113
+    for (size_t i = 0; i < kContainersCount; ++i) {
+        void* plane = nullptr;
+        size_t got_pitch = 0;
+        if (CheckFlow2DError(flow2d_plane_alloc(context_, dev_container_size_.width, dev_container_size_.height,
+                                                &plane, &got_pitch),
+                             "flow2d_plane_alloc") ||
+            got_pitch != pitch) {
+            std::printf("Error during device memory allocation.");
+            return false;
+        }
+        all_planes_.push_back(static_cast<DevicePtr>(reinterpret_cast<uintptr_t>(plane)));
+    }
+    free_planes_ = all_planes_;
+    dev_container_size_.pitch = pitch;
+    return true;
+}
+
+bool OpticalFlow2D::InitOperations()
+{
+    if (dev_container_size_.pitch == 0) {
+        std::printf("Initialization failed. Device pitch is 0.\n");
+        return false;
+    }
+    OperationParameters op;
+    op.PushValuePtr("container_size", &dev_container_size_);
+    op.PushValuePtr("data_constancy", &data_constancy_);
+    op.PushValuePtr("flow2d_context", &context_);
+    CudaOperationBase* ops[] = {&cuop_add_, &cuop_convolution_, &cuop_median_,
+                                &cuop_register_, &cuop_resample_, &cuop_solve_};
+    for (CudaOperationBase* cuop : ops) {
+        const bool ok = cuop->Initialize(&op);
+        if (!silent) std::printf("%-18s: %s\n", cuop->GetName(), ok ? "OK" : "FAILED");
+        if (!ok) return false;
+    }
+    return true;
+}
+
+void OpticalFlow2D::Destroy()
+{
+    CudaOperationBase* ops[] = {&cuop_add_, &cuop_convolution_, &cuop_median_,
+                                &cuop_register_, &cuop_resample_, &cuop_solve_};
+    for (CudaOperationBase* cuop : ops) cuop->Destroy();
+    if (context_) {
+        if (!all_planes_.empty()) flow2d_synchronize(context_);
+        if (free_planes_.size() != all_planes_.size())
+            std::printf("Warning. Not all device memory allocations were freed.\n");
+        for (DevicePtr p : all_planes_) flow2d_plane_free(context_, AsPlane(p));
+    }
+    all_planes_.clear();
+    free_planes_.clear();
+    initialized_ = false;
+}
+
+DevicePtr OpticalFlow2D::Acquire()
+{
+    DevicePtr p = free_planes_.back();
+    free_planes_.pop_back();
+    return p;
+}
+
+void OpticalFlow2D::Release(DevicePtr p) { free_planes_.push_back(p); }
+
+std::vector<FlowLevelTiming> OpticalFlow2D::LastLevelTimings()
+{
+    std::vector<FlowLevelTiming> out;
+    size_t n = 0;
+    if (!context_ || flow2d_timing_count(context_, &n) != FLOW2D_OK) return out;
+    for (size_t i = 0; i < n; ++i) {
+        flow2d_timing_record r;
+        if (flow2d_timing_get(context_, i, &r) != FLOW2D_OK) break;
+        out.push_back({r.width, r.height, r.elapsed_ms});
+    }
+    return out;
+}
+
+void OpticalFlow2D::ComputeFlow(Data2D& frame_0, Data2D& frame_1, Data2D& flow_u, Data2D& flow_v,
+                                OperationParameters& params)
+{
+    if (!IsInitialized()) return;
+    const size_t W = dev_container_size_.width, H = dev_container_size_.height;
+    if (frame_0.Width() != W || frame_0.Height() != H || frame_1.Width() != W || frame_1.Height() != H ||
+        flow_u.Width() != W || flow_u.Height() != H || flow_v.Width() != W || flow_v.Height() != H) {
+        std::printf("Error: '%s': frame / flow sizes do not match the initialised size %zu x %zu.\n", GetName(), W, H);
+        return;
+    }
+    std::printf("\nStarting optical flow computation...\n");
+    void *ev_start = nullptr, *ev_stop = nullptr;
+    flow2d_event_create(context_, &ev_start);
+    flow2d_event_create(context_, &ev_stop);
+    flow2d_event_record(context_, ev_start);
+
+    dev_frame_0_ = Acquire();
+    dev_frame_1_ = Acquire();
+    dev_flow_u_ = Acquire();
+    dev_flow_v_ = Acquire();
+    bool ok = CopyData2DtoDevice(frame_0, dev_frame_0_, H, dev_container_size_.pitch) &&
+              CopyData2DtoDevice(frame_1, dev_frame_1_, H, dev_container_size_.pitch);
+    ok = ok && RunPyramid(params);
+    if (ok) {
+        CopyData2DFromDevice(dev_flow_u_, flow_u, H, dev_container_size_.pitch);
+        CopyData2DFromDevice(dev_flow_v_, flow_v, H, dev_container_size_.pitch);
+    }
+    flow2d_event_record(context_, ev_stop);
+    flow2d_event_synchronize(context_, ev_stop);  // the only host wait of a pair
+    flow2d_event_elapsed_ms(context_, ev_start, ev_stop, &last_total_ms_);
+    std::printf("Total GPU computation time: % 4.4fs\n", last_total_ms_ / 1000.);
+    flow2d_event_destroy(context_, ev_start);
+    flow2d_event_destroy(context_, ev_stop);
+
+    Release(dev_frame_0_);
+    Release(dev_frame_1_);
+    Release(dev_flow_u_);
+    Release(dev_flow_v_);
+}
+
+bool OpticalFlow2D::ComputeFlowDevice(DevicePtr dev_frame_0, DevicePtr dev_frame_1, DevicePtr dev_flow_u,
+                                      DevicePtr dev_flow_v, OperationParameters& params)
+{
+    if (!IsInitialized() || !dev_frame_0 || !dev_frame_1 || !dev_flow_u || !dev_flow_v) return false;
+    const size_t bytes = dev_container_size_.pitch * dev_container_size_.height;
+    dev_frame_0_ = Acquire();
+    dev_frame_1_ = Acquire();
+    dev_flow_u_ = Acquire();
+    dev_flow_v_ = Acquire();
+    // the pyramid consumes its frame planes (blur and level-0 swaps), so work on copies
+    bool ok = !CheckFlow2DError(flow2d_copy_d2d(context_, AsPlane(dev_frame_0_), AsPlane(dev_frame_0), bytes), "copy") &&
+              !CheckFlow2DError(flow2d_copy_d2d(context_, AsPlane(dev_frame_1_), AsPlane(dev_frame_1), bytes), "copy");
+    ok = ok && RunPyramid(params);
+    if (ok) {
+        ok = !CheckFlow2DError(flow2d_copy_d2d(context_, AsPlane(dev_flow_u), AsPlane(dev_flow_u_), bytes), "copy") &&
+             !CheckFlow2DError(flow2d_copy_d2d(context_, AsPlane(dev_flow_v), AsPlane(dev_flow_v_), bytes), "copy");
+    }
+    Release(dev_frame_0_);
+    Release(dev_frame_1_);
+    Release(dev_flow_u_);
+    Release(dev_flow_v_);
+    return ok;
+}
+
+// The coarse-to-fine loop on device planes: pre-blur, then per level { resample frames from full
+// resolution, resample the flow from the previous level, warp frame 1, solve, u += du, median }.
+// Order, buffer roles and float level-size arithmetic follow optical_flow_2d.cpp:160-449.
+// On entry dev_frame_0_/1_ hold the frames; on success dev_flow_u_/v_ hold the flow.
+bool OpticalFlow2D::RunPyramid(OperationParameters& params)
+{
+    size_t warp_levels_count = 0, outer_iterations_count = 0, inner_iterations_count = 0, median_radius = 0;
+    float warp_scale_factor = 0.f, equation_alpha = 0.f, equation_smoothness = 0.f, equation_data = 0.f;
+    float gaussian_sigma = 0.f;
+    struct {
+        const char* key;
+        bool ok;
+    } reads[] = {
+        {"warp_levels_count", params.Read<size_t>("warp_levels_count", warp_levels_count)},
+        {"warp_scale_factor", params.Read<float>("warp_scale_factor", warp_scale_factor)},
+        {"outer_iterations_count", params.Read<size_t>("outer_iterations_count", outer_iterations_count)},
+        {"inner_iterations_count", params.Read<size_t>("inner_iterations_count", inner_iterations_count)},
+        {"equation_alpha", params.Read<float>("equation_alpha", equation_alpha)},
+        {"equation_smoothness", params.Read<float>("equation_smoothness", equation_smoothness)},
+        {"equation_data", params.Read<float>("equation_data", equation_data)},
+        {"median_radius", params.Read<size_t>("median_radius", median_radius)},
+        {"gaussian_sigma", params.Read<float>("gaussian_sigma", gaussian_sigma)},
+    };
+    for (const auto& r : reads)
+        if (!r.ok) {
+            std::printf("Operation: '%s'. Missing parameter '%s'.\n", GetName(), r.key);
+            return false;
+        }
+    int solver_algorithm = FLOW2D_SOLVER_AUTO;
+    params.Read<int>("solver_algorithm", solver_algorithm);
+
+    DataSize3 original_size = {dev_container_size_.width, dev_container_size_.height, 0};
+    const size_t max_level = GetMaxWarpLevel(original_size.width, original_size.height, warp_scale_factor);
+    int level = static_cast<int>(std::min(warp_levels_count, max_level)) - 1;
+    if (level < 0 || !(warp_scale_factor < 1.f)) {
+        // the reference would skip the loop and hand back stale buffers: refuse instead
+        std::printf("Error: '%s': no pyramid level to run (levels %zu, scale %g).\n", GetName(), warp_levels_count,
+                    warp_scale_factor);
+        return false;
+    }
+
+    {  // widths the median operator accepts: 1 (copy), 3..8 (even widths use width - 1); anything else would
+       // make the reference swap in a stale buffer (cuda_operation_median_2d.cpp:150-152)
+        const size_t eff = (median_radius != 1 && median_radius % 2 == 0) ? median_radius - 1 : median_radius;
+        if (!(median_radius == 1 || (median_radius != 2 && eff >= 3 && eff <= 7))) {
+            std::printf("Error. Wrong median raduis (%zu). Supported values: 3, 5, 7\n", median_radius);
+            return false;
+        }
+    }
+
+    flow2d_timing_reset(context_);
+    flow2d_timing_enable(context_, collect_level_timings ? 1 : 0);
+
+    DevicePtr frame_0 = dev_frame_0_, frame_1 = dev_frame_1_, flow_u = dev_flow_u_, flow_v = dev_flow_v_;
+    DevicePtr frame_0_res = Acquire(), frame_1_res = Acquire(), flow_du = Acquire(), flow_dv = Acquire();
+    OperationParameters op;
+
+    if (gaussian_sigma > 0.0) {  // optical_flow_2d.cpp:218-246: blur into the flow planes, then swap roles
+        DevicePtr temp = Acquire();
+        DevicePtr* io[2][2] = {{&frame_0, &flow_u}, {&frame_1, &flow_v}};
+        for (auto& pair : io) {
+            op.Clear();
+            op.PushValuePtr("dev_input", pair[0]);
+            op.PushValuePtr("dev_output", pair[1]);
+            op.PushValuePtr("dev_temp", &temp);
+            op.PushValuePtr("data_size", &original_size);
+            op.PushValuePtr("gaussian_sigma", &gaussian_sigma);
+            cuop_convolution_.Execute(op);
+            std::swap(*pair[0], *pair[1]);
+        }
+        Release(temp);
+    }
+
+    DataSize3 current_size = {0, 0, 0}, prev_size = {0, 0, 0};
+    for (; level >= 0; --level) {
+        const float scale = std::pow(warp_scale_factor, static_cast<float>(level));
+        current_size.width = static_cast<size_t>(std::ceil(original_size.width * scale));
+        current_size.height = static_cast<size_t>(std::ceil(original_size.height * scale));
+        float hx = original_size.width / static_cast<float>(current_size.width);
+        float hy = original_size.height / static_cast<float>(current_size.height);
+        if (!silent) std::printf("Solve level %2d (%4zu x%4zu) \n", level, current_size.width, current_size.height);
+
+        // frames: level 0 uses the (blurred) full-resolution planes, others are resampled from them
+        if (level == 0) {
+            std::swap(frame_0, frame_0_res);
+            std::swap(frame_1, frame_1_res);
+        } else {
+            DevicePtr temp = Acquire();
+            DevicePtr* io[2][2] = {{&frame_0, &frame_0_res}, {&frame_1, &frame_1_res}};
+            for (auto& pair : io) {
+                op.Clear();
+                op.PushValuePtr("dev_input", pair[0]);
+                op.PushValuePtr("dev_output", pair[1]);
+                op.PushValuePtr("dev_temp", &temp);
+                op.PushValuePtr("data_size", &original_size);
+                op.PushValuePtr("resample_size", &current_size);
+                cuop_resample_.Execute(op);
+            }
+            Release(temp);
+        }
+
+        // flow: zero at the coarsest level, otherwise previous level -> this level (no magnitude scaling)
+        if (prev_size.width == 0) {
+            const size_t row_bytes = dev_container_size_.width * sizeof(float);
+            flow2d_memset_2d(context_, AsPlane(flow_u), dev_container_size_.pitch, 0, row_bytes, dev_container_size_.height);
+            flow2d_memset_2d(context_, AsPlane(flow_v), dev_container_size_.pitch, 0, row_bytes, dev_container_size_.height);
+        } else {
+            DevicePtr temp = Acquire();
+            DevicePtr* io[2][2] = {{&flow_u, &flow_du}, {&flow_v, &flow_dv}};
+            for (auto& pair : io) {
+                op.Clear();
+                op.PushValuePtr("dev_input", pair[0]);
+                op.PushValuePtr("dev_output", pair[1]);
+                op.PushValuePtr("dev_temp", &temp);
+                op.PushValuePtr("data_size", &prev_size);
+                op.PushValuePtr("resample_size", &current_size);
+                cuop_resample_.Execute(op);
+                std::swap(*pair[0], *pair[1]);
+            }
+            Release(temp);
+        }
+
+        {  // backward registration of frame 1 by the current flow; the warped frame replaces it
+            DevicePtr temp = Acquire();
+            op.Clear();
+            op.PushValuePtr("dev_frame_0", &frame_0_res);
+            op.PushValuePtr("dev_frame_1", &frame_1_res);
+            op.PushValuePtr("dev_flow_u", &flow_u);
+            op.PushValuePtr("dev_flow_v", &flow_v);
+            op.PushValuePtr("dev_output", &temp);
+            op.PushValuePtr("data_size", &current_size);
+            op.PushValuePtr("hx", &hx);
+            op.PushValuePtr("hy", &hy);
+            cuop_register_.Execute(op);
+            std::swap(frame_1_res, temp);
+            Release(temp);
+        }
+
+        {  // lagged-diffusivity fixed point: the hot loop
+            DevicePtr phi = Acquire(), ksi = Acquire(), temp_du = Acquire(), temp_dv = Acquire();
+            op.Clear();
+            op.PushValuePtr("dev_frame_0", &frame_0_res);
+            op.PushValuePtr("dev_frame_1", &frame_1_res);
+            op.PushValuePtr("dev_flow_u", &flow_u);
+            op.PushValuePtr("dev_flow_v", &flow_v);
+            op.PushValuePtr("dev_flow_du", &flow_du);
+            op.PushValuePtr("dev_flow_dv", &flow_dv);
+            op.PushValuePtr("dev_phi", &phi);
+            op.PushValuePtr("dev_ksi", &ksi);
+            op.PushValuePtr("dev_temp_du", &temp_du);
+            op.PushValuePtr("dev_temp_dv", &temp_dv);
+            op.PushValuePtr("data_constancy", &data_constancy_);
+            op.PushValuePtr("outer_iterations_count", &outer_iterations_count);
+            op.PushValuePtr("inner_iterations_count", &inner_iterations_count);
+            op.PushValuePtr("equation_alpha", &equation_alpha);
+            op.PushValuePtr("equation_smoothness", &equation_smoothness);
+            op.PushValuePtr("equation_data", &equation_data);
+            op.PushValuePtr("data_size", &current_size);
+            op.PushValuePtr("hx", &hx);
+            op.PushValuePtr("hy", &hy);
+            op.PushValuePtr("solver_algorithm", &solver_algorithm);
+            cuop_solve_.silent = true;  // per-level printing would need a host wait; timings are collected instead
+            cuop_solve_.Execute(op);
+            Release(phi);
+            Release(ksi);
+            Release(temp_du);
+            Release(temp_dv);
+        }
+
+        {  // u += du, v += dv
+            DevicePtr* io[2][2] = {{&flow_u, &flow_du}, {&flow_v, &flow_dv}};
+            for (auto& pair : io) {
+                op.Clear();
+                op.PushValuePtr("operand_0", pair[0]);
+                op.PushValuePtr("operand_1", pair[1]);
+                op.PushValuePtr("data_size", &current_size);
+                cuop_add_.Execute(op);
+            }
+        }
+        prev_size = current_size;
+
+        {  // median of u and v after every level, the finest included
+            DevicePtr temp = Acquire();
+            DevicePtr* fields[2] = {&flow_u, &flow_v};
+            for (DevicePtr* field : fields) {
+                op.Clear();
+                op.PushValuePtr("dev_input", field);
+                op.PushValuePtr("dev_output", &temp);
+                op.PushValuePtr("data_size", &current_size);
+                op.PushValuePtr("radius", &median_radius);
+                cuop_median_.Execute(op);
+                std::swap(*field, temp);
+            }
+            Release(temp);
+        }
+    }
+
+    // hand the roles back: the caller reads the flow from dev_flow_u_/v_ and releases all four
+    dev_frame_0_ = frame_0;
+    dev_frame_1_ = frame_1;
+    dev_flow_u_ = flow_u;
+    dev_flow_v_ = flow_v;
+    Release(frame_0_res);
+    Release(frame_1_res);
+    Release(flow_du);
+    Release(flow_dv);
+    flow2d_timing_enable(context_, 0);
+    return true;
+}

@@ -1,0 +1,102 @@
+// Coarse-to-fine orchestrator of the flow2d hot path.
+// Public interface of the reference's OpticalFlowBase2D / OpticalFlow2D
+// (src/optical_flow/optical_flow_base_2d.h:29-52, src/optical_flow/optical_flow_2d.h:43-71):
+//   bool Initialize(const DataSize3&, DataConstancy = Grey);
+//   void ComputeFlow(Data2D& frame_0, Data2D& frame_1, Data2D& flow_u, Data2D& flow_v, OperationParameters&);
+//   void Destroy();   bool silent;
+// ComputeFlow bag keys and pointee types (optical_flow_2d.cpp:160-168): warp_levels_count size_t,
+// warp_scale_factor float, outer_iterations_count size_t, inner_iterations_count size_t,
+// equation_alpha float, equation_smoothness float, equation_data float, median_radius size_t,
+// gaussian_sigma float.  Optional superset key: solver_algorithm int (flow2d_solver_algorithm).
+//
+// MI355X-first differences (results unchanged): every launch of a pair is queued on one HIP stream
+// with no host synchronisation until the flow is copied back (the reference blocks after every
+// sweep, cuda_operation_solve_2d.cpp:291); frames may already live in HBM (ComputeFlowDevice).
+#pragma once
+
+#include <cstddef>
+#include <vector>
+
+#include "cuda_operations_2d.h"
+#include "data2d.h"
+#include "data_structs.h"
+#include "operation_parameters.h"
+
+class OpticalFlowBase2D {
+public:
+    const char* GetName() const { return name_; }
+
+    virtual bool Initialize(const DataSize3& data_size, DataConstancy data_constancy = DataConstancy::Grey) = 0;
+    virtual void ComputeFlow(Data2D& frame_0, Data2D& frame_1, Data2D& flow_u, Data2D& flow_v,
+                             OperationParameters& params);
+    virtual void Destroy();
+    virtual ~OpticalFlowBase2D();
+
+    // Number of usable pyramid levels (src/optical_flow/optical_flow_base_2d.cpp:36-59); public here so
+    // callers and tests can size a run.
+    size_t GetMaxWarpLevel(size_t width, size_t height, float scale_factor) const;
+
+protected:
+    explicit OpticalFlowBase2D(const char* name) : name_(name) {}
+    bool IsInitialized() const;
+
+    bool initialized_ = false;
+    DataConstancy data_constancy_ = DataConstancy::Grey;
+
+private:
+    const char* name_ = nullptr;
+};
+
+struct FlowLevelTiming {
+    size_t width, height;
+    float solve_ms;  // device time of the level's whole solve call (reference timer, cuda_operation_solve_2d.cpp:220,302)
+};
+
+class OpticalFlow2D : public OpticalFlowBase2D {
+public:
+    OpticalFlow2D();
+    ~OpticalFlow2D() override;
+
+    bool Initialize(const DataSize3& data_size, DataConstancy data_constancy = DataConstancy::Grey) override;
+    void ComputeFlow(Data2D& frame_0, Data2D& frame_1, Data2D& flow_u, Data2D& flow_v,
+                     OperationParameters& params) override;
+    void Destroy() override;
+
+    // Same computation for frames that already sit in pitched device containers of the initialised
+    // size (pitch = ContainerSize().pitch).  dev_frame_* are read, dev_flow_* are written.  Nothing is
+    // synchronised: the work is queued on the context's stream.  Returns false on a bad argument.
+    bool ComputeFlowDevice(DevicePtr dev_frame_0, DevicePtr dev_frame_1, DevicePtr dev_flow_u, DevicePtr dev_flow_v,
+                           OperationParameters& params);
+
+    const DataSize3& ContainerSize() const { return dev_container_size_; }
+    // Device time of the last ComputeFlow (events around upload..download), milliseconds.
+    float LastTotalMs() const { return last_total_ms_; }
+    // When true the context's solver timing is collected per level (a few events per level).
+    bool collect_level_timings = false;
+    // Valid after a synchronisation of the context when collect_level_timings was set.
+    std::vector<FlowLevelTiming> LastLevelTimings();
+
+    bool silent = false;
+
+private:
+    bool InitMemory();
+    bool InitOperations();
+    bool RunPyramid(OperationParameters& params);
+    DevicePtr Acquire();
+    void Release(DevicePtr p);
+
+    static constexpr size_t kContainersCount = 12;  // optical_flow_2d.h:45 of the reference
+    DataSize3 dev_container_size_{0, 0, 0};
+    std::vector<DevicePtr> all_planes_;
+    std::vector<DevicePtr> free_planes_;
+    DevicePtr dev_frame_0_ = 0, dev_frame_1_ = 0, dev_flow_u_ = 0, dev_flow_v_ = 0;  // valid inside a run
+    flow2d_context* context_ = nullptr;
+    float last_total_ms_ = 0.f;
+
+    CudaOperationAdd2D cuop_add_;
+    CudaOperationConvolution2D cuop_convolution_;
+    CudaOperationMedian2D cuop_median_;
+    CudaOperationRegistration2D cuop_register_;
+    CudaOperationResample2D cuop_resample_;
+    CudaOperationSolve2D cuop_solve_;
+};

@@ -1,0 +1,205 @@
+"""CPU-side checks (no GPU, no compute calls): the C-ABI library loads and exports every symbol the
+header declares, the oracle still reproduces the committed golden vectors, and the host-side
+logic that does not touch the device (settings reader, raw IO, colour wheel) behaves like the
+reference's."""
+import ctypes
+import hashlib
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = os.path.join(ROOT, "tests", "golden", "flow2d_golden.npz")
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a, np.float32).tobytes()).hexdigest()
+
+
+def test_c_abi_exports_every_declared_symbol(flow2d):
+    header = open(os.path.join(ROOT, "include", "flow2d_c_abi.h")).read()
+    declared = set(re.findall(r"FLOW2D_API\s+[\w\s\*]+?\b(flow2d_\w+)\s*\(", header))
+    assert len(declared) >= 35
+    lib = flow2d.hip_lib()
+    missing = [name for name in sorted(declared) if not hasattr(lib, name)]
+    assert not missing, "declared in include/flow2d_c_abi.h but not exported: %s" % missing
+    assert lib.flow2d_abi_version() == 1
+    assert lib.flow2d_status_string(5) == b"unsupported parameter"
+    # no torch / C++ types in the signatures: the header must compile as plain C
+    src = os.path.join(ROOT, "include", "flow2d_c_abi.h")
+    subprocess.check_call(["gcc", "-std=c99", "-fsyntax-only", "-x", "c", src])
+
+
+def test_c_abi_rejects_bad_arguments_without_a_device(flow2d):
+    lib = flow2d.hip_lib()
+    assert lib.flow2d_context_destroy(None) == 1
+    assert lib.flow2d_plane_pitch_bytes(584) == 2560 and lib.flow2d_plane_pitch_bytes(64) == 256
+    taps = (ctypes.c_float * 51)()
+    r = ctypes.c_int()
+    assert lib.flow2d_gaussian_kernel(-1.0, taps, ctypes.byref(r)) == 1
+    assert lib.flow2d_gaussian_kernel(9.0, taps, ctypes.byref(r)) == 5  # 55 taps > 51
+
+
+def test_gaussian_taps_match_oracle(flow2d, oracle):
+    for sigma in (0.45, 1.0, 1.5, 3.0, 8.3):
+        taps, r = flow2d.gaussian_kernel(sigma)
+        otaps, orad = oracle.gaussian_taps(sigma)
+        assert r == orad and np.array_equal(taps, otaps)
+
+
+def test_oracle_reproduces_golden_vectors(oracle):
+    g = np.load(GOLDEN)
+    f0, f1 = g["small_f0"], g["small_f1"]
+    for name, constancy in (("grey", 0), ("grad", 1)):
+        stages = {}
+        u, v, _ = oracle.compute_flow(f0, f1, 6, 0.8, 2, 3, 3.5, 0.001, 0.001, 5, 0.45, constancy,
+                                      dump=lambda t, l, p: stages.__setitem__("%s_L%d" % (t, l), p.copy()))
+        assert np.array_equal(u, g["small_%s_u" % name]) and np.array_equal(v, g["small_%s_v" % name])
+        for k in ("blur0_L-1", "frame0_res_L3", "warped_L2", "phi_L1", "ksi_L1", "du_L1", "dv_L1", "flow_u_add_L1",
+                  "flow_u_med_L1", "flow_u_res_L0"):
+            assert np.array_equal(stages[k], g["small_%s_%s" % (name, k)]), k
+    for s in (0.45, 1.5):
+        assert np.array_equal(oracle.gaussian_taps(s)[0], g["taps_%g" % s])
+    for w, h, s100, want in g["level_table"]:
+        assert oracle.max_warp_level(int(w), int(h), s100 / 100.0) == want
+
+
+def test_oracle_reproduces_rub_golden(oracle):
+    from test_oracle import rub_pair
+    g = np.load(GOLDEN)
+    r1, r2 = rub_pair()
+    u, v, _ = oracle.compute_flow(r1, r2, 8, 0.8, 3, 5, 3.5, 0.001, 0.001, 5, 0.45)
+    assert [sha(u), sha(v)] == list(g["rub_short_sha"])
+    assert np.array_equal(u[::2, ::2], g["rub_short_u_sub2"])
+
+
+def test_settings_reader(flow2d, tmp_path):
+    xml = """<?xml version="1.0"?>
+<!-- Settings for the Optical flow computation program -->
+<OpticalFlow>
+  <Input>
+    <Path inputPath="./data/"/>
+    <Mode Nx="584" Ny="388" imageType="8-bit">
+    	<Files file1 ="rub1.raw" file2 ="rub2.raw"/>
+    </Mode>
+  </Input>
+  <Parameters>
+    <Method mode ="2d" run="flow" key="0" />
+    <Solver>
+      <Iterations inner="5" outer="20"/>
+      <Warping levels="20" scaling="0.9" medianRadius="5"/>
+      <Model sigma="0.45" alpha ="3.5" e_smooth="0.001" e_data="0.001"/>
+    </Solver>
+  </Parameters>
+  <Output>
+    <Path outputPath="./out/"/>
+  </Output>
+</OpticalFlow>
+"""
+    p = tmp_path / "settings.xml"
+    p.write_text(xml)
+    s = flow2d.load_settings(str(p))
+    assert s is not None
+    assert (s.width, s.height, s.iterInner, s.iterOuter, s.levels, s.medianRadius) == (584, 388, 5, 20, 20, 5)
+    assert abs(s.sigma - 0.45) < 1e-7 and abs(s.alpha - 3.5) < 1e-7 and abs(s.warpScale - 0.9) < 1e-7
+    assert abs(s.e_smooth - 0.001) < 1e-9 and abs(s.e_data - 0.001) < 1e-9
+    assert s.inputPath == b"./data/" and s.outputPath == b"./out/"
+    assert s.fileName1 == b"rub1.raw" and s.fileName2 == b"rub2.raw"
+    assert s.imageType == b"8-bit" and s.dataConstancy == b"grey" and s.press_key == 0
+    # a missing element is an error (-1 -> exit code 3 in the CLI), not a crash as in the reference
+    q = tmp_path / "broken.xml"
+    q.write_text(xml.replace('<Warping levels="20" scaling="0.9" medianRadius="5"/>', ""))
+    assert flow2d.load_settings(str(q)) is None
+    assert flow2d.load_settings(str(tmp_path / "absent.xml")) is None
+
+
+def test_shipped_rub_settings_file(flow2d):
+    s = flow2d.load_settings(os.path.join(ROOT, "cuda-flow2d_amd", "host", "settings_rub.xml"))
+    assert s is not None and (s.width, s.height) == (584, 388) and s.imageType == b"8-bit"
+
+
+def test_raw_readers(flow2d, tmp_path):
+    rng = np.random.default_rng(5)
+    a8 = rng.integers(0, 256, (7, 9), dtype=np.uint8)
+    a32 = rng.normal(0, 1, (7, 9)).astype(np.float32)
+    (tmp_path / "a8.raw").write_bytes(a8.tobytes())
+    (tmp_path / "a32.raw").write_bytes(a32.tobytes())
+    assert np.array_equal(flow2d.read_raw(str(tmp_path / "a8.raw"), 9, 7, True), a8.astype(np.float32))
+    assert np.array_equal(flow2d.read_raw(str(tmp_path / "a32.raw"), 9, 7, False), a32)
+    # wrong dimensions (too short / trailing bytes) and missing files are rejected, no crash
+    assert flow2d.read_raw(str(tmp_path / "a8.raw"), 9, 8, True) is None
+    assert flow2d.read_raw(str(tmp_path / "a8.raw"), 9, 6, True) is None
+    assert flow2d.read_raw(str(tmp_path / "a8.raw"), 9, 7, False) is None
+    assert flow2d.read_raw(str(tmp_path / "nope.raw"), 9, 7, True) is None
+
+
+_libm = ctypes.CDLL("libm.so.6")
+_libm.atanf.restype = ctypes.c_float
+_libm.atanf.argtypes = [ctypes.c_float]
+
+
+def _atanf(t):
+    # the reference calls the float overload of atan (io_utils.cpp:24 includes <math.h> in C++);
+    # numpy's own float32 arctan can differ from libm's in the last bit
+    return np.float32(_libm.atanf(float(t)))
+
+
+def _wheel_reference(x, y):
+    """The Bruhn colour wheel as io_utils.cpp:140-225 words it, in numpy scalars."""
+    f = np.float32
+    pi = f(2.0 * np.arccos(0.0))
+    x, y = f(x), f(y)
+    amp = np.sqrt(x * x + y * y)
+    amp = f(1) if amp > 1 else amp
+    if x == 0:
+        phi = f(0.5 * float(pi)) if y >= 0 else f(1.5 * float(pi))
+    elif x > 0:
+        phi = _atanf(y / x) if y >= 0 else f(2.0 * float(pi) + float(_atanf(y / x)))
+    else:
+        phi = f(float(pi) + float(_atanf(y / x)))
+    phi = f(float(phi) / 2.0)
+    P = float(pi)
+    segs = [(0.0, 0.125, (255, 0, 0), (255, 0, 255)), (0.125, 0.25, (255, 0, 255), (64, 64, 255)),
+            (0.25, 0.375, (64, 64, 255), (0, 255, 255)), (0.375, 0.5, (0, 255, 255), (0, 255, 0)),
+            (0.5, 0.75, (0, 255, 0), (255, 255, 0)), (0.75, 1.0, (255, 255, 0), (255, 0, 0))]
+    rgb = [0, 0, 0]
+    for lo, hi, c0, c1 in segs:
+        inside = (float(phi) >= lo * P) and (float(phi) <= hi * P if hi == 1.0 else float(phi) < hi * P)
+        if inside:
+            beta = f((float(phi) - lo * P) / ((hi - lo) * P))
+            alpha = f(1.0 - float(beta))
+            rgb = [int(np.floor(float(amp) * (float(alpha) * a + float(beta) * b))) for a, b in zip(c0, c1)]
+    return tuple(255 if c >= 255 else (c if c > 0 else 0) for c in rgb)
+
+
+def test_colour_wheel_and_output_files(flow2d, tmp_path):
+    rng = np.random.default_rng(9)
+    pts = [(0, 0), (1, 0), (0, 1), (-1, 0), (0, -1), (0.3, 0.3), (-2, 5), (0.5, -0.1), (1e-3, -1e-3)]
+    pts += [tuple(p) for p in rng.uniform(-1.5, 1.5, (300, 2))]
+    for x, y in pts:
+        assert flow2d.convert_to_rgb(x, y) == _wheel_reference(x, y), (x, y)
+    u = rng.normal(0, 4, (6, 5)).astype(np.float32)
+    v = rng.normal(0, 4, (6, 5)).astype(np.float32)
+    ppm, amp = str(tmp_path / "res.pgm"), str(tmp_path / "amp.raw")
+    flow2d.write_outputs(u, v, ppm, amp, 10.0)
+    data = open(ppm, "rb").read()
+    header = b"P6 \n5 6 \n255\n"
+    assert data.startswith(header) and len(data) == len(header) + 5 * 6 * 3
+    px = np.frombuffer(data[len(header):], np.uint8).reshape(6, 5, 3)
+    k = np.float32(1.0 / 10.0)
+    for yy in range(6):
+        for xx in range(5):
+            assert tuple(px[yy, xx]) == _wheel_reference(u[yy, xx] * k, v[yy, xx] * k)
+    mag = np.fromfile(amp, np.float32).reshape(6, 5)
+    assert np.array_equal(mag, np.sqrt(u * u + v * v))
+
+
+def test_cli_exit_codes_without_device(flow2d, tmp_path):
+    """Exit code 1 = no device (main.cpp:51-54); only meaningful where no GPU is visible."""
+    if flow2d.device_count() > 0:
+        pytest.skip("a GPU is visible; the no-device exit path cannot be exercised")
+    rc = subprocess.call([flow2d.CLI_PATH, "nope.xml"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    assert rc == 1
