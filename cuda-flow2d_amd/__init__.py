@@ -377,6 +377,7 @@ class OpticalFlow:
 
     def __init__(self, width, height, constancy=GREY, device=0, ctx=None, silent=True):
         L = host_lib()
+        self._adopted = ctx is not None
         if ctx is not None:
             L.flow2d_host_adopt_context(ctx.handle)
         elif L.flow2d_host_init_device(device) != 0:
@@ -384,6 +385,8 @@ class OpticalFlow:
         self.width, self.height = width, height
         self.handle = L.flow2d_host_flow_create(width, height, constancy, int(silent))
         if not self.handle:
+            if self._adopted:
+                L.flow2d_host_adopt_context(None)
             raise Flow2DError(1, "OpticalFlow2D::Initialize")
         self.pitch = L.flow2d_host_flow_pitch(self.handle)
 
@@ -427,6 +430,8 @@ class OpticalFlow:
         if self.handle:
             host_lib().flow2d_host_flow_destroy(self.handle)
             self.handle = None
+            if self._adopted:  # the caller owns (and may now destroy) the adopted context
+                host_lib().flow2d_host_adopt_context(None)
 
 
 def read_raw(path, width, height, u8):

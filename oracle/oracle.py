@@ -47,10 +47,32 @@ class FlowParams(C.Structure):
 DUMP_FN = C.CFUNCTYPE(None, C.c_char_p, C.c_int, C.POINTER(C.c_float), C.c_size_t, C.c_size_t, C.c_size_t, C.c_void_p)
 
 
+def usable_cpus():
+    """CPUs this process may really use: affinity mask capped by the cgroup CPU quota.  OpenMP's own
+    default (all hardware threads) oversubscribes a quota-limited container badly."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, q // per))
+        except (OSError, ValueError):
+            pass
+    return max(1, n)
+
+
 def lib():
     global _lib
     if _lib is None:
         build()
+        # idle OpenMP workers must sleep, not spin: the checker shares the box with the code under test
+        os.environ.setdefault("OMP_WAIT_POLICY", "passive")
+        os.environ.setdefault("GOMP_SPINCOUNT", "0")
         L = C.CDLL(_LIB_PATH)
         fp = C.POINTER(C.c_float)
         sz = C.c_size_t
@@ -82,6 +104,7 @@ def lib():
         L.oracle_compute_flow.argtypes = [fp, fp, fp, fp, sz, sz, C.POINTER(FlowParams), DUMP_FN, C.c_void_p,
                                           C.POINTER(C.c_double)]
         _lib = L
+        L.oracle_set_threads(min(usable_cpus(), 16))
     return _lib
 
 
