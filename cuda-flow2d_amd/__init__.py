@@ -54,7 +54,7 @@ class TimingRecord(C.Structure):
     _fields_ = [
         ("width", C.c_size_t), ("height", C.c_size_t), ("outer", C.c_size_t), ("inner", C.c_size_t),
         ("data_constancy", C.c_int), ("algorithm", C.c_int), ("kernel_launches", C.c_int),
-        ("elapsed_ms", C.c_float),
+        ("elapsed_ms", C.c_float), ("kernel_ms", C.c_float), ("algorithmic_bytes_per_launch", C.c_double),
     ]
 
 
@@ -293,8 +293,8 @@ class Context:
         return (tdu, tdv) if flag.value else (du, dv)
 
     # -- timing -----------------------------------------------------------------------------------
-    def timing_enable(self, on=True):
-        _check(hip_lib().flow2d_timing_enable(self.handle, int(on)), "flow2d_timing_enable")
+    def timing_enable(self, mode=1):
+        _check(hip_lib().flow2d_timing_enable(self.handle, int(mode)), "flow2d_timing_enable")
 
     def timing_records(self):
         n = C.c_size_t()
@@ -359,6 +359,7 @@ def host_lib():
         L.flow2d_host_compute_flow_device.argtypes = [vp, vp, vp, vp, vp, C.POINTER(HostParams), i]
         L.flow2d_host_level_timings.restype = sz
         L.flow2d_host_level_timings.argtypes = [vp, fp, sz]
+        L.flow2d_host_reset_timings.argtypes = [vp]
         L.flow2d_host_missing_key_leaves_outputs.argtypes = [vp, C.c_char_p]
         L.flow2d_host_read_raw.argtypes = [C.c_char_p, sz, sz, i, fp]
         L.flow2d_host_write_outputs.argtypes = [fp, fp, sz, sz, C.c_char_p, C.c_char_p, f]
@@ -411,17 +412,24 @@ class OpticalFlow:
             raise Flow2DError(rc, "OpticalFlow2D::ComputeFlow")
         return u, v, ms.value
 
-    def compute_flow_device(self, dev_f0, dev_f1, dev_u, dev_v, params, collect_level_timings=False):
-        """Device-resident pair (raw device addresses of pitched containers); queued, not synchronised."""
+    def compute_flow_device(self, dev_f0, dev_f1, dev_u, dev_v, params, timing_mode=0):
+        """Device-resident pair (raw device addresses of pitched containers); queued, not synchronised.
+        timing_mode: 0 off, 1 events around each level's solve, 2 also around each solver-kernel launch."""
         rc = host_lib().flow2d_host_compute_flow_device(self.handle, dev_f0, dev_f1, dev_u, dev_v, C.byref(params),
-                                                        int(collect_level_timings))
+                                                        int(timing_mode))
         if rc:
             raise Flow2DError(rc, "OpticalFlow2D::ComputeFlowDevice")
 
     def level_timings(self):
-        buf = np.zeros(3 * 64, np.float32)
-        n = host_lib().flow2d_host_level_timings(self.handle, _fptr(buf), 64)
-        return [(int(buf[3 * i]), int(buf[3 * i + 1]), float(buf[3 * i + 2])) for i in range(min(n, 64))]
+        """[(width, height, solve_ms, kernel_ms, kernel_launches, algorithmic_bytes_per_launch)] per level."""
+        cap = 8192
+        buf = np.zeros(6 * cap, np.float32)
+        n = host_lib().flow2d_host_level_timings(self.handle, _fptr(buf), cap)
+        return [(int(buf[6 * i]), int(buf[6 * i + 1]), float(buf[6 * i + 2]), float(buf[6 * i + 3]),
+                 int(buf[6 * i + 4]), float(buf[6 * i + 5])) for i in range(min(n, cap))]
+
+    def reset_timings(self):
+        host_lib().flow2d_host_reset_timings(self.handle)
 
     def missing_key_leaves_outputs(self, key):
         return host_lib().flow2d_host_missing_key_leaves_outputs(self.handle, key.encode())

@@ -13,13 +13,14 @@ struct flow2d_timing_slot {
     flow2d_timing_record rec;
     hipEvent_t start;
     hipEvent_t stop;
+    std::vector<hipEvent_t> kernel_events;  // mode 2: start/stop pairs of the dominant kernel's launches
 };
 
 struct flow2d_context {
     int device = 0;
     hipStream_t stream = nullptr;
     bool owns_stream = false;
-    bool timing = false;
+    int timing = 0;  // flow2d_timing_enable mode
     std::vector<flow2d_timing_slot> timings;
     int num_cus = 256;
 };

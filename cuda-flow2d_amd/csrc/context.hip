@@ -113,10 +113,7 @@ int flow2d_context_destroy(flow2d_context* ctx)
 {
     FLOW2D_ENTER(ctx);
     (void)hipStreamSynchronize(ctx->stream);
-    for (auto& s : ctx->timings) {
-        (void)hipEventDestroy(s.start);
-        (void)hipEventDestroy(s.stop);
-    }
+    flow2d_timing_reset(ctx);
     if (ctx->owns_stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return FLOW2D_OK;

@@ -15,6 +15,18 @@ int launch_sweep(flow2d_context* ctx, int constancy, const float* f0, const floa
                  size_t pitch_bytes, float hx, float hy, float alpha, float* tdu, float* tdv);
 }  // namespace flow2d
 
+namespace {
+// mode-2 timing: one more event on the stream, appended to the slot's start/stop list
+hipError_t mark(flow2d_context* ctx, flow2d_timing_slot* slot)
+{
+    hipEvent_t ev;
+    hipError_t e = hipEventCreate(&ev);
+    if (e != hipSuccess) return e;
+    slot->kernel_events.push_back(ev);
+    return hipEventRecord(ev, ctx->stream);
+}
+}  // namespace
+
 extern "C" {
 
 int flow2d_solve_level(flow2d_context* ctx, const float* frame_0, const float* frame_1, const float* flow_u,
@@ -64,9 +76,11 @@ int flow2d_solve_level(flow2d_context* ctx, const float* frame_0, const float* f
                                         ksi);
         if (st != FLOW2D_OK) return st;
         for (size_t j = 0; j < p->inner_iterations_count; ++j) {
+            if (slot && ctx->timing >= 2) FLOW2D_HIP_TRY(mark(ctx, slot));
             st = flow2d::launch_sweep(ctx, p->data_constancy, frame_0, frame_1, flow_u, flow_v, du, dv, phi, ksi,
                                       p->width, p->height, p->pitch_bytes, p->hx, p->hy, p->equation_alpha, tdu, tdv);
             if (st != FLOW2D_OK) return st;
+            if (slot && ctx->timing >= 2) FLOW2D_HIP_TRY(mark(ctx, slot));
             std::swap(du, tdu);
             std::swap(dv, tdv);
             ++launches;
@@ -84,14 +98,16 @@ int flow2d_solve_level(flow2d_context* ctx, const float* frame_0, const float* f
         slot->rec.algorithm = algorithm;
         slot->rec.kernel_launches = launches;
         slot->rec.elapsed_ms = -1.f;
+        slot->rec.kernel_ms = -1.f;
+        slot->rec.algorithmic_bytes_per_launch = 40.0 * static_cast<double>(p->width) * static_cast<double>(p->height);
     }
     return FLOW2D_OK;
 }
 
-int flow2d_timing_enable(flow2d_context* ctx, int enabled)
+int flow2d_timing_enable(flow2d_context* ctx, int mode)
 {
-    if (!ctx) return FLOW2D_ERR_INVALID_ARGUMENT;
-    ctx->timing = enabled != 0;
+    if (!ctx || mode < 0 || mode > 2) return FLOW2D_ERR_INVALID_ARGUMENT;
+    ctx->timing = mode;
     return FLOW2D_OK;
 }
 
@@ -110,6 +126,15 @@ int flow2d_timing_get(flow2d_context* ctx, size_t index, flow2d_timing_record* o
     if (s.rec.elapsed_ms < 0.f) {
         FLOW2D_HIP_TRY(hipEventSynchronize(s.stop));
         FLOW2D_HIP_TRY(hipEventElapsedTime(&s.rec.elapsed_ms, s.start, s.stop));
+        if (!s.kernel_events.empty()) {
+            float total = 0.f;
+            for (size_t k = 0; k + 1 < s.kernel_events.size(); k += 2) {
+                float ms = 0.f;
+                FLOW2D_HIP_TRY(hipEventElapsedTime(&ms, s.kernel_events[k], s.kernel_events[k + 1]));
+                total += ms;
+            }
+            s.rec.kernel_ms = total;
+        }
     }
     *out = s.rec;
     return FLOW2D_OK;
@@ -121,6 +146,7 @@ int flow2d_timing_reset(flow2d_context* ctx)
     for (auto& s : ctx->timings) {
         (void)hipEventDestroy(s.start);
         (void)hipEventDestroy(s.stop);
+        for (hipEvent_t ev : s.kernel_events) (void)hipEventDestroy(ev);
     }
     ctx->timings.clear();
     return FLOW2D_OK;

@@ -107,29 +107,38 @@ HOST_API int flow2d_host_compute_flow(flow2d_host_flow* h, const float* frame_0,
 // the context's stream, no synchronisation.  0 on success.
 HOST_API int flow2d_host_compute_flow_device(flow2d_host_flow* h, void* dev_frame_0, void* dev_frame_1,
                                              void* dev_flow_u, void* dev_flow_v, const flow2d_host_params* params,
-                                             int collect_level_timings)
+                                             int timing_mode)
 {
     if (!h || !params) return 1;
     flow2d_host_params p = *params;
     OperationParameters bag;
     FillBag(bag, p);
-    h->flow.collect_level_timings = collect_level_timings != 0;
+    h->flow.timing_mode = timing_mode;
     auto dp = [](void* q) { return static_cast<DevicePtr>(reinterpret_cast<uintptr_t>(q)); };
     return h->flow.ComputeFlowDevice(dp(dev_frame_0), dp(dev_frame_1), dp(dev_flow_u), dp(dev_flow_v), bag) ? 0 : 2;
 }
 
-// Per-level solve times of the last run (needs collect_level_timings and a synchronised context).
-// Writes up to `capacity` triples (width, height, ms) and returns the number of levels.
+// Per-level solve records of the last run (needs timing_mode >= 1 and a synchronised context).
+// Writes up to `capacity` records of 6 floats (width, height, solve_ms, kernel_ms, kernel_launches,
+// algorithmic bytes per launch) and returns the number of levels.
 HOST_API size_t flow2d_host_level_timings(flow2d_host_flow* h, float* triples, size_t capacity)
 {
     if (!h) return 0;
     std::vector<FlowLevelTiming> t = h->flow.LastLevelTimings();
     for (size_t i = 0; i < t.size() && i < capacity; ++i) {
-        triples[3 * i + 0] = static_cast<float>(t[i].width);
-        triples[3 * i + 1] = static_cast<float>(t[i].height);
-        triples[3 * i + 2] = t[i].solve_ms;
+        triples[6 * i + 0] = static_cast<float>(t[i].width);
+        triples[6 * i + 1] = static_cast<float>(t[i].height);
+        triples[6 * i + 2] = t[i].solve_ms;
+        triples[6 * i + 3] = t[i].kernel_ms;
+        triples[6 * i + 4] = static_cast<float>(t[i].kernel_launches);
+        triples[6 * i + 5] = static_cast<float>(t[i].bytes_per_launch);
     }
     return t.size();
+}
+
+HOST_API void flow2d_host_reset_timings(flow2d_host_flow* h)
+{
+    if (h) h->flow.ResetLevelTimings();
 }
 
 // Omitting a bag key must make ComputeFlow print and return with the outputs untouched

@@ -135,6 +135,11 @@ DevicePtr OpticalFlow2D::Acquire()
 
 void OpticalFlow2D::Release(DevicePtr p) { free_planes_.push_back(p); }
 
+void OpticalFlow2D::ResetLevelTimings()
+{
+    if (context_) flow2d_timing_reset(context_);
+}
+
 std::vector<FlowLevelTiming> OpticalFlow2D::LastLevelTimings()
 {
     std::vector<FlowLevelTiming> out;
@@ -143,7 +148,8 @@ std::vector<FlowLevelTiming> OpticalFlow2D::LastLevelTimings()
     for (size_t i = 0; i < n; ++i) {
         flow2d_timing_record r;
         if (flow2d_timing_get(context_, i, &r) != FLOW2D_OK) break;
-        out.push_back({r.width, r.height, r.elapsed_ms});
+        out.push_back({r.width, r.height, r.elapsed_ms, r.kernel_ms, r.kernel_launches, r.algorithm,
+                       r.algorithmic_bytes_per_launch});
     }
     return out;
 }
@@ -262,8 +268,7 @@ bool OpticalFlow2D::RunPyramid(OperationParameters& params)
         }
     }
 
-    flow2d_timing_reset(context_);
-    flow2d_timing_enable(context_, collect_level_timings ? 1 : 0);
+    flow2d_timing_enable(context_, timing_mode);
 
     DevicePtr frame_0 = dev_frame_0_, frame_1 = dev_frame_1_, flow_u = dev_flow_u_, flow_v = dev_flow_v_;
     DevicePtr frame_0_res = Acquire(), frame_1_res = Acquire(), flow_du = Acquire(), flow_dv = Acquire();

@@ -49,7 +49,11 @@ private:
 
 struct FlowLevelTiming {
     size_t width, height;
-    float solve_ms;  // device time of the level's whole solve call (reference timer, cuda_operation_solve_2d.cpp:220,302)
+    float solve_ms;   // device time of the level's whole solve call (reference timer, cuda_operation_solve_2d.cpp:220,302)
+    float kernel_ms;  // timing_mode 2: summed launch durations of the level's dominant solver kernel, else -1
+    int kernel_launches;
+    int algorithm;
+    double bytes_per_launch;  // algorithmic bytes one launch of that kernel accounts for
 };
 
 class OpticalFlow2D : public OpticalFlowBase2D {
@@ -71,10 +75,11 @@ public:
     const DataSize3& ContainerSize() const { return dev_container_size_; }
     // Device time of the last ComputeFlow (events around upload..download), milliseconds.
     float LastTotalMs() const { return last_total_ms_; }
-    // When true the context's solver timing is collected per level (a few events per level).
-    bool collect_level_timings = false;
-    // Valid after a synchronisation of the context when collect_level_timings was set.
+    int timing_mode = 0;  // flow2d_timing_enable mode used during a run (0 off, 1 per level, 2 + per kernel launch)
+    // One record per level solved since the last ResetLevelTimings() (oldest first); call after the
+    // context has been synchronised.  Records accumulate across runs while timing_mode is non-zero.
     std::vector<FlowLevelTiming> LastLevelTimings();
+    void ResetLevelTimings();
 
     bool silent = false;
 

@@ -186,18 +186,23 @@ FLOW2D_API int flow2d_solve_level(flow2d_context* ctx, const float* frame_0, con
                                   const flow2d_solve_params* params, int* result_in_temp);
 
 /* ---- launch timing of the solver (measurement only; bench.py's roofline leg) ----------------
- * When enabled, every flow2d_solve_level call is bracketed by a pair of events on the context's
- * stream (no synchronisation).  After flow2d_synchronize the records can be read back. */
+ * mode 1: every flow2d_solve_level call is bracketed by a pair of events on the context's stream
+ * (the reference's own per-level timer, cuda_operation_solve_2d.cpp:220,302).  mode 2: additionally
+ * every launch of the level's dominant kernel (the Jacobi sweep, or the fused outer-iteration kernel)
+ * is bracketed by its own event pair.  Nothing synchronises; read the records after
+ * flow2d_synchronize.  mode 0 switches the collection off. */
 typedef struct flow2d_timing_record {
     size_t width, height;
     size_t outer, inner;
     int data_constancy;
-    int algorithm;          /* the algorithm actually used */
+    int algorithm;          /* the algorithm actually used (flow2d_solver_algorithm, never AUTO) */
     int kernel_launches;    /* launches of the dominant solver kernel inside the bracket */
     float elapsed_ms;       /* event time of the whole solve call */
+    float kernel_ms;        /* mode 2: sum of the dominant kernel's launch durations; -1 otherwise */
+    double algorithmic_bytes_per_launch; /* W*H*40 per sweep launch, W*H*(32+40*inner) per fused launch */
 } flow2d_timing_record;
 
-FLOW2D_API int flow2d_timing_enable(flow2d_context* ctx, int enabled);
+FLOW2D_API int flow2d_timing_enable(flow2d_context* ctx, int mode);
 FLOW2D_API int flow2d_timing_count(flow2d_context* ctx, size_t* count);
 FLOW2D_API int flow2d_timing_get(flow2d_context* ctx, size_t index, flow2d_timing_record* out);
 FLOW2D_API int flow2d_timing_reset(flow2d_context* ctx);
