@@ -9,6 +9,7 @@
 // 32 B per pixel for phi/ksi).  Arithmetic keeps the reference's order of operations; the file is
 // built with -ffp-contract=off so no multiply-add is fused.
 #include "common.hpp"
+#include "solver_math.hpp"
 
 namespace {
 
@@ -38,8 +39,8 @@ __device__ __forceinline__ void image_derivatives(const float* __restrict__ f0, 
                                                   const Neighbourhood& n, float hx, float hy, float& fx, float& fy,
                                                   float& ft)
 {
-    fx = (f0[n.r] - f0[n.l] + f1[n.r] - f1[n.l]) / (4.f * hx);
-    fy = (f0[n.d] - f0[n.u] + f1[n.d] - f1[n.u]) / (4.f * hy);
+    fx = flow2d_math::diff4(f0[n.r], f0[n.l], f1[n.r], f1[n.l], 4.f * hx);
+    fy = flow2d_math::diff4(f0[n.d], f0[n.u], f1[n.d], f1[n.u], 4.f * hy);
     ft = f1[n.c] - f0[n.c];
 }
 
@@ -55,19 +56,16 @@ __global__ __launch_bounds__(256) void phi_ksi_kernel(const float* __restrict__ 
     if (x >= w || y >= h) return;
     const Neighbourhood n = neighbourhood(x, y, w, h, pitch);
 
-    const float dux = (u[n.r] - u[n.l] + du[n.r] - du[n.l]) / (2.f * hx);
-    const float duy = (u[n.d] - u[n.u] + du[n.d] - du[n.u]) / (2.f * hy);
-    const float dvx = (v[n.r] - v[n.l] + dv[n.r] - dv[n.l]) / (2.f * hx);
-    const float dvy = (v[n.d] - v[n.u] + dv[n.d] - dv[n.u]) / (2.f * hy);
-    phi[n.c] = 1.f / (2.f * sqrtf(dux * dux + duy * duy + dvx * dvx + dvy * dvy + e_smooth * e_smooth));
+    using namespace flow2d_math;
+    const float dux = diff4(u[n.r], u[n.l], du[n.r], du[n.l], 2.f * hx);
+    const float duy = diff4(u[n.d], u[n.u], du[n.d], du[n.u], 2.f * hy);
+    const float dvx = diff4(v[n.r], v[n.l], dv[n.r], dv[n.l], 2.f * hx);
+    const float dvy = diff4(v[n.d], v[n.u], dv[n.d], dv[n.u], 2.f * hy);
+    phi[n.c] = phi_value(dux, duy, dvx, dvy, e_smooth);
 
     float fx, fy, ft;
     image_derivatives(f0, f1, n, hx, hy, fx, fy, ft);
-    const float J11 = fx * fx, J22 = fy * fy, J33 = ft * ft, J12 = fx * fy, J13 = fx * ft, J23 = fy * ft;
-    const float a = du[n.c], b = dv[n.c];
-    float s = (J11 * a + J12 * b + J13) * a + (J12 * a + J22 * b + J23) * b + (J13 * a + J23 * b + J33);
-    s = static_cast<float>(s > 0) * s;
-    ksi[n.c] = 1.f / (2.f * sqrtf(s + e_data * e_data));
+    ksi[n.c] = ksi_value(fx, fy, ft, du[n.c], dv[n.c], e_data);
 }
 
 // The pointwise Jacobi update shared by solve_2d (solve_2d.cu:332-374) and solve_2d_grad (:889-931).
@@ -85,22 +83,19 @@ __device__ __forceinline__ void jacobi_update(const float* __restrict__ u, const
     const float yp = static_cast<float>(y < h - 1) * hy_2;
     const float ym = static_cast<float>(y > 0) * hy_2;
 
+    using namespace flow2d_math;
     const float pc = phi[n.c];
-    const float phi_xp = (phi[n.r] + pc) / 2.f;
-    const float phi_xm = (phi[n.l] + pc) / 2.f;
-    const float phi_yp = (phi[n.d] + pc) / 2.f;
-    const float phi_ym = (phi[n.u] + pc) / 2.f;
-
-    const float sumH = (xp * phi_xp + xm * phi_xm + yp * phi_yp + ym * phi_ym);
-    const float uc = u[n.c], vc = v[n.c];
-    const float sumU = phi_xp * xp * (u[n.r] + du[n.r] - uc) + phi_xm * xm * (u[n.l] + du[n.l] - uc) +
-                       phi_yp * yp * (u[n.d] + du[n.d] - uc) + phi_ym * ym * (u[n.u] + du[n.u] - uc);
-    const float sumV = phi_xp * xp * (v[n.r] + dv[n.r] - vc) + phi_xm * xm * (v[n.l] + dv[n.l] - vc) +
-                       phi_yp * yp * (v[n.d] + dv[n.d] - vc) + phi_ym * ym * (v[n.u] + dv[n.u] - vc);
-
-    const float k = ksi[n.c];
-    const float r_du = (k * (-J13 - J12 * dv[n.c]) + sumU) / (k * J11 + sumH);
-    const float r_dv = (k * (-J23 - J12 * r_du) + sumV) / (k * J22 + sumH);
+    const float wxp = face_phi(phi[n.r], pc) * xp;
+    const float wxm = face_phi(phi[n.l], pc) * xm;
+    const float wyp = face_phi(phi[n.d], pc) * yp;
+    const float wym = face_phi(phi[n.u], pc) * ym;
+    const float sumH = sum_weights(wxp, wxm, wyp, wym);
+    const float sumU = sum_flux(wxp, wxm, wyp, wym, u[n.r] + du[n.r], u[n.l] + du[n.l], u[n.d] + du[n.d],
+                                u[n.u] + du[n.u], u[n.c]);
+    const float sumV = sum_flux(wxp, wxm, wyp, wym, v[n.r] + dv[n.r], v[n.l] + dv[n.l], v[n.d] + dv[n.d],
+                                v[n.u] + dv[n.u], v[n.c]);
+    float r_du, r_dv;
+    point_update(ksi[n.c], J11, J22, J12, J13, J23, sumH, sumU, sumV, dv[n.c], r_du, r_dv);
     tdu[n.c] = r_du;
     tdv[n.c] = r_dv;
 }
@@ -173,11 +168,8 @@ __global__ __launch_bounds__(512) void sweep_grad_kernel(const float* __restrict
     const float fxt = (s_ft[ty][xb] - s_ft[ty][xa]) * hx_1;
     const float fyt = (s_ft[yb][tx] - s_ft[ya][tx]) * hy_1;
 
-    const float J11 = fxx * fxx + fxy * fxy;
-    const float J22 = fxy * fxy + fyy * fyy;
-    const float J12 = fxx * fxy + fxy * fyy;
-    const float J13 = fxx * fxt + fxy * fyt;
-    const float J23 = fxy * fxt + fyy * fyt;
+    float J11, J22, J12, J13, J23;
+    flow2d_math::gradient_tensor(fxx, fxy, fyy, fxt, fyt, J11, J22, J12, J13, J23);
     jacobi_update(u, v, du, dv, phi, ksi, n, x, y, w, h, hx, hy, alpha, J11, J22, J12, J13, J23, tdu, tdv);
 }
 

@@ -1,0 +1,359 @@
+// Fused outer iteration of the variational solver for gfx950: robust weights (phi, ksi) + ALL inner
+// Jacobi sweeps of one outer iteration in ONE pass over HBM.
+//
+// The reference launches compute_phi_ksi once and solve_2d* `inner` times per outer iteration
+// (cuda_operation_solve_2d.cpp:238-299), moving 32 + 40*inner bytes per pixel through DRAM.  Here a
+// wavefront owns a strip of 64 columns and streams down the image row by row with every plane it needs
+// held in registers: each lane keeps, for its column, 3-row sliding windows of the inputs and of the
+// intermediate flow of every sweep, and the per-pixel coefficients in a short delay line.  Sweep k of
+// row r-2-k runs as soon as sweep k-1 has produced row r-1-k (time skewing), so one trip down the strip
+// performs phi/ksi and all sweeps while reading f0, f1, u, v, du, dv once and writing du, dv once
+// (about 32 B per pixel instead of 32 + 40*inner).
+//
+//  - x neighbours come from the adjacent lanes with DPP wave shifts (no LDS, no barriers; the four waves
+//    of a workgroup are independent strips).  A strip computes INNER+1 halo columns per side redundantly,
+//    so 64 - 2*(INNER+1) columns of each wave are stored.
+//  - y neighbours are the lane's own registers (sliding windows, rotated by unrolling the row loop).
+//  - Image borders follow the reference's reflect rule (-1 -> 1, n -> n-2) by substituting the opposite
+//    neighbour at the border pixel; rows/columns outside the image are computed on clamped addresses and
+//    never reach a stored value.
+//  - Every pixel goes through exactly the expressions of solve_2d.cu (solver_math.hpp), in the same
+//    order, without FMA contraction: results are bit-identical to the per-sweep kernels and the oracle.
+//
+// Bound: fp32 VALU issue (about 480 instructions per pixel and outer iteration at inner = 5), not HBM.
+#include <utility>
+
+#include "common.hpp"
+#include "solver_math.hpp"
+
+namespace {
+
+using namespace flow2d_math;
+
+struct FusedArgs {
+    const float* f0;
+    const float* f1;
+    const float* u;
+    const float* v;
+    const float* du;
+    const float* dv;
+    float* out_du;
+    float* out_dv;
+    int w, h, pitch;
+    int rows_per_strip;
+    float hx, hy, alpha, e_smooth, e_data;
+};
+
+// lane i receives lane i-1 (wave_shr:1) / lane i+1 (wave_shl:1); the end lanes keep their own value
+__device__ __forceinline__ float from_left(float v)
+{
+    const int i = __float_as_int(v);
+    return __int_as_float(__builtin_amdgcn_update_dpp(i, i, 0x138, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float from_right(float v)
+{
+    const int i = __float_as_int(v);
+    return __int_as_float(__builtin_amdgcn_update_dpp(i, i, 0x130, 0xf, 0xf, false));
+}
+
+// static per-pixel coefficients of one outer iteration (what the sweeps need besides the moving flow)
+struct Coef {
+    float wxp, wxm, wyp, wym;  // face diffusivity * neighbour weight (solve_2d.cu:337-346)
+    float sumH;
+    float ksi, J11, J22, J12, J13, J23;
+    float uc, vc;
+};
+
+template <int INNER, bool GRAD>
+struct Strip {
+    static constexpr int kHalo = INNER + 1;
+    static constexpr int kValid = 64 - 2 * kHalo;
+    static constexpr int kRing = ((INNER + 1 + 2) / 3) * 3;  // coefficient ring, a multiple of the 3-row windows
+
+    // 3-row sliding windows, slot = row mod 3
+    float f0w[3], f1w[3], uw[3], vw[3], duw[3], dvw[3];
+    float phiw[3];
+    float fxw[3], fyw[3], ftw[3];  // GRAD only
+    float U[INNER][3], V[INNER][3];  // U[k] = (u + du^k) rows around the row sweep k+1 is working on
+    float dvc[INNER];                // dv^k of the row sweep k+1 processes in the current step
+    Coef C[kRing];
+    // brightness derivatives and ksi of the row stage W consumes next (produced by stage P one step earlier)
+    float p_fx, p_fy, p_ft, p_ksi;
+    // prefetched input row
+    float n_f0, n_f1, n_u, n_v, n_du, n_dv;
+};
+
+template <int INNER, bool GRAD, int J>
+__device__ __forceinline__ void strip_step(Strip<INNER, GRAD>& s, const FusedArgs& a, int r, int x, int xc, bool at_l,
+                                           bool at_r, bool lane_stores, int y0, int y1, float xp, float xm,
+                                           float hx_2, float hy_2)
+{
+    using S = Strip<INNER, GRAD>;
+    constexpr int kRing = S::kRing;
+    // slots of input rows r, r-1, r-2 (J == r - first_row mod kRing, kRing % 3 == 0)
+    constexpr int s0 = J % 3, s1 = (J + 2) % 3, s2 = (J + 1) % 3;
+    const int w = a.w, h = a.h;
+
+    // ---- commit the prefetched row r (its slot still holds row r-3: sweep 1 needs that row's dv) ----------
+    const float dv_row3 = s.dvw[s0];
+    s.f0w[s0] = s.n_f0;
+    s.f1w[s0] = s.n_f1;
+    s.uw[s0] = s.n_u;
+    s.vw[s0] = s.n_v;
+    s.duw[s0] = s.n_du;
+    s.dvw[s0] = s.n_dv;
+    {  // prefetch row r+1 (clamped: rows outside the image are never used by a stored pixel)
+        const int rn = min(max(r + 1, 0), h - 1);
+        const size_t o = static_cast<size_t>(rn) * a.pitch + xc;
+        s.n_f0 = a.f0[o];
+        s.n_f1 = a.f1[o];
+        s.n_u = a.u[o];
+        s.n_v = a.v[o];
+        s.n_du = a.du[o];
+        s.n_dv = a.dv[o];
+    }
+
+    // ---- stage P, row rp = r-1: phi, brightness derivatives, ksi (solve_2d.cu:138-197) -------------------
+    const int rp = r - 1;
+    float fx, fy, ft, ksi;
+    {
+        const bool top = (rp == 0), bot = (rp == h - 1);
+        auto lr = [&](float c, float& l, float& rr) {
+            const float dl = from_left(c), dr = from_right(c);
+            l = at_l ? dr : dl;
+            rr = at_r ? dl : dr;
+        };
+        auto ud = [&](const float (&win)[3], float& up, float& dn) {
+            const float a_up = win[s2], a_dn = win[s0];
+            up = top ? a_dn : a_up;
+            dn = bot ? a_up : a_dn;
+        };
+        float uL, uR, uU, uD, duL, duR, duU, duD, vL, vR, vU, vD, dvL, dvR, dvU, dvD;
+        lr(s.uw[s1], uL, uR);
+        lr(s.duw[s1], duL, duR);
+        lr(s.vw[s1], vL, vR);
+        lr(s.dvw[s1], dvL, dvR);
+        ud(s.uw, uU, uD);
+        ud(s.duw, duU, duD);
+        ud(s.vw, vU, vD);
+        ud(s.dvw, dvU, dvD);
+        const float dux = diff4(uR, uL, duR, duL, 2.f * a.hx);
+        const float duy = diff4(uD, uU, duD, duU, 2.f * a.hy);
+        const float dvx = diff4(vR, vL, dvR, dvL, 2.f * a.hx);
+        const float dvy = diff4(vD, vU, dvD, dvU, 2.f * a.hy);
+        s.phiw[s1] = phi_value(dux, duy, dvx, dvy, a.e_smooth);
+
+        float f0L, f0R, f0U, f0D, f1L, f1R, f1U, f1D;
+        lr(s.f0w[s1], f0L, f0R);
+        lr(s.f1w[s1], f1L, f1R);
+        ud(s.f0w, f0U, f0D);
+        ud(s.f1w, f1U, f1D);
+        fx = diff4(f0R, f0L, f1R, f1L, 4.f * a.hx);
+        fy = diff4(f0D, f0U, f1D, f1U, 4.f * a.hy);
+        ft = s.f1w[s1] - s.f0w[s1];
+        ksi = ksi_value(fx, fy, ft, s.duw[s1], s.dvw[s1], a.e_data);
+        if (GRAD) {
+            s.fxw[s1] = fx;
+            s.fyw[s1] = fy;
+            s.ftw[s1] = ft;
+        }
+    }
+
+    // ---- stage W, row rw = r-2: face weights and the motion tensor -> coefficient ring --------------------
+    const int rw = r - 2;
+    {
+        constexpr int cw = (J + 2 * kRing - 2) % kRing;
+        Coef& c = s.C[cw];
+        const bool top = (rw == 0), bot = (rw == h - 1);
+        const float pc = s.phiw[s2];
+        const float pl0 = from_left(pc), pr0 = from_right(pc);
+        const float pL = at_l ? pr0 : pl0, pR = at_r ? pl0 : pr0;
+        const float pu0 = s.phiw[s0], pd0 = s.phiw[s1];  // rows r-3 (slot of r) ... careful: phi ring lags by one
+        // phi ring: slot s1 holds row r-1 (just written), s2 holds row r-2, s0 holds row r-3
+        const float pU = top ? pd0 : pu0, pD = bot ? pu0 : pd0;
+        const float yp = static_cast<float>(rw < h - 1) * hy_2;
+        const float ym = static_cast<float>(rw > 0) * hy_2;
+        c.wxp = face_phi(pR, pc) * xp;
+        c.wxm = face_phi(pL, pc) * xm;
+        c.wyp = face_phi(pD, pc) * yp;
+        c.wym = face_phi(pU, pc) * ym;
+        c.sumH = sum_weights(c.wxp, c.wxm, c.wyp, c.wym);
+        c.ksi = s.p_ksi;
+        c.uc = s.uw[s2];
+        c.vc = s.vw[s2];
+        if (!GRAD) {
+            c.J11 = s.p_fx * s.p_fx;
+            c.J22 = s.p_fy * s.p_fy;
+            c.J12 = s.p_fx * s.p_fy;
+            c.J13 = s.p_fx * s.p_ft;
+            c.J23 = s.p_fy * s.p_ft;
+        } else {
+            // second derivatives inside the reference's 16x8 blocks, own value replicated at block and
+            // image edges (solve_2d.cu:816-841,872-876); fx/fy/ft rings: s1 = row r-1, s2 = r-2, s0 = r-3
+            const int tx = x & 15, ty = rw & 7;
+            const bool x_lo = (tx == 0), x_hi = (tx == 15) || (x == w - 1);
+            const bool y_lo = (ty == 0), y_hi = (ty == 7) || (rw == h - 1);
+            const float fxc = s.fxw[s2], fyc = s.fyw[s2], ftc = s.ftw[s2];
+            // cross-lane reads first, with every lane active; select afterwards (a DPP read under a
+            // divergent branch would see disabled source lanes)
+            const float fx_l0 = from_left(fxc), fx_r0 = from_right(fxc);
+            const float ft_l0 = from_left(ftc), ft_r0 = from_right(ftc);
+            const float fx_l = x_lo ? fxc : fx_l0, fx_r = x_hi ? fxc : fx_r0;
+            const float ft_l = x_lo ? ftc : ft_l0, ft_r = x_hi ? ftc : ft_r0;
+            const float fx_u = y_lo ? fxc : s.fxw[s0], fx_d = y_hi ? fxc : s.fxw[s1];
+            const float fy_u = y_lo ? fyc : s.fyw[s0], fy_d = y_hi ? fyc : s.fyw[s1];
+            const float ft_u = y_lo ? ftc : s.ftw[s0], ft_d = y_hi ? ftc : s.ftw[s1];
+            const float hx_1 = 1.0 / (2.0 * a.hx);  // double, rounded to float (solve_2d.cu:868-869)
+            const float hy_1 = 1.0 / (2.0 * a.hy);
+            const float fxx = (fx_r - fx_l) * hx_1;
+            const float fxy = (fx_d - fx_u) * hy_1;
+            const float fyy = (fy_d - fy_u) * hy_1;
+            const float fxt = (ft_r - ft_l) * hx_1;
+            const float fyt = (ft_d - ft_u) * hy_1;
+            gradient_tensor(fxx, fxy, fyy, fxt, fyt, c.J11, c.J22, c.J12, c.J13, c.J23);
+        }
+        // u + du of row r-2 enters sweep 1's window
+        s.U[0][s2] = s.uw[s2] + s.duw[s2];
+        s.V[0][s2] = s.vw[s2] + s.dvw[s2];
+    }
+    // stage P's outputs of this step are what stage W consumes in the next one
+    s.p_fx = fx;
+    s.p_fy = fy;
+    s.p_ft = ft;
+    s.p_ksi = ksi;
+
+    // ---- sweeps k = 1..INNER, row rk = r-2-k (solve_2d.cu:349-367) ------------------------------------------
+    float dv_in = dv_row3;  // dv^0 of row r-3
+#pragma unroll
+    for (int k = 1; k <= INNER; ++k) {
+        const int rk = r - 2 - k;
+        // window slots of rows rk-1, rk, rk+1 (rk = r-2-k  ->  slot (J - 2 - k) mod 3)
+        const int sc = (J + 3 * 8 - 2 - k) % 3, su = (sc + 2) % 3, sd = (sc + 1) % 3;
+        const Coef& c = s.C[(J + 4 * kRing - 2 - k) % kRing];
+        const bool top = (rk == 0), bot = (rk == h - 1);
+        const float Uc = s.U[k - 1][sc], Vc = s.V[k - 1][sc];
+        const float Ul0 = from_left(Uc), Ur0 = from_right(Uc), Vl0 = from_left(Vc), Vr0 = from_right(Vc);
+        const float UL = at_l ? Ur0 : Ul0, UR = at_r ? Ul0 : Ur0;
+        const float VL = at_l ? Vr0 : Vl0, VR = at_r ? Vl0 : Vr0;
+        const float Uu0 = s.U[k - 1][su], Ud0 = s.U[k - 1][sd], Vu0 = s.V[k - 1][su], Vd0 = s.V[k - 1][sd];
+        const float UU = top ? Ud0 : Uu0, UD = bot ? Uu0 : Ud0;
+        const float VU = top ? Vd0 : Vu0, VD = bot ? Vu0 : Vd0;
+        const float sumU = sum_flux(c.wxp, c.wxm, c.wyp, c.wym, UR, UL, UD, UU, c.uc);
+        const float sumV = sum_flux(c.wxp, c.wxm, c.wyp, c.wym, VR, VL, VD, VU, c.vc);
+        float du_new, dv_new;
+        point_update(c.ksi, c.J11, c.J22, c.J12, c.J13, c.J23, c.sumH, sumU, sumV, dv_in, du_new, dv_new);
+        if (k < INNER) {
+            s.U[k][sc] = c.uc + du_new;
+            s.V[k][sc] = c.vc + dv_new;
+            dv_in = s.dvc[k];      // dv^k of row r-3-k, produced by this sweep one step ago
+            s.dvc[k] = dv_new;     // dv^k of row r-2-k, for the next step
+        } else if (lane_stores && rk >= y0 && rk < y1) {
+            const size_t o = static_cast<size_t>(rk) * a.pitch + x;
+            a.out_du[o] = du_new;
+            a.out_dv[o] = dv_new;
+        }
+    }
+}
+
+template <int INNER, bool GRAD, size_t... Js>
+__device__ __forceinline__ void strip_steps(Strip<INNER, GRAD>& s, const FusedArgs& a, int r_base, int x, int xc,
+                                            bool at_l, bool at_r, bool lane_stores, int y0, int y1, float xp, float xm,
+                                            float hx_2, float hy_2, std::index_sequence<Js...>)
+{
+    (strip_step<INNER, GRAD, static_cast<int>(Js)>(s, a, r_base + static_cast<int>(Js), x, xc, at_l, at_r, lane_stores,
+                                                   y0, y1, xp, xm, hx_2, hy_2),
+     ...);
+}
+
+template <int INNER, bool GRAD>
+__global__ __launch_bounds__(256) void fused_outer_kernel(FusedArgs a)
+{
+    using S = Strip<INNER, GRAD>;
+    const int lane = threadIdx.x & 63;
+    const int strip_x = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (strip_x * S::kValid >= a.w) return;  // whole wave leaves; waves never synchronise with each other
+    const int x = strip_x * S::kValid - S::kHalo + lane;
+    const int xc = min(max(x, 0), a.w - 1);
+    const int y0 = blockIdx.y * a.rows_per_strip;
+    const int y1 = min(y0 + a.rows_per_strip, a.h);
+    const bool at_l = (x == 0), at_r = (x == a.w - 1);
+    const bool lane_stores = lane >= S::kHalo && lane < 64 - S::kHalo && x < a.w;
+    const float hx_2 = a.alpha / (a.hx * a.hx);
+    const float hy_2 = a.alpha / (a.hy * a.hy);
+    const float xp = static_cast<float>(x < a.w - 1) * hx_2;
+    const float xm = static_cast<float>(x > 0) * hx_2;
+
+    S s;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        s.f0w[i] = s.f1w[i] = s.uw[i] = s.vw[i] = s.duw[i] = s.dvw[i] = s.phiw[i] = 0.f;
+        s.fxw[i] = s.fyw[i] = s.ftw[i] = 0.f;
+    }
+#pragma unroll
+    for (int k = 0; k < INNER; ++k) {
+        s.dvc[k] = 0.f;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) s.U[k][i] = s.V[k][i] = 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < S::kRing; ++i) s.C[i] = Coef{0.f, 0.f, 0.f, 0.f, 1.f, 1.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    s.p_fx = s.p_fy = s.p_ft = s.p_ksi = 0.f;
+
+    // first input row: the strip's first stored row needs INNER+1 rows of halo above it
+    const int r_first = y0 - S::kHalo;
+    {
+        const int rn = min(max(r_first, 0), a.h - 1);
+        const size_t o = static_cast<size_t>(rn) * a.pitch + xc;
+        s.n_f0 = a.f0[o];
+        s.n_f1 = a.f1[o];
+        s.n_u = a.u[o];
+        s.n_v = a.v[o];
+        s.n_du = a.du[o];
+        s.n_dv = a.dv[o];
+    }
+    // the last stored row y1-1 leaves the last sweep at input row (y1-1) + 2 + INNER
+    const int r_last = y1 - 1 + 2 + INNER;
+    for (int r = r_first; r <= r_last; r += S::kRing)
+        strip_steps<INNER, GRAD>(s, a, r, x, xc, at_l, at_r, lane_stores, y0, y1, xp, xm, hx_2, hy_2,
+                                 std::make_index_sequence<S::kRing>{});
+}
+
+template <bool GRAD>
+int launch_for_inner(int inner, dim3 grid, hipStream_t stream, const FusedArgs& a)
+{
+    switch (inner) {
+        case 1: fused_outer_kernel<1, GRAD><<<grid, 256, 0, stream>>>(a); return 0;
+        case 2: fused_outer_kernel<2, GRAD><<<grid, 256, 0, stream>>>(a); return 0;
+        case 3: fused_outer_kernel<3, GRAD><<<grid, 256, 0, stream>>>(a); return 0;
+        case 4: fused_outer_kernel<4, GRAD><<<grid, 256, 0, stream>>>(a); return 0;
+        case 5: fused_outer_kernel<5, GRAD><<<grid, 256, 0, stream>>>(a); return 0;
+        default: return 1;
+    }
+}
+
+}  // namespace
+
+namespace flow2d {
+
+bool fused_supports(size_t inner) { return inner >= 1 && inner <= 5; }
+
+// One outer iteration: reads du/dv (previous outer iteration), writes out_du/out_dv (after `inner` sweeps).
+int launch_fused_outer(flow2d_context* ctx, int constancy, const float* f0, const float* f1, const float* u,
+                       const float* v, const float* du, const float* dv, size_t w, size_t h, size_t pitch_bytes,
+                       float hx, float hy, float alpha, float e_smooth, float e_data, size_t inner, float* out_du,
+                       float* out_dv, int rows_per_strip)
+{
+    if (!fused_supports(inner)) return FLOW2D_ERR_UNSUPPORTED;
+    FusedArgs a{f0, f1, u, v, du, dv, out_du, out_dv, (int)w, (int)h, (int)(pitch_bytes / 4), rows_per_strip,
+                hx, hy, alpha, e_smooth, e_data};
+    const int valid = 64 - 2 * ((int)inner + 1);
+    const unsigned strips_x = div_up(w, valid);
+    const dim3 grid(div_up(strips_x, 4), div_up(h, rows_per_strip));
+    const int rc = constancy == FLOW2D_CONSTANCY_GRADIENT ? launch_for_inner<true>((int)inner, grid, ctx->stream, a)
+                                                          : launch_for_inner<false>((int)inner, grid, ctx->stream, a);
+    if (rc) return FLOW2D_ERR_UNSUPPORTED;
+    FLOW2D_CHECK_LAUNCH();
+    return FLOW2D_OK;
+}
+
+}  // namespace flow2d

@@ -2,6 +2,7 @@
 // Replaces the launch loop of CudaOperationSolve2D::Execute
 // (src/cuda_operations/2d/cuda_operation_solve_2d.cpp:229-300) without its per-sweep host
 // synchronisation (:291): everything is queued on the context's stream.
+#include <cstdlib>
 #include <utility>
 
 #include "common.hpp"
@@ -13,6 +14,11 @@ int launch_phi_ksi(flow2d_context* ctx, const float* f0, const float* f1, const 
 int launch_sweep(flow2d_context* ctx, int constancy, const float* f0, const float* f1, const float* u, const float* v,
                  const float* du, const float* dv, const float* phi, const float* ksi, size_t w, size_t h,
                  size_t pitch_bytes, float hx, float hy, float alpha, float* tdu, float* tdv);
+bool fused_supports(size_t inner);
+int launch_fused_outer(flow2d_context* ctx, int constancy, const float* f0, const float* f1, const float* u,
+                       const float* v, const float* du, const float* dv, size_t w, size_t h, size_t pitch_bytes,
+                       float hx, float hy, float alpha, float e_smooth, float e_data, size_t inner, float* out_du,
+                       float* out_dv, int rows_per_strip);
 }  // namespace flow2d
 
 namespace {
@@ -47,7 +53,11 @@ int flow2d_solve_level(flow2d_context* ctx, const float* frame_0, const float* f
         return FLOW2D_ERR_UNSUPPORTED;
     if (p->algorithm < FLOW2D_SOLVER_AUTO || p->algorithm > FLOW2D_SOLVER_FUSED) return FLOW2D_ERR_INVALID_ARGUMENT;
 
-    int algorithm = FLOW2D_SOLVER_PER_SWEEP;
+    int algorithm = p->algorithm;
+    if (algorithm == FLOW2D_SOLVER_AUTO)
+        algorithm = flow2d::fused_supports(p->inner_iterations_count) ? FLOW2D_SOLVER_FUSED : FLOW2D_SOLVER_PER_SWEEP;
+    if (algorithm == FLOW2D_SOLVER_FUSED && !flow2d::fused_supports(p->inner_iterations_count))
+        return FLOW2D_ERR_UNSUPPORTED;
 
     flow2d_timing_slot* slot = nullptr;
     if (ctx->timing) {
@@ -70,7 +80,23 @@ int flow2d_solve_level(flow2d_context* ctx, const float* frame_0, const float* f
     float* tdu = temp_du;
     float* tdv = temp_dv;
     int launches = 0;
-    for (size_t i = 0; i < p->outer_iterations_count; ++i) {
+    static const int rows_env = std::getenv("FLOW2D_FUSED_ROWS") ? std::atoi(std::getenv("FLOW2D_FUSED_ROWS")) : 0;
+    for (size_t i = 0; algorithm == FLOW2D_SOLVER_FUSED && i < p->outer_iterations_count; ++i) {
+        // one launch per outer iteration: phi/ksi and all inner sweeps in one pass (solve_fused.hip);
+        // phi and ksi are not materialised in this mode.
+        const int rows = rows_env > 0 ? rows_env : 64;
+        if (slot && ctx->timing >= 2) FLOW2D_HIP_TRY(mark(ctx, slot));
+        int st = flow2d::launch_fused_outer(ctx, p->data_constancy, frame_0, frame_1, flow_u, flow_v, du, dv, p->width,
+                                            p->height, p->pitch_bytes, p->hx, p->hy, p->equation_alpha,
+                                            p->equation_smoothness, p->equation_data, p->inner_iterations_count, tdu,
+                                            tdv, rows);
+        if (st != FLOW2D_OK) return st;
+        if (slot && ctx->timing >= 2) FLOW2D_HIP_TRY(mark(ctx, slot));
+        std::swap(du, tdu);
+        std::swap(dv, tdv);
+        ++launches;
+    }
+    for (size_t i = 0; algorithm == FLOW2D_SOLVER_PER_SWEEP && i < p->outer_iterations_count; ++i) {
         int st = flow2d::launch_phi_ksi(ctx, frame_0, frame_1, flow_u, flow_v, du, dv, p->width, p->height,
                                         p->pitch_bytes, p->hx, p->hy, p->equation_smoothness, p->equation_data, phi,
                                         ksi);
@@ -99,7 +125,8 @@ int flow2d_solve_level(flow2d_context* ctx, const float* frame_0, const float* f
         slot->rec.kernel_launches = launches;
         slot->rec.elapsed_ms = -1.f;
         slot->rec.kernel_ms = -1.f;
-        slot->rec.algorithmic_bytes_per_launch = 40.0 * static_cast<double>(p->width) * static_cast<double>(p->height);
+        const double per_px = algorithm == FLOW2D_SOLVER_FUSED ? 32.0 + 40.0 * p->inner_iterations_count : 40.0;
+        slot->rec.algorithmic_bytes_per_launch = per_px * static_cast<double>(p->width) * static_cast<double>(p->height);
     }
     return FLOW2D_OK;
 }

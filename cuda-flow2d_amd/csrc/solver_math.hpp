@@ -1,0 +1,66 @@
+// Pointwise arithmetic of the variational solver, shared by the per-sweep kernels (solve.hip) and the
+// fused outer-iteration kernel (solve_fused.hip) so both evaluate literally the same expressions.
+// Operation order and float/double promotions are those of the reference's src/kernels/solve_2d.cu
+// (lines cited per function); built with -ffp-contract=off, so nothing is fused.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+namespace flow2d_math {
+
+// central difference of (a + da) as the reference sums it: (aP - aM + daP - daM) / den
+// (solve_2d.cu:141-157 with den = 2*h; :164-171 with den = 4*h for the two frames)
+__device__ __forceinline__ float diff4(float aP, float aM, float bP, float bM, float den)
+{
+    return (aP - aM + bP - bM) / den;
+}
+
+// smoothness diffusivity, solve_2d.cu:161-162
+__device__ __forceinline__ float phi_value(float dux, float duy, float dvx, float dvy, float e_smooth)
+{
+    return 1.f / (2.f * sqrtf(dux * dux + duy * duy + dvx * dvx + dvy * dvy + e_smooth * e_smooth));
+}
+
+// data-term robustifier from the brightness tensor, solve_2d.cu:176-196
+__device__ __forceinline__ float ksi_value(float fx, float fy, float ft, float du, float dv, float e_data)
+{
+    const float J11 = fx * fx, J22 = fy * fy, J33 = ft * ft, J12 = fx * fy, J13 = fx * ft, J23 = fy * ft;
+    float s = (J11 * du + J12 * dv + J13) * du + (J12 * du + J22 * dv + J23) * dv + (J13 * du + J23 * dv + J33);
+    s = static_cast<float>(s > 0) * s;
+    return 1.f / (2.f * sqrtf(s + e_data * e_data));
+}
+
+// face diffusivity, solve_2d.cu:343-346
+__device__ __forceinline__ float face_phi(float neighbour, float centre) { return (neighbour + centre) / 2.f; }
+
+// sumH of solve_2d.cu:349 from the four face weights w = face_phi * {xp,xm,yp,ym}
+__device__ __forceinline__ float sum_weights(float wxp, float wxm, float wyp, float wym) { return (wxp + wxm + wyp + wym); }
+
+// sumU / sumV of solve_2d.cu:350-359: neighbours are the full flow (u + du) of the previous sweep
+__device__ __forceinline__ float sum_flux(float wxp, float wxm, float wyp, float wym, float nR, float nL, float nD,
+                                          float nU, float centre)
+{
+    return wxp * (nR - centre) + wxm * (nL - centre) + wyp * (nD - centre) + wym * (nU - centre);
+}
+
+// the coupled 2x2 update of solve_2d.cu:361-367 (dv' uses the fresh du')
+__device__ __forceinline__ void point_update(float ksi, float J11, float J22, float J12, float J13, float J23,
+                                             float sumH, float sumU, float sumV, float dv_old, float& du_new,
+                                             float& dv_new)
+{
+    du_new = (ksi * (-J13 - J12 * dv_old) + sumU) / (ksi * J11 + sumH);
+    dv_new = (ksi * (-J23 - J12 * du_new) + sumV) / (ksi * J22 + sumH);
+}
+
+// gradient-constancy tensor from the second derivatives, solve_2d.cu:879-884
+__device__ __forceinline__ void gradient_tensor(float fxx, float fxy, float fyy, float fxt, float fyt, float& J11,
+                                                float& J22, float& J12, float& J13, float& J23)
+{
+    J11 = fxx * fxx + fxy * fxy;
+    J22 = fxy * fxy + fyy * fyy;
+    J12 = fxx * fxy + fxy * fyy;
+    J13 = fxx * fxt + fxy * fyt;
+    J23 = fxy * fxt + fyy * fyt;
+}
+
+}  // namespace flow2d_math

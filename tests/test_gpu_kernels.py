@@ -105,10 +105,10 @@ def test_median_rejects_bad_window(ctx, flow2d, oracle):
     assert e.value.status == 1
 
 
-@pytest.mark.parametrize("algorithm", [1, 0])
+@pytest.mark.parametrize("algorithm", [1, 2, 0])
 @pytest.mark.parametrize("constancy", [0, 1])
-@pytest.mark.parametrize("outer,inner", [(2, 3), (3, 2), (1, 5)])
-@pytest.mark.parametrize("w,h,cw,ch", SIZES[:4])
+@pytest.mark.parametrize("outer,inner", [(2, 3), (3, 2), (1, 5), (2, 1), (1, 4)])
+@pytest.mark.parametrize("w,h,cw,ch", SIZES[:4] + [(300, 150, 320, 160), (52, 64, 64, 64), (53, 65, 64, 80)])
 def test_solve_level(ctx, oracle, w, h, cw, ch, outer, inner, constancy, algorithm):
     f0, f1, u, v, _, _ = level_fields(oracle, w, h, 7)
     hx, hy = np.float32(cw / w), np.float32(ch / h)
@@ -119,5 +119,21 @@ def test_solve_level(ctx, oracle, w, h, cw, ch, outer, inner, constancy, algorit
     odu, odv, ophi, oksi = oracle.solve_level(f0, f1, u, v, w, h, hx, hy, 3.5, 0.001, 0.001, outer, inner, constancy)
     assert np.array_equal(rdu.download(w, h), odu)
     assert np.array_equal(rdv.download(w, h), odv)
-    # the pointer-swap contract of the reference (cuda_operation_solve_2d.cpp:288-289)
-    assert (rdu is tdu) == ((outer * inner) % 2 == 1)
+    # which pair holds the result: per-sweep = the reference's swap parity (cuda_operation_solve_2d.cpp:288-289),
+    # fused = one swap per outer iteration; either way the library reports it
+    launches = outer if algorithm in (0, 2) else outer * inner
+    assert (rdu is tdu) == (launches % 2 == 1)
+
+
+def test_solve_level_fused_rejects_long_inner_loops(ctx, flow2d, oracle):
+    """inner > 5 is outside the fused kernel's register budget: FUSED refuses, AUTO falls back to per-sweep."""
+    w, h = 64, 48
+    f0, f1, u, v, _, _ = level_fields(oracle, w, h, 8)
+    d = [up(ctx, a, w, h) for a in (f0, f1, u, v)]
+    du, dv, phi, ksi, tdu, tdv = (ctx.plane(w, h) for _ in range(6))
+    with pytest.raises(flow2d.Flow2DError) as e:
+        ctx.solve_level(*d, du, dv, phi, ksi, tdu, tdv, w, h, 1.0, 1.0, 3.5, 0.001, 0.001, 1, 7, 0, 2)
+    assert e.value.status == 5
+    rdu, rdv = ctx.solve_level(*d, du, dv, phi, ksi, tdu, tdv, w, h, 1.0, 1.0, 3.5, 0.001, 0.001, 1, 7, 0, 0)
+    odu, odv, _, _ = oracle.solve_level(f0, f1, u, v, w, h, 1.0, 1.0, 3.5, 0.001, 0.001, 1, 7, 0)
+    assert np.array_equal(rdu.download(w, h), odu) and np.array_equal(rdv.download(w, h), odv)
