@@ -95,7 +95,9 @@ __device__ __forceinline__ void jacobi_update(const float* __restrict__ u, const
     const float sumV = sum_flux(wxp, wxm, wyp, wym, v[n.r] + dv[n.r], v[n.l] + dv[n.l], v[n.d] + dv[n.d],
                                 v[n.u] + dv[n.u], v[n.c]);
     float r_du, r_dv;
-    point_update(ksi[n.c], J11, J22, J12, J13, J23, sumH, sumU, sumV, dv[n.c], r_du, r_dv);
+    const float k = ksi[n.c];
+    point_update(k, update_denominator(k, J11, sumH), update_denominator(k, J22, sumH), J12, J13, J23, sumU, sumV,
+                 dv[n.c], r_du, r_dv);
     tdu[n.c] = r_du;
     tdv[n.c] = r_dv;
 }

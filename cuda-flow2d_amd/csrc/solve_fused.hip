@@ -21,6 +21,7 @@
 //    order, without FMA contraction: results are bit-identical to the per-sweep kernels and the oracle.
 //
 // Bound: fp32 VALU issue (about 480 instructions per pixel and outer iteration at inner = 5), not HBM.
+#include <cmath>
 #include <utility>
 
 #include "common.hpp"
@@ -44,23 +45,23 @@ struct FusedArgs {
     float hx, hy, alpha, e_smooth, e_data;
 };
 
-// lane i receives lane i-1 (wave_shr:1) / lane i+1 (wave_shl:1); the end lanes keep their own value
+// lane i receives lane i-1 (wave_shr:1) / lane i+1 (wave_shl:1); the end lanes of the wave receive 0
+// (bound_ctrl), which only ever reaches halo columns.  No "old" operand, so the move can fold into the
+// consuming VALU instruction.
 __device__ __forceinline__ float from_left(float v)
 {
-    const int i = __float_as_int(v);
-    return __int_as_float(__builtin_amdgcn_update_dpp(i, i, 0x138, 0xf, 0xf, false));
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x138, 0xf, 0xf, true));
 }
 __device__ __forceinline__ float from_right(float v)
 {
-    const int i = __float_as_int(v);
-    return __int_as_float(__builtin_amdgcn_update_dpp(i, i, 0x130, 0xf, 0xf, false));
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x130, 0xf, 0xf, true));
 }
 
 // static per-pixel coefficients of one outer iteration (what the sweeps need besides the moving flow)
 struct Coef {
     float wxp, wxm, wyp, wym;  // face diffusivity * neighbour weight (solve_2d.cu:337-346)
-    float sumH;
-    float ksi, J11, J22, J12, J13, J23;
+    float den_u, den_v;        // ksi * J11 + sumH, ksi * J22 + sumH (solve_2d.cu:363,367)
+    float ksi, J12, J13, J23;
     float uc, vc;
 };
 
@@ -83,7 +84,9 @@ struct Strip {
     float n_f0, n_f1, n_u, n_v, n_du, n_dv;
 };
 
-template <int INNER, bool GRAD, int J>
+// EDGE = false: the strip touches no image border, so the reflect substitutions (a v_cndmask per
+// neighbour fetch) are compiled out; EDGE = true keeps them.  Chosen per wave (wave-uniform branch).
+template <int INNER, bool GRAD, bool EDGE, bool POW2, int J>
 __device__ __forceinline__ void strip_step(Strip<INNER, GRAD>& s, const FusedArgs& a, int r, int x, int xc, bool at_l,
                                            bool at_r, bool lane_stores, int y0, int y1, float xp, float xm,
                                            float hx_2, float hy_2)
@@ -93,6 +96,7 @@ __device__ __forceinline__ void strip_step(Strip<INNER, GRAD>& s, const FusedArg
     // slots of input rows r, r-1, r-2 (J == r - first_row mod kRing, kRing % 3 == 0)
     constexpr int s0 = J % 3, s1 = (J + 2) % 3, s2 = (J + 1) % 3;
     const int w = a.w, h = a.h;
+    if (!EDGE) at_l = at_r = false;
 
     // ---- commit the prefetched row r (its slot still holds row r-3: sweep 1 needs that row's dv) ----------
     const float dv_row3 = s.dvw[s0];
@@ -117,7 +121,7 @@ __device__ __forceinline__ void strip_step(Strip<INNER, GRAD>& s, const FusedArg
     const int rp = r - 1;
     float fx, fy, ft, ksi;
     {
-        const bool top = (rp == 0), bot = (rp == h - 1);
+        const bool top = EDGE && (rp == 0), bot = EDGE && (rp == h - 1);
         auto lr = [&](float c, float& l, float& rr) {
             const float dl = from_left(c), dr = from_right(c);
             l = at_l ? dr : dl;
@@ -137,10 +141,11 @@ __device__ __forceinline__ void strip_step(Strip<INNER, GRAD>& s, const FusedArg
         ud(s.duw, duU, duD);
         ud(s.vw, vU, vD);
         ud(s.dvw, dvU, dvD);
-        const float dux = diff4(uR, uL, duR, duL, 2.f * a.hx);
-        const float duy = diff4(uD, uU, duD, duU, 2.f * a.hy);
-        const float dvx = diff4(vR, vL, dvR, dvL, 2.f * a.hx);
-        const float dvy = diff4(vD, vU, dvD, dvU, 2.f * a.hy);
+        // POW2: 2h and 4h are powers of two, so the division is an exact multiply by the reciprocal
+        const float dux = diff4s<POW2>(uR, uL, duR, duL, 2.f * a.hx, 1.f / (2.f * a.hx));
+        const float duy = diff4s<POW2>(uD, uU, duD, duU, 2.f * a.hy, 1.f / (2.f * a.hy));
+        const float dvx = diff4s<POW2>(vR, vL, dvR, dvL, 2.f * a.hx, 1.f / (2.f * a.hx));
+        const float dvy = diff4s<POW2>(vD, vU, dvD, dvU, 2.f * a.hy, 1.f / (2.f * a.hy));
         s.phiw[s1] = phi_value(dux, duy, dvx, dvy, a.e_smooth);
 
         float f0L, f0R, f0U, f0D, f1L, f1R, f1U, f1D;
@@ -148,8 +153,8 @@ __device__ __forceinline__ void strip_step(Strip<INNER, GRAD>& s, const FusedArg
         lr(s.f1w[s1], f1L, f1R);
         ud(s.f0w, f0U, f0D);
         ud(s.f1w, f1U, f1D);
-        fx = diff4(f0R, f0L, f1R, f1L, 4.f * a.hx);
-        fy = diff4(f0D, f0U, f1D, f1U, 4.f * a.hy);
+        fx = diff4s<POW2>(f0R, f0L, f1R, f1L, 4.f * a.hx, 1.f / (4.f * a.hx));
+        fy = diff4s<POW2>(f0D, f0U, f1D, f1U, 4.f * a.hy, 1.f / (4.f * a.hy));
         ft = s.f1w[s1] - s.f0w[s1];
         ksi = ksi_value(fx, fy, ft, s.duw[s1], s.dvw[s1], a.e_data);
         if (GRAD) {
@@ -164,26 +169,27 @@ __device__ __forceinline__ void strip_step(Strip<INNER, GRAD>& s, const FusedArg
     {
         constexpr int cw = (J + 2 * kRing - 2) % kRing;
         Coef& c = s.C[cw];
-        const bool top = (rw == 0), bot = (rw == h - 1);
+        const bool top = EDGE && (rw == 0), bot = EDGE && (rw == h - 1);
         const float pc = s.phiw[s2];
         const float pl0 = from_left(pc), pr0 = from_right(pc);
         const float pL = at_l ? pr0 : pl0, pR = at_r ? pl0 : pr0;
         const float pu0 = s.phiw[s0], pd0 = s.phiw[s1];  // rows r-3 (slot of r) ... careful: phi ring lags by one
         // phi ring: slot s1 holds row r-1 (just written), s2 holds row r-2, s0 holds row r-3
         const float pU = top ? pd0 : pu0, pD = bot ? pu0 : pd0;
-        const float yp = static_cast<float>(rw < h - 1) * hy_2;
-        const float ym = static_cast<float>(rw > 0) * hy_2;
+        const float yp = EDGE ? static_cast<float>(rw < h - 1) * hy_2 : hy_2;
+        const float ym = EDGE ? static_cast<float>(rw > 0) * hy_2 : hy_2;
         c.wxp = face_phi(pR, pc) * xp;
         c.wxm = face_phi(pL, pc) * xm;
         c.wyp = face_phi(pD, pc) * yp;
         c.wym = face_phi(pU, pc) * ym;
-        c.sumH = sum_weights(c.wxp, c.wxm, c.wyp, c.wym);
+        const float sumH = sum_weights(c.wxp, c.wxm, c.wyp, c.wym);
         c.ksi = s.p_ksi;
+        float J11, J22;
         c.uc = s.uw[s2];
         c.vc = s.vw[s2];
         if (!GRAD) {
-            c.J11 = s.p_fx * s.p_fx;
-            c.J22 = s.p_fy * s.p_fy;
+            J11 = s.p_fx * s.p_fx;
+            J22 = s.p_fy * s.p_fy;
             c.J12 = s.p_fx * s.p_fy;
             c.J13 = s.p_fx * s.p_ft;
             c.J23 = s.p_fy * s.p_ft;
@@ -210,8 +216,10 @@ __device__ __forceinline__ void strip_step(Strip<INNER, GRAD>& s, const FusedArg
             const float fyy = (fy_d - fy_u) * hy_1;
             const float fxt = (ft_r - ft_l) * hx_1;
             const float fyt = (ft_d - ft_u) * hy_1;
-            gradient_tensor(fxx, fxy, fyy, fxt, fyt, c.J11, c.J22, c.J12, c.J13, c.J23);
+            gradient_tensor(fxx, fxy, fyy, fxt, fyt, J11, J22, c.J12, c.J13, c.J23);
         }
+        c.den_u = update_denominator(c.ksi, J11, sumH);
+        c.den_v = update_denominator(c.ksi, J22, sumH);
         // u + du of row r-2 enters sweep 1's window
         s.U[0][s2] = s.uw[s2] + s.duw[s2];
         s.V[0][s2] = s.vw[s2] + s.dvw[s2];
@@ -230,7 +238,7 @@ __device__ __forceinline__ void strip_step(Strip<INNER, GRAD>& s, const FusedArg
         // window slots of rows rk-1, rk, rk+1 (rk = r-2-k  ->  slot (J - 2 - k) mod 3)
         const int sc = (J + 3 * 8 - 2 - k) % 3, su = (sc + 2) % 3, sd = (sc + 1) % 3;
         const Coef& c = s.C[(J + 4 * kRing - 2 - k) % kRing];
-        const bool top = (rk == 0), bot = (rk == h - 1);
+        const bool top = EDGE && (rk == 0), bot = EDGE && (rk == h - 1);
         const float Uc = s.U[k - 1][sc], Vc = s.V[k - 1][sc];
         const float Ul0 = from_left(Uc), Ur0 = from_right(Uc), Vl0 = from_left(Vc), Vr0 = from_right(Vc);
         const float UL = at_l ? Ur0 : Ul0, UR = at_r ? Ul0 : Ur0;
@@ -241,7 +249,7 @@ __device__ __forceinline__ void strip_step(Strip<INNER, GRAD>& s, const FusedArg
         const float sumU = sum_flux(c.wxp, c.wxm, c.wyp, c.wym, UR, UL, UD, UU, c.uc);
         const float sumV = sum_flux(c.wxp, c.wxm, c.wyp, c.wym, VR, VL, VD, VU, c.vc);
         float du_new, dv_new;
-        point_update(c.ksi, c.J11, c.J22, c.J12, c.J13, c.J23, c.sumH, sumU, sumV, dv_in, du_new, dv_new);
+        point_update(c.ksi, c.den_u, c.den_v, c.J12, c.J13, c.J23, sumU, sumV, dv_in, du_new, dv_new);
         if (k < INNER) {
             s.U[k][sc] = c.uc + du_new;
             s.V[k][sc] = c.vc + dv_new;
@@ -255,17 +263,17 @@ __device__ __forceinline__ void strip_step(Strip<INNER, GRAD>& s, const FusedArg
     }
 }
 
-template <int INNER, bool GRAD, size_t... Js>
+template <int INNER, bool GRAD, bool EDGE, bool POW2, size_t... Js>
 __device__ __forceinline__ void strip_steps(Strip<INNER, GRAD>& s, const FusedArgs& a, int r_base, int x, int xc,
                                             bool at_l, bool at_r, bool lane_stores, int y0, int y1, float xp, float xm,
                                             float hx_2, float hy_2, std::index_sequence<Js...>)
 {
-    (strip_step<INNER, GRAD, static_cast<int>(Js)>(s, a, r_base + static_cast<int>(Js), x, xc, at_l, at_r, lane_stores,
+    (strip_step<INNER, GRAD, EDGE, POW2, static_cast<int>(Js)>(s, a, r_base + static_cast<int>(Js), x, xc, at_l, at_r, lane_stores,
                                                    y0, y1, xp, xm, hx_2, hy_2),
      ...);
 }
 
-template <int INNER, bool GRAD>
+template <int INNER, bool GRAD, bool POW2>
 __global__ __launch_bounds__(256) void fused_outer_kernel(FusedArgs a)
 {
     using S = Strip<INNER, GRAD>;
@@ -296,7 +304,7 @@ __global__ __launch_bounds__(256) void fused_outer_kernel(FusedArgs a)
         for (int i = 0; i < 3; ++i) s.U[k][i] = s.V[k][i] = 0.f;
     }
 #pragma unroll
-    for (int i = 0; i < S::kRing; ++i) s.C[i] = Coef{0.f, 0.f, 0.f, 0.f, 1.f, 1.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < S::kRing; ++i) s.C[i] = Coef{0.f, 0.f, 0.f, 0.f, 1.f, 1.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     s.p_fx = s.p_fy = s.p_ft = s.p_ksi = 0.f;
 
     // first input row: the strip's first stored row needs INNER+1 rows of halo above it
@@ -313,22 +321,38 @@ __global__ __launch_bounds__(256) void fused_outer_kernel(FusedArgs a)
     }
     // the last stored row y1-1 leaves the last sweep at input row (y1-1) + 2 + INNER
     const int r_last = y1 - 1 + 2 + INNER;
-    for (int r = r_first; r <= r_last; r += S::kRing)
-        strip_steps<INNER, GRAD>(s, a, r, x, xc, at_l, at_r, lane_stores, y0, y1, xp, xm, hx_2, hy_2,
-                                 std::make_index_sequence<S::kRing>{});
+    // does any row or column this wave touches sit on an image border?  (a superset test is fine)
+    const int x_first = strip_x * S::kValid - S::kHalo;
+    const bool edge = x_first <= 0 || x_first + 63 >= a.w - 1 || y0 <= S::kHalo + 1 || y1 + S::kHalo + 1 >= a.h;
+    if (__builtin_amdgcn_readfirstlane(edge)) {
+        for (int r = r_first; r <= r_last; r += S::kRing)
+            strip_steps<INNER, GRAD, true, POW2>(s, a, r, x, xc, at_l, at_r, lane_stores, y0, y1, xp, xm, hx_2, hy_2,
+                                           std::make_index_sequence<S::kRing>{});
+    } else {
+        for (int r = r_first; r <= r_last; r += S::kRing)
+            strip_steps<INNER, GRAD, false, POW2>(s, a, r, x, xc, at_l, at_r, lane_stores, y0, y1, xp, xm, hx_2, hy_2,
+                                            std::make_index_sequence<S::kRing>{});
+    }
 }
 
-template <bool GRAD>
+template <bool GRAD, bool POW2>
 int launch_for_inner(int inner, dim3 grid, hipStream_t stream, const FusedArgs& a)
 {
     switch (inner) {
-        case 1: fused_outer_kernel<1, GRAD><<<grid, 256, 0, stream>>>(a); return 0;
-        case 2: fused_outer_kernel<2, GRAD><<<grid, 256, 0, stream>>>(a); return 0;
-        case 3: fused_outer_kernel<3, GRAD><<<grid, 256, 0, stream>>>(a); return 0;
-        case 4: fused_outer_kernel<4, GRAD><<<grid, 256, 0, stream>>>(a); return 0;
-        case 5: fused_outer_kernel<5, GRAD><<<grid, 256, 0, stream>>>(a); return 0;
+        case 1: fused_outer_kernel<1, GRAD, POW2><<<grid, 256, 0, stream>>>(a); return 0;
+        case 2: fused_outer_kernel<2, GRAD, POW2><<<grid, 256, 0, stream>>>(a); return 0;
+        case 3: fused_outer_kernel<3, GRAD, POW2><<<grid, 256, 0, stream>>>(a); return 0;
+        case 4: fused_outer_kernel<4, GRAD, POW2><<<grid, 256, 0, stream>>>(a); return 0;
+        case 5: fused_outer_kernel<5, GRAD, POW2><<<grid, 256, 0, stream>>>(a); return 0;
         default: return 1;
     }
+}
+
+// true when x is a normal power of two whose reciprocal (and 1/(2x), 1/(4x)) is exactly representable
+bool is_power_of_two(float x)
+{
+    int e = 0;
+    return x > 0.f && std::frexp(x, &e) == 0.5f && e > -100 && e < 100;
 }
 
 }  // namespace
@@ -349,8 +373,12 @@ int launch_fused_outer(flow2d_context* ctx, int constancy, const float* f0, cons
     const int valid = 64 - 2 * ((int)inner + 1);
     const unsigned strips_x = div_up(w, valid);
     const dim3 grid(div_up(strips_x, 4), div_up(h, rows_per_strip));
-    const int rc = constancy == FLOW2D_CONSTANCY_GRADIENT ? launch_for_inner<true>((int)inner, grid, ctx->stream, a)
-                                                          : launch_for_inner<false>((int)inner, grid, ctx->stream, a);
+    const bool pow2 = is_power_of_two(hx) && is_power_of_two(hy);
+    const bool grad = constancy == FLOW2D_CONSTANCY_GRADIENT;
+    const int rc = grad ? (pow2 ? launch_for_inner<true, true>((int)inner, grid, ctx->stream, a)
+                                : launch_for_inner<true, false>((int)inner, grid, ctx->stream, a))
+                        : (pow2 ? launch_for_inner<false, true>((int)inner, grid, ctx->stream, a)
+                                : launch_for_inner<false, false>((int)inner, grid, ctx->stream, a));
     if (rc) return FLOW2D_ERR_UNSUPPORTED;
     FLOW2D_CHECK_LAUNCH();
     return FLOW2D_OK;

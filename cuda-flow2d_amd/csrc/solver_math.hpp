@@ -43,13 +43,30 @@ __device__ __forceinline__ float sum_flux(float wxp, float wxm, float wyp, float
     return wxp * (nR - centre) + wxm * (nL - centre) + wyp * (nD - centre) + wym * (nU - centre);
 }
 
+// denominators of the point update, solve_2d.cu:363,367: constant over the sweeps of an outer iteration
+__device__ __forceinline__ float update_denominator(float ksi, float Jnn, float sumH) { return ksi * Jnn + sumH; }
+
 // the coupled 2x2 update of solve_2d.cu:361-367 (dv' uses the fresh du')
-__device__ __forceinline__ void point_update(float ksi, float J11, float J22, float J12, float J13, float J23,
-                                             float sumH, float sumU, float sumV, float dv_old, float& du_new,
-                                             float& dv_new)
+__device__ __forceinline__ void point_update(float ksi, float den_u, float den_v, float J12, float J13, float J23,
+                                             float sumU, float sumV, float dv_old, float& du_new, float& dv_new)
 {
-    du_new = (ksi * (-J13 - J12 * dv_old) + sumU) / (ksi * J11 + sumH);
-    dv_new = (ksi * (-J23 - J12 * du_new) + sumV) / (ksi * J22 + sumH);
+    du_new = (ksi * (-J13 - J12 * dv_old) + sumU) / den_u;
+    dv_new = (ksi * (-J23 - J12 * du_new) + sumV) / den_v;
+}
+
+// x / d for the grid-spacing divisors (2h, 4h).  When d is a power of two, x * (1/d) is the same
+// correctly rounded value as x / d (1/d is exact and both round the same real number), so the caller
+// may pass inv_d and pow2 = true to replace the ~10-instruction division by one multiply.
+template <bool POW2>
+__device__ __forceinline__ float div_spacing(float x, float d, float inv_d)
+{
+    return POW2 ? x * inv_d : x / d;
+}
+
+template <bool POW2>
+__device__ __forceinline__ float diff4s(float aP, float aM, float bP, float bM, float den, float inv_den)
+{
+    return div_spacing<POW2>(aP - aM + bP - bM, den, inv_den);
 }
 
 // gradient-constancy tensor from the second derivatives, solve_2d.cu:879-884
