@@ -59,11 +59,16 @@ __device__ __forceinline__ float from_right(float v)
 
 // static per-pixel coefficients of one outer iteration (what the sweeps need besides the moving flow)
 struct Coef {
-    float wxp, wxm, wyp, wym;  // face diffusivity * neighbour weight (solve_2d.cu:337-346)
-    float den_u, den_v;        // ksi * J11 + sumH, ksi * J22 + sumH (solve_2d.cu:363,367)
-    float ksi, J12, J13, J23;
-    float uc, vc;
+    v2f wx, wy;    // (w_x+, w_x-), (w_y+, w_y-): face diffusivity * neighbour weight (solve_2d.cu:337-346)
+    v2f den;       // (ksi * J11 + sumH, ksi * J22 + sumH) (solve_2d.cu:363,367)
+    v2f J13_23;    // (J13, J23)
+    float ksi, J12;
+    v2f uvc;       // (u, v) of the pixel
 };
+
+__device__ __forceinline__ v2f from_left2(v2f v) { return v2f{from_left(v.x), from_left(v.y)}; }
+__device__ __forceinline__ v2f from_right2(v2f v) { return v2f{from_right(v.x), from_right(v.y)}; }
+__device__ __forceinline__ v2f pick2(bool c, v2f a, v2f b) { return v2f{c ? a.x : b.x, c ? a.y : b.y}; }
 
 template <int INNER, bool GRAD>
 struct Strip {
@@ -71,25 +76,28 @@ struct Strip {
     static constexpr int kValid = 64 - 2 * kHalo;
     static constexpr int kRing = ((INNER + 1 + 2) / 3) * 3;  // coefficient ring, a multiple of the 3-row windows
 
-    // 3-row sliding windows, slot = row mod 3
-    float f0w[3], f1w[3], uw[3], vw[3], duw[3], dvw[3];
+    // 3-row sliding windows, slot = row mod 3; (u, v) and (du, dv) travel as pairs
+    float f0w[3], f1w[3];
+    v2f uvw[3], duvw[3];
     float phiw[3];
     float fxw[3], fyw[3], ftw[3];  // GRAD only
-    float U[INNER][3], V[INNER][3];  // U[k] = (u + du^k) rows around the row sweep k+1 is working on
+    v2f UV[INNER][3];                // UV[k] = (u + du^k, v + dv^k) rows around the row sweep k+1 is working on
     float dvc[INNER];                // dv^k of the row sweep k+1 processes in the current step
     Coef C[kRing];
     // brightness derivatives and ksi of the row stage W consumes next (produced by stage P one step earlier)
     float p_fx, p_fy, p_ft, p_ksi;
     // prefetched input row
-    float n_f0, n_f1, n_u, n_v, n_du, n_dv;
+    float n_f0, n_f1;
+    v2f n_uv, n_duv;
 };
 
 // EDGE = false: the strip touches no image border, so the reflect substitutions (a v_cndmask per
 // neighbour fetch) are compiled out; EDGE = true keeps them.  Chosen per wave (wave-uniform branch).
+// POW2: 2h and 4h are powers of two, so dividing by them is an exact multiply by the reciprocal.
 template <int INNER, bool GRAD, bool EDGE, bool POW2, int J>
 __device__ __forceinline__ void strip_step(Strip<INNER, GRAD>& s, const FusedArgs& a, int r, int x, int xc, bool at_l,
-                                           bool at_r, bool lane_stores, int y0, int y1, float xp, float xm,
-                                           float hx_2, float hy_2)
+                                           bool at_r, bool lane_stores, int y0, int y1, v2f xpm, float hx_2,
+                                           float hy_2)
 {
     using S = Strip<INNER, GRAD>;
     constexpr int kRing = S::kRing;
@@ -99,22 +107,18 @@ __device__ __forceinline__ void strip_step(Strip<INNER, GRAD>& s, const FusedArg
     if (!EDGE) at_l = at_r = false;
 
     // ---- commit the prefetched row r (its slot still holds row r-3: sweep 1 needs that row's dv) ----------
-    const float dv_row3 = s.dvw[s0];
+    const float dv_row3 = s.duvw[s0].y;
     s.f0w[s0] = s.n_f0;
     s.f1w[s0] = s.n_f1;
-    s.uw[s0] = s.n_u;
-    s.vw[s0] = s.n_v;
-    s.duw[s0] = s.n_du;
-    s.dvw[s0] = s.n_dv;
+    s.uvw[s0] = s.n_uv;
+    s.duvw[s0] = s.n_duv;
     {  // prefetch row r+1 (clamped: rows outside the image are never used by a stored pixel)
         const int rn = min(max(r + 1, 0), h - 1);
         const size_t o = static_cast<size_t>(rn) * a.pitch + xc;
         s.n_f0 = a.f0[o];
         s.n_f1 = a.f1[o];
-        s.n_u = a.u[o];
-        s.n_v = a.v[o];
-        s.n_du = a.du[o];
-        s.n_dv = a.dv[o];
+        s.n_uv = v2f{a.u[o], a.v[o]};
+        s.n_duv = v2f{a.du[o], a.dv[o]};
     }
 
     // ---- stage P, row rp = r-1: phi, brightness derivatives, ksi (solve_2d.cu:138-197) -------------------
@@ -122,41 +126,35 @@ __device__ __forceinline__ void strip_step(Strip<INNER, GRAD>& s, const FusedArg
     float fx, fy, ft, ksi;
     {
         const bool top = EDGE && (rp == 0), bot = EDGE && (rp == h - 1);
-        auto lr = [&](float c, float& l, float& rr) {
-            const float dl = from_left(c), dr = from_right(c);
-            l = at_l ? dr : dl;
-            rr = at_r ? dl : dr;
-        };
-        auto ud = [&](const float (&win)[3], float& up, float& dn) {
-            const float a_up = win[s2], a_dn = win[s0];
-            up = top ? a_dn : a_up;
-            dn = bot ? a_up : a_dn;
-        };
-        float uL, uR, uU, uD, duL, duR, duU, duD, vL, vR, vU, vD, dvL, dvR, dvU, dvD;
-        lr(s.uw[s1], uL, uR);
-        lr(s.duw[s1], duL, duR);
-        lr(s.vw[s1], vL, vR);
-        lr(s.dvw[s1], dvL, dvR);
-        ud(s.uw, uU, uD);
-        ud(s.duw, duU, duD);
-        ud(s.vw, vU, vD);
-        ud(s.dvw, dvU, dvD);
-        // POW2: 2h and 4h are powers of two, so the division is an exact multiply by the reciprocal
-        const float dux = diff4s<POW2>(uR, uL, duR, duL, 2.f * a.hx, 1.f / (2.f * a.hx));
-        const float duy = diff4s<POW2>(uD, uU, duD, duU, 2.f * a.hy, 1.f / (2.f * a.hy));
-        const float dvx = diff4s<POW2>(vR, vL, dvR, dvL, 2.f * a.hx, 1.f / (2.f * a.hx));
-        const float dvy = diff4s<POW2>(vD, vU, dvD, dvU, 2.f * a.hy, 1.f / (2.f * a.hy));
-        s.phiw[s1] = phi_value(dux, duy, dvx, dvy, a.e_smooth);
+        // cross-lane reads happen with every lane active; the border substitution is a select afterwards
+        const v2f uv_l0 = from_left2(s.uvw[s1]), uv_r0 = from_right2(s.uvw[s1]);
+        const v2f duv_l0 = from_left2(s.duvw[s1]), duv_r0 = from_right2(s.duvw[s1]);
+        const v2f uvL = pick2(at_l, uv_r0, uv_l0), uvR = pick2(at_r, uv_l0, uv_r0);
+        const v2f duvL = pick2(at_l, duv_r0, duv_l0), duvR = pick2(at_r, duv_l0, duv_r0);
+        const v2f uvU = pick2(top, s.uvw[s0], s.uvw[s2]), uvD = pick2(bot, s.uvw[s2], s.uvw[s0]);
+        const v2f duvU = pick2(top, s.duvw[s0], s.duvw[s2]), duvD = pick2(bot, s.duvw[s2], s.duvw[s0]);
+        const v2f xnum = diff4_num2(uvR, uvL, duvR, duvL);  // numerators of (dux, dvx)
+        const v2f ynum = diff4_num2(uvD, uvU, duvD, duvU);  // numerators of (duy, dvy)
+        v2f dx, dy;
+        if (POW2) {
+            dx = xnum * (1.f / (2.f * a.hx));
+            dy = ynum * (1.f / (2.f * a.hy));
+        } else {
+            dx = v2f{xnum.x / (2.f * a.hx), xnum.y / (2.f * a.hx)};
+            dy = v2f{ynum.x / (2.f * a.hy), ynum.y / (2.f * a.hy)};
+        }
+        s.phiw[s1] = phi_value(dx.x, dy.x, dx.y, dy.y, a.e_smooth);
 
-        float f0L, f0R, f0U, f0D, f1L, f1R, f1U, f1D;
-        lr(s.f0w[s1], f0L, f0R);
-        lr(s.f1w[s1], f1L, f1R);
-        ud(s.f0w, f0U, f0D);
-        ud(s.f1w, f1U, f1D);
+        const float f0c = s.f0w[s1], f1c = s.f1w[s1];
+        const float f0l0 = from_left(f0c), f0r0 = from_right(f0c), f1l0 = from_left(f1c), f1r0 = from_right(f1c);
+        const float f0L = at_l ? f0r0 : f0l0, f0R = at_r ? f0l0 : f0r0;
+        const float f1L = at_l ? f1r0 : f1l0, f1R = at_r ? f1l0 : f1r0;
+        const float f0U = top ? s.f0w[s0] : s.f0w[s2], f0D = bot ? s.f0w[s2] : s.f0w[s0];
+        const float f1U = top ? s.f1w[s0] : s.f1w[s2], f1D = bot ? s.f1w[s2] : s.f1w[s0];
         fx = diff4s<POW2>(f0R, f0L, f1R, f1L, 4.f * a.hx, 1.f / (4.f * a.hx));
         fy = diff4s<POW2>(f0D, f0U, f1D, f1U, 4.f * a.hy, 1.f / (4.f * a.hy));
-        ft = s.f1w[s1] - s.f0w[s1];
-        ksi = ksi_value(fx, fy, ft, s.duw[s1], s.dvw[s1], a.e_data);
+        ft = f1c - f0c;
+        ksi = ksi_value(fx, fy, ft, s.duvw[s1].x, s.duvw[s1].y, a.e_data);
         if (GRAD) {
             s.fxw[s1] = fx;
             s.fyw[s1] = fy;
@@ -165,6 +163,7 @@ __device__ __forceinline__ void strip_step(Strip<INNER, GRAD>& s, const FusedArg
     }
 
     // ---- stage W, row rw = r-2: face weights and the motion tensor -> coefficient ring --------------------
+    // phi ring: slot s1 holds row r-1 (just written), s2 row r-2, s0 row r-3
     const int rw = r - 2;
     {
         constexpr int cw = (J + 2 * kRing - 2) % kRing;
@@ -172,27 +171,21 @@ __device__ __forceinline__ void strip_step(Strip<INNER, GRAD>& s, const FusedArg
         const bool top = EDGE && (rw == 0), bot = EDGE && (rw == h - 1);
         const float pc = s.phiw[s2];
         const float pl0 = from_left(pc), pr0 = from_right(pc);
-        const float pL = at_l ? pr0 : pl0, pR = at_r ? pl0 : pr0;
-        const float pu0 = s.phiw[s0], pd0 = s.phiw[s1];  // rows r-3 (slot of r) ... careful: phi ring lags by one
-        // phi ring: slot s1 holds row r-1 (just written), s2 holds row r-2, s0 holds row r-3
-        const float pU = top ? pd0 : pu0, pD = bot ? pu0 : pd0;
+        const v2f p_rl = v2f{at_r ? pl0 : pr0, at_l ? pr0 : pl0};                       // (phi[x+1], phi[x-1])
+        const float pU = top ? s.phiw[s1] : s.phiw[s0], pD = bot ? s.phiw[s0] : s.phiw[s1];
         const float yp = EDGE ? static_cast<float>(rw < h - 1) * hy_2 : hy_2;
         const float ym = EDGE ? static_cast<float>(rw > 0) * hy_2 : hy_2;
-        c.wxp = face_phi(pR, pc) * xp;
-        c.wxm = face_phi(pL, pc) * xm;
-        c.wyp = face_phi(pD, pc) * yp;
-        c.wym = face_phi(pU, pc) * ym;
-        const float sumH = sum_weights(c.wxp, c.wxm, c.wyp, c.wym);
+        c.wx = (p_rl + pc) / 2.f * xpm;                                                  // face_phi * (xp, xm)
+        c.wy = v2f{face_phi(pD, pc) * yp, face_phi(pU, pc) * ym};
+        const float sumH = sum_weights(c.wx.x, c.wx.y, c.wy.x, c.wy.y);
         c.ksi = s.p_ksi;
-        float J11, J22;
-        c.uc = s.uw[s2];
-        c.vc = s.vw[s2];
+        c.uvc = s.uvw[s2];
+        v2f J11_22;
         if (!GRAD) {
-            J11 = s.p_fx * s.p_fx;
-            J22 = s.p_fy * s.p_fy;
+            const v2f fxy = v2f{s.p_fx, s.p_fy};
+            J11_22 = fxy * fxy;
             c.J12 = s.p_fx * s.p_fy;
-            c.J13 = s.p_fx * s.p_ft;
-            c.J23 = s.p_fy * s.p_ft;
+            c.J13_23 = fxy * s.p_ft;
         } else {
             // second derivatives inside the reference's 16x8 blocks, own value replicated at block and
             // image edges (solve_2d.cu:816-841,872-876); fx/fy/ft rings: s1 = row r-1, s2 = r-2, s0 = r-3
@@ -216,13 +209,14 @@ __device__ __forceinline__ void strip_step(Strip<INNER, GRAD>& s, const FusedArg
             const float fyy = (fy_d - fy_u) * hy_1;
             const float fxt = (ft_r - ft_l) * hx_1;
             const float fyt = (ft_d - ft_u) * hy_1;
-            gradient_tensor(fxx, fxy, fyy, fxt, fyt, J11, J22, c.J12, c.J13, c.J23);
+            float J11, J22, J13, J23;
+            gradient_tensor(fxx, fxy, fyy, fxt, fyt, J11, J22, c.J12, J13, J23);
+            J11_22 = v2f{J11, J22};
+            c.J13_23 = v2f{J13, J23};
         }
-        c.den_u = update_denominator(c.ksi, J11, sumH);
-        c.den_v = update_denominator(c.ksi, J22, sumH);
-        // u + du of row r-2 enters sweep 1's window
-        s.U[0][s2] = s.uw[s2] + s.duw[s2];
-        s.V[0][s2] = s.vw[s2] + s.dvw[s2];
+        c.den = c.ksi * J11_22 + sumH;  // update_denominator for u and v
+        // (u + du, v + dv) of row r-2 enters sweep 1's window
+        s.UV[0][s2] = s.uvw[s2] + s.duvw[s2];
     }
     // stage P's outputs of this step are what stage W consumes in the next one
     s.p_fx = fx;
@@ -239,20 +233,15 @@ __device__ __forceinline__ void strip_step(Strip<INNER, GRAD>& s, const FusedArg
         const int sc = (J + 3 * 8 - 2 - k) % 3, su = (sc + 2) % 3, sd = (sc + 1) % 3;
         const Coef& c = s.C[(J + 4 * kRing - 2 - k) % kRing];
         const bool top = EDGE && (rk == 0), bot = EDGE && (rk == h - 1);
-        const float Uc = s.U[k - 1][sc], Vc = s.V[k - 1][sc];
-        const float Ul0 = from_left(Uc), Ur0 = from_right(Uc), Vl0 = from_left(Vc), Vr0 = from_right(Vc);
-        const float UL = at_l ? Ur0 : Ul0, UR = at_r ? Ul0 : Ur0;
-        const float VL = at_l ? Vr0 : Vl0, VR = at_r ? Vl0 : Vr0;
-        const float Uu0 = s.U[k - 1][su], Ud0 = s.U[k - 1][sd], Vu0 = s.V[k - 1][su], Vd0 = s.V[k - 1][sd];
-        const float UU = top ? Ud0 : Uu0, UD = bot ? Uu0 : Ud0;
-        const float VU = top ? Vd0 : Vu0, VD = bot ? Vu0 : Vd0;
-        const float sumU = sum_flux(c.wxp, c.wxm, c.wyp, c.wym, UR, UL, UD, UU, c.uc);
-        const float sumV = sum_flux(c.wxp, c.wxm, c.wyp, c.wym, VR, VL, VD, VU, c.vc);
+        const v2f n_c = s.UV[k - 1][sc];
+        const v2f n_l0 = from_left2(n_c), n_r0 = from_right2(n_c);
+        const v2f nL = pick2(at_l, n_r0, n_l0), nR = pick2(at_r, n_l0, n_r0);
+        const v2f nU = pick2(top, s.UV[k - 1][sd], s.UV[k - 1][su]), nD = pick2(bot, s.UV[k - 1][su], s.UV[k - 1][sd]);
+        const v2f sums = sum_flux2(c.wx, c.wy, nR, nL, nD, nU, c.uvc);  // (sumU, sumV)
         float du_new, dv_new;
-        point_update(c.ksi, c.den_u, c.den_v, c.J12, c.J13, c.J23, sumU, sumV, dv_in, du_new, dv_new);
+        point_update(c.ksi, c.den.x, c.den.y, c.J12, c.J13_23.x, c.J13_23.y, sums.x, sums.y, dv_in, du_new, dv_new);
         if (k < INNER) {
-            s.U[k][sc] = c.uc + du_new;
-            s.V[k][sc] = c.vc + dv_new;
+            s.UV[k][sc] = c.uvc + v2f{du_new, dv_new};
             dv_in = s.dvc[k];      // dv^k of row r-3-k, produced by this sweep one step ago
             s.dvc[k] = dv_new;     // dv^k of row r-2-k, for the next step
         } else if (lane_stores && rk >= y0 && rk < y1) {
@@ -265,11 +254,11 @@ __device__ __forceinline__ void strip_step(Strip<INNER, GRAD>& s, const FusedArg
 
 template <int INNER, bool GRAD, bool EDGE, bool POW2, size_t... Js>
 __device__ __forceinline__ void strip_steps(Strip<INNER, GRAD>& s, const FusedArgs& a, int r_base, int x, int xc,
-                                            bool at_l, bool at_r, bool lane_stores, int y0, int y1, float xp, float xm,
+                                            bool at_l, bool at_r, bool lane_stores, int y0, int y1, v2f xpm,
                                             float hx_2, float hy_2, std::index_sequence<Js...>)
 {
-    (strip_step<INNER, GRAD, EDGE, POW2, static_cast<int>(Js)>(s, a, r_base + static_cast<int>(Js), x, xc, at_l, at_r, lane_stores,
-                                                   y0, y1, xp, xm, hx_2, hy_2),
+    (strip_step<INNER, GRAD, EDGE, POW2, static_cast<int>(Js)>(s, a, r_base + static_cast<int>(Js), x, xc, at_l, at_r,
+                                                               lane_stores, y0, y1, xpm, hx_2, hy_2),
      ...);
 }
 
@@ -288,23 +277,23 @@ __global__ __launch_bounds__(256) void fused_outer_kernel(FusedArgs a)
     const bool lane_stores = lane >= S::kHalo && lane < 64 - S::kHalo && x < a.w;
     const float hx_2 = a.alpha / (a.hx * a.hx);
     const float hy_2 = a.alpha / (a.hy * a.hy);
-    const float xp = static_cast<float>(x < a.w - 1) * hx_2;
-    const float xm = static_cast<float>(x > 0) * hx_2;
+    const v2f xpm = v2f{static_cast<float>(x < a.w - 1) * hx_2, static_cast<float>(x > 0) * hx_2};  // (xp, xm)
 
     S s;
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
-        s.f0w[i] = s.f1w[i] = s.uw[i] = s.vw[i] = s.duw[i] = s.dvw[i] = s.phiw[i] = 0.f;
+        s.f0w[i] = s.f1w[i] = s.phiw[i] = 0.f;
+        s.uvw[i] = s.duvw[i] = v2f{0.f, 0.f};
         s.fxw[i] = s.fyw[i] = s.ftw[i] = 0.f;
     }
 #pragma unroll
     for (int k = 0; k < INNER; ++k) {
         s.dvc[k] = 0.f;
 #pragma unroll
-        for (int i = 0; i < 3; ++i) s.U[k][i] = s.V[k][i] = 0.f;
+        for (int i = 0; i < 3; ++i) s.UV[k][i] = v2f{0.f, 0.f};
     }
 #pragma unroll
-    for (int i = 0; i < S::kRing; ++i) s.C[i] = Coef{0.f, 0.f, 0.f, 0.f, 1.f, 1.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < S::kRing; ++i) s.C[i] = Coef{v2f{0.f, 0.f}, v2f{0.f, 0.f}, v2f{1.f, 1.f}, v2f{0.f, 0.f}, 0.f, 0.f, v2f{0.f, 0.f}};
     s.p_fx = s.p_fy = s.p_ft = s.p_ksi = 0.f;
 
     // first input row: the strip's first stored row needs INNER+1 rows of halo above it
@@ -314,10 +303,8 @@ __global__ __launch_bounds__(256) void fused_outer_kernel(FusedArgs a)
         const size_t o = static_cast<size_t>(rn) * a.pitch + xc;
         s.n_f0 = a.f0[o];
         s.n_f1 = a.f1[o];
-        s.n_u = a.u[o];
-        s.n_v = a.v[o];
-        s.n_du = a.du[o];
-        s.n_dv = a.dv[o];
+        s.n_uv = v2f{a.u[o], a.v[o]};
+        s.n_duv = v2f{a.du[o], a.dv[o]};
     }
     // the last stored row y1-1 leaves the last sweep at input row (y1-1) + 2 + INNER
     const int r_last = y1 - 1 + 2 + INNER;
@@ -326,11 +313,11 @@ __global__ __launch_bounds__(256) void fused_outer_kernel(FusedArgs a)
     const bool edge = x_first <= 0 || x_first + 63 >= a.w - 1 || y0 <= S::kHalo + 1 || y1 + S::kHalo + 1 >= a.h;
     if (__builtin_amdgcn_readfirstlane(edge)) {
         for (int r = r_first; r <= r_last; r += S::kRing)
-            strip_steps<INNER, GRAD, true, POW2>(s, a, r, x, xc, at_l, at_r, lane_stores, y0, y1, xp, xm, hx_2, hy_2,
+            strip_steps<INNER, GRAD, true, POW2>(s, a, r, x, xc, at_l, at_r, lane_stores, y0, y1, xpm, hx_2, hy_2,
                                            std::make_index_sequence<S::kRing>{});
     } else {
         for (int r = r_first; r <= r_last; r += S::kRing)
-            strip_steps<INNER, GRAD, false, POW2>(s, a, r, x, xc, at_l, at_r, lane_stores, y0, y1, xp, xm, hx_2, hy_2,
+            strip_steps<INNER, GRAD, false, POW2>(s, a, r, x, xc, at_l, at_r, lane_stores, y0, y1, xpm, hx_2, hy_2,
                                             std::make_index_sequence<S::kRing>{});
     }
 }

@@ -80,4 +80,18 @@ __device__ __forceinline__ void gradient_tensor(float fxx, float fxy, float fyy,
     J23 = fxy * fxt + fyy * fyt;
 }
 
+// ---- two-wide forms: the u and v equations share their weights, so the pair (u, v) goes through
+// v_pk_add_f32 / v_pk_mul_f32 (one VALU issue for both fields).  Component by component these are the
+// scalar expressions above, in the same order; nothing is contracted into an FMA.
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+// (aP - aM + bP - bM) per component, solve_2d.cu:141-157
+__device__ __forceinline__ v2f diff4_num2(v2f aP, v2f aM, v2f bP, v2f bM) { return aP - aM + bP - bM; }
+
+// sumU and sumV of solve_2d.cu:350-359 at once: wx = (w_x+, w_x-), wy = (w_y+, w_y-)
+__device__ __forceinline__ v2f sum_flux2(v2f wx, v2f wy, v2f nR, v2f nL, v2f nD, v2f nU, v2f centre)
+{
+    return wx.xx * (nR - centre) + wx.yy * (nL - centre) + wy.xx * (nD - centre) + wy.yy * (nU - centre);
+}
+
 }  // namespace flow2d_math
