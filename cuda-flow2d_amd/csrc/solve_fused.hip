@@ -348,6 +348,36 @@ namespace flow2d {
 
 bool fused_supports(size_t inner) { return inner >= 1 && inner <= 5; }
 
+// Rows per strip.  A wave spends (rows + 2*inner + 3) row steps on `rows` stored rows, so tall strips
+// waste less; but the launch should fill the chip in whole co-resident rounds (two 256-thread
+// workgroups per CU at ~190 VGPRs).  Cost model in row steps: a full round of 2 workgroups per CU
+// costs 2 * steps (VALU-issue bound), a last round with at most one workgroup per CU 1.3 * steps
+// (a lone wave per SIMD cannot saturate the VALU).  Pick the strip height with the smallest estimate.
+int fused_rows_per_strip(const flow2d_context* ctx, size_t w, size_t h, size_t inner)
+{
+    const int valid = 64 - 2 * ((int)inner + 1);
+    const long blocks_x = (div_up(w, valid) + 3) / 4;
+    const long cus = ctx->num_cus > 0 ? ctx->num_cus : 256;
+    const long cap = cus * 2;
+    const int ring = (((int)inner + 1 + 2) / 3) * 3;
+    double best = 1e300;
+    int best_rows = 4;
+    for (long ny = 1; ny <= (long)((h + 3) / 4); ++ny) {
+        const long rows = (long)((h + ny - 1) / ny);
+        if (rows < 4) break;
+        if ((long)((h + rows - 1) / rows) != ny) continue;  // same ny reachable with fewer rows: skip duplicates
+        const long steps = ((rows + 2 * (long)inner + 3 + ring - 1) / ring) * ring;
+        const long blocks = blocks_x * ny;
+        const long full = blocks / cap, rem = blocks % cap;
+        const double cost = full * 2.0 * steps + (rem == 0 ? 0.0 : (rem <= cus ? 1.3 * steps : 2.0 * steps));
+        if (cost < best - 1e-9) {
+            best = cost;
+            best_rows = (int)rows;
+        }
+    }
+    return best_rows;
+}
+
 // One outer iteration: reads du/dv (previous outer iteration), writes out_du/out_dv (after `inner` sweeps).
 int launch_fused_outer(flow2d_context* ctx, int constancy, const float* f0, const float* f1, const float* u,
                        const float* v, const float* du, const float* dv, size_t w, size_t h, size_t pitch_bytes,

@@ -15,6 +15,7 @@ int launch_sweep(flow2d_context* ctx, int constancy, const float* f0, const floa
                  const float* du, const float* dv, const float* phi, const float* ksi, size_t w, size_t h,
                  size_t pitch_bytes, float hx, float hy, float alpha, float* tdu, float* tdv);
 bool fused_supports(size_t inner);
+int fused_rows_per_strip(const flow2d_context* ctx, size_t w, size_t h, size_t inner);
 int launch_fused_outer(flow2d_context* ctx, int constancy, const float* f0, const float* f1, const float* u,
                        const float* v, const float* du, const float* dv, size_t w, size_t h, size_t pitch_bytes,
                        float hx, float hy, float alpha, float e_smooth, float e_data, size_t inner, float* out_du,
@@ -54,8 +55,13 @@ int flow2d_solve_level(flow2d_context* ctx, const float* frame_0, const float* f
     if (p->algorithm < FLOW2D_SOLVER_AUTO || p->algorithm > FLOW2D_SOLVER_FUSED) return FLOW2D_ERR_INVALID_ARGUMENT;
 
     int algorithm = p->algorithm;
-    if (algorithm == FLOW2D_SOLVER_AUTO)
-        algorithm = flow2d::fused_supports(p->inner_iterations_count) ? FLOW2D_SOLVER_FUSED : FLOW2D_SOLVER_PER_SWEEP;
+    if (algorithm == FLOW2D_SOLVER_AUTO) {
+        // Below ~512^2 both forms are launch/latency bound and the per-sweep kernels are marginally
+        // quicker (measured on MI355X, profiles/r01_*); above, the fused kernel wins by 1.7-2.9x.
+        const bool big = p->width * p->height >= 512 * 512 && p->inner_iterations_count >= 2;
+        algorithm = (big && flow2d::fused_supports(p->inner_iterations_count)) ? FLOW2D_SOLVER_FUSED
+                                                                               : FLOW2D_SOLVER_PER_SWEEP;
+    }
     if (algorithm == FLOW2D_SOLVER_FUSED && !flow2d::fused_supports(p->inner_iterations_count))
         return FLOW2D_ERR_UNSUPPORTED;
 
@@ -84,7 +90,8 @@ int flow2d_solve_level(flow2d_context* ctx, const float* frame_0, const float* f
     for (size_t i = 0; algorithm == FLOW2D_SOLVER_FUSED && i < p->outer_iterations_count; ++i) {
         // one launch per outer iteration: phi/ksi and all inner sweeps in one pass (solve_fused.hip);
         // phi and ksi are not materialised in this mode.
-        const int rows = rows_env > 0 ? rows_env : 64;
+        const int rows = rows_env > 0 ? rows_env
+                                      : flow2d::fused_rows_per_strip(ctx, p->width, p->height, p->inner_iterations_count);
         if (slot && ctx->timing >= 2) FLOW2D_HIP_TRY(mark(ctx, slot));
         int st = flow2d::launch_fused_outer(ctx, p->data_constancy, frame_0, frame_1, flow_u, flow_v, du, dv, p->width,
                                             p->height, p->pitch_bytes, p->hx, p->hy, p->equation_alpha,
