@@ -124,9 +124,9 @@ def main():
     args = ap.parse_args()
     cfg = WORKLOADS[args.workload]
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    flow2d = importlib.import_module("cuda-flow2d_amd")
+    batch = importlib.import_module("cuda-flow2d_amd.batch")
+    rank, local_rank, world = batch.world_info()
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             sys.exit("bench.py --gpus %d must be launched with torch.distributed.run (WORLD_SIZE=%d)" %
@@ -134,16 +134,12 @@ def main():
         args.gpus = world
 
     import torch  # device plumbing only: barrier, device-wide synchronise, max-over-ranks
-    import torch.distributed as dist
 
     if not torch.cuda.is_available():
         sys.exit("bench.py needs an MI355X: the flow2d path has no CPU fallback")
     torch.cuda.set_device(local_rank)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    batch.init(backend="nccl", device=torch.device("cuda", local_rank))  # RCCL; no-op for one process
 
-    flow2d = importlib.import_module("cuda-flow2d_amd")
     ctx = flow2d.Context(local_rank)
     w, h = cfg["w"], cfg["h"]
     flow = flow2d.OpticalFlow(w, h, cfg["constancy"], ctx=ctx)
@@ -152,8 +148,8 @@ def main():
 
     # this rank's pairs, resident in HBM before the timed region (pair k of rank r: seed-dependent shift)
     pairs = []
-    for k in range(cfg["pairs_per_rank"]):
-        gk = rank * cfg["pairs_per_rank"] + k
+    total_pairs = cfg["pairs_per_rank"] * world
+    for gk in batch.pairs_of_rank(total_pairs, rank, world):  # pair k -> rank k mod world
         if args.workload == "cfg4_1080p_batch":
             dx, dy = 2.0 * np.cos(gk), 2.0 * np.sin(gk)
         else:
@@ -163,8 +159,7 @@ def main():
     free_b, total_b = ctx.mem_info()
 
     def barrier():
-        if world > 1:
-            dist.barrier()
+        batch.barrier()
         ctx.synchronize()
         torch.cuda.synchronize()
 
@@ -182,10 +177,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     finest = [r for r in flow.level_timings() if (r[0], r[1]) == (w, h)]
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = batch.max_over_ranks(elapsed, device="cuda" if world > 1 else "cpu")
 
     if rank == 0:
         pairs_total = args.steps * cfg["pairs_per_rank"] * world
@@ -247,8 +239,7 @@ def main():
 
     flow.close()
     ctx.close()
-    if world > 1:
-        dist.destroy_process_group()
+    batch.shutdown()
 
 
 if __name__ == "__main__":

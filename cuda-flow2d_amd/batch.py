@@ -1,0 +1,63 @@
+"""Sharding of independent image pairs over the GPUs of one node: one process per GPU,
+pair k -> rank k mod world, no data-path collective.  torch.distributed is used only for the start/stop
+barrier, the max-over-ranks of the elapsed time and (optionally) gathering per-pair result digests.
+Backend "nccl" is RCCL on ROCm; "gloo" is what the CPU tests use."""
+import os
+
+
+def world_info():
+    return (int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")),
+            int(os.environ.get("WORLD_SIZE", "1")))
+
+
+def init(backend="nccl", device=None):
+    """Joins the process group when launched by torch.distributed.run; a no-op for a single process."""
+    rank, local_rank, world = world_info()
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        if not dist.is_initialized():
+            kwargs = {"device_id": device} if (device is not None and backend == "nccl") else {}
+            dist.init_process_group(backend=backend, rank=rank, world_size=world, **kwargs)
+    return rank, local_rank, world
+
+
+def pairs_of_rank(total_pairs, rank, world):
+    """Global pair indices owned by `rank`: k mod world == rank (every pair exactly once, balanced +-1)."""
+    return list(range(rank, total_pairs, world))
+
+
+def barrier():
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
+        dist.barrier()
+
+
+def max_over_ranks(value, device="cpu"):
+    """The slowest rank's value (the bench contract times the whole job by its slowest rank)."""
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        return float(value)
+    t = torch.tensor([float(value)], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def gather_digests(local, total_pairs, device="cpu"):
+    """local: {global_pair_index: float digest}.  Returns the list of all pairs' digests on every rank."""
+    import torch
+    import torch.distributed as dist
+    mine = torch.zeros(total_pairs, dtype=torch.float64, device=device)
+    for k, d in local.items():
+        mine[k] = d
+    if dist.is_available() and dist.is_initialized():
+        dist.all_reduce(mine, op=dist.ReduceOp.SUM)  # owners are disjoint, so the sum is a gather
+    return mine.tolist()
+
+
+def shutdown():
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
+        dist.destroy_process_group()
