@@ -96,6 +96,62 @@ __global__ __launch_bounds__(256) void resample_kernel(const float* __restrict__
     out[static_cast<size_t>(y) * pitch + x] = value * normalization;
 }
 
+// Down-sampling along x with a large ratio (the frames are resampled from FULL resolution at every level,
+// optical_flow_2d.cpp:284-303): with one output per lane the lanes of a wave read 64 different cache
+// lines per load.  Here each wave (one image row, 64 outputs) stages the contiguous input span of its
+// outputs through LDS in coalesced chunks and the lanes then walk their cells in LDS.  Every output still
+// accumulates its cells left to right in fp32, so the result is bit-identical to resample_kernel<true>.
+constexpr int kResampleChunk = 2048;                                   // floats of input per wave and pass
+constexpr int kResampleLdsPerWave = kResampleChunk + kResampleChunk / 32;  // one pad word per 32: conflict-free strides
+
+__global__ __launch_bounds__(256) void resample_x_lds_kernel(const float* __restrict__ in, float* __restrict__ out,
+                                                             int out_w, int out_h, int in_w, int pitch)
+{
+    __shared__ float lds[4][kResampleLdsPerWave];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int x = blockIdx.x * 64 + lane;
+    const int y = blockIdx.y * 4 + wave;
+    const bool row_ok = y < out_h;
+    const bool active = row_ok && x < out_w;
+    const float delta = static_cast<float>(in_w) / static_cast<float>(out_w);
+    const float normalization = static_cast<float>(out_w) / static_cast<float>(in_w);
+    // this lane's cells, exactly as resample_2d.cu:46-53
+    const int gx = min(x, out_w - 1);
+    const float left_f = static_cast<float>(static_cast<unsigned>(gx)) * delta;
+    const float right_f = static_cast<float>(static_cast<unsigned>(gx) + 1u) * delta;
+    const int left_i = static_cast<int>(floorf(left_f));
+    const int right_i = min(in_w, static_cast<int>(ceilf(right_f)));
+    const int cells = right_i - left_i;
+    // span of the whole wave: first lane's left cell .. last valid lane's right cell (block-uniform)
+    const int x_first = blockIdx.x * 64, x_last = min(x_first + 63, out_w - 1);
+    const int lo = static_cast<int>(floorf(static_cast<float>(static_cast<unsigned>(x_first)) * delta));
+    const int hi = min(in_w, static_cast<int>(ceilf(static_cast<float>(static_cast<unsigned>(x_last) + 1u) * delta)));
+    const float* row = in + static_cast<size_t>(min(y, out_h - 1)) * pitch;
+    float value = 0.f;
+    for (int c0 = lo; c0 < hi; c0 += kResampleChunk) {
+        const int c1 = min(c0 + kResampleChunk, hi);
+        for (int i = c0 + lane; i < c1; i += 64) {
+            const int k = i - c0;
+            lds[wave][k + (k >> 5)] = row[i];
+        }
+        __syncthreads();
+        if (active) {
+            const int b = max(left_i, c0), e = min(right_i, c1);
+            for (int i = b; i < e; ++i) {
+                const int j = i - left_i;
+                float frac = 1.f;
+                if (j == 0) frac = static_cast<float>(left_i + 1) - left_f;
+                if (j == cells - 1) frac = right_f - static_cast<float>(left_i + j);
+                if (cells == 1) frac = delta;
+                const int k = i - c0;
+                value += lds[wave][k + (k >> 5)] * frac;
+            }
+        }
+        __syncthreads();
+    }
+    if (active) out[static_cast<size_t>(y) * pitch + x] = value * normalization;
+}
+
 // ---- backward registration: src/kernels/registration_2d.cu:34-73 --------------------------------
 __global__ __launch_bounds__(256) void registration_kernel(const float* __restrict__ f0, const float* __restrict__ f1,
                                                            const float* __restrict__ u, const float* __restrict__ v,
@@ -210,7 +266,11 @@ static int launch_resample(flow2d_context* ctx, bool along_x, const float* input
     if (!flow2d::plane_args_ok(input, in_w, in_h, pitch_bytes) ||
         !flow2d::plane_args_ok(output, out_width, out_height, pitch_bytes) || input == output)
         return FLOW2D_ERR_INVALID_ARGUMENT;
-    if (along_x)
+    if (along_x && in_extent >= 2 * out_width)  // strong down-sampling: coalesced staging through LDS
+        resample_x_lds_kernel<<<dim3(flow2d::div_up(out_width, 64), flow2d::div_up(out_height, 4)), 256, 0,
+                                ctx->stream>>>(input, output, (int)out_width, (int)out_height, (int)in_extent,
+                                               (int)(pitch_bytes / 4));
+    else if (along_x)
         resample_kernel<true><<<grid_for(out_width, out_height), dim3(kBlockX, kBlockY), 0, ctx->stream>>>(
             input, output, (int)out_width, (int)out_height, (int)in_extent, (int)(pitch_bytes / 4));
     else

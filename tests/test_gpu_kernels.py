@@ -43,7 +43,8 @@ def test_gaussian(ctx, flow2d, oracle, w, h, cw, ch, sigma):
 
 
 @pytest.mark.parametrize("w,h,ow,oh", [(100, 70, 80, 64), (100, 70, 37, 20), (100, 70, 13, 9), (100, 70, 5, 4),
-                                       (37, 20, 100, 70), (64, 64, 32, 32), (33, 17, 34, 18)])
+                                       (37, 20, 100, 70), (64, 64, 32, 32), (33, 17, 34, 18), (1000, 37, 77, 9), (4096, 8, 32, 8),
+                                       (5000, 5, 2, 3), (300, 40, 150, 40), (257, 13, 128, 6)])
 def test_resample(ctx, oracle, w, h, ow, oh):
     cw, ch = max(w, ow) + 3, max(h, oh) + 2
     f0, *_ = level_fields(oracle, w, h, 3)
