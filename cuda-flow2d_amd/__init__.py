@@ -109,6 +109,7 @@ def hip_lib():
         L.flow2d_solve_2d_grad.argtypes = [vp] * 9 + [sz, sz, sz, f, f, f, vp, vp]
         L.flow2d_solve_level.argtypes = [vp] * 11 + [C.POINTER(SolveParams), C.POINTER(i)]
         L.flow2d_timing_enable.argtypes = [vp, i]
+        L.flow2d_timing_launch_filter.argtypes = [vp, sz, sz]
         L.flow2d_timing_count.argtypes = [vp, C.POINTER(sz)]
         L.flow2d_timing_get.argtypes = [vp, sz, C.POINTER(TimingRecord)]
         L.flow2d_timing_reset.argtypes = [vp]

@@ -21,6 +21,8 @@ struct flow2d_context {
     hipStream_t stream = nullptr;
     bool owns_stream = false;
     int timing = 0;  // flow2d_timing_enable mode
+    size_t timing_min_w = 0, timing_min_h = 0;  // flow2d_timing_launch_filter
+    std::vector<hipEvent_t> event_pool;          // recycled timing events
     std::vector<flow2d_timing_slot> timings;
     int num_cus = 256;
 };

@@ -114,6 +114,8 @@ int flow2d_context_destroy(flow2d_context* ctx)
     FLOW2D_ENTER(ctx);
     (void)hipStreamSynchronize(ctx->stream);
     flow2d_timing_reset(ctx);
+    for (hipEvent_t ev : ctx->event_pool) (void)hipEventDestroy(ev);
+    ctx->event_pool.clear();
     if (ctx->owns_stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return FLOW2D_OK;

@@ -24,10 +24,20 @@ int launch_fused_outer(flow2d_context* ctx, int constancy, const float* f0, cons
 
 namespace {
 // mode-2 timing: one more event on the stream, appended to the slot's start/stop list
+hipError_t take_event(flow2d_context* ctx, hipEvent_t* ev)
+{
+    if (!ctx->event_pool.empty()) {
+        *ev = ctx->event_pool.back();
+        ctx->event_pool.pop_back();
+        return hipSuccess;
+    }
+    return hipEventCreate(ev);
+}
+
 hipError_t mark(flow2d_context* ctx, flow2d_timing_slot* slot)
 {
     hipEvent_t ev;
-    hipError_t e = hipEventCreate(&ev);
+    hipError_t e = take_event(ctx, &ev);
     if (e != hipSuccess) return e;
     slot->kernel_events.push_back(ev);
     return hipEventRecord(ev, ctx->stream);
@@ -68,8 +78,8 @@ int flow2d_solve_level(flow2d_context* ctx, const float* frame_0, const float* f
     flow2d_timing_slot* slot = nullptr;
     if (ctx->timing) {
         flow2d_timing_slot s{};
-        FLOW2D_HIP_TRY(hipEventCreate(&s.start));
-        FLOW2D_HIP_TRY(hipEventCreate(&s.stop));
+        FLOW2D_HIP_TRY(take_event(ctx, &s.start));
+        FLOW2D_HIP_TRY(take_event(ctx, &s.stop));
         ctx->timings.push_back(s);
         slot = &ctx->timings.back();
         FLOW2D_HIP_TRY(hipEventRecord(slot->start, ctx->stream));
@@ -81,6 +91,7 @@ int flow2d_solve_level(flow2d_context* ctx, const float* frame_0, const float* f
     FLOW2D_HIP_TRY(hipMemset2DAsync(flow_dv, p->pitch_bytes, 0, p->width * sizeof(float), p->container_height,
                                     ctx->stream));
 
+    const bool per_launch = slot && ctx->timing >= 2 && p->width >= ctx->timing_min_w && p->height >= ctx->timing_min_h;
     float* du = flow_du;
     float* dv = flow_dv;
     float* tdu = temp_du;
@@ -92,13 +103,13 @@ int flow2d_solve_level(flow2d_context* ctx, const float* frame_0, const float* f
         // phi and ksi are not materialised in this mode.
         const int rows = rows_env > 0 ? rows_env
                                       : flow2d::fused_rows_per_strip(ctx, p->width, p->height, p->inner_iterations_count);
-        if (slot && ctx->timing >= 2) FLOW2D_HIP_TRY(mark(ctx, slot));
+        if (per_launch) FLOW2D_HIP_TRY(mark(ctx, slot));
         int st = flow2d::launch_fused_outer(ctx, p->data_constancy, frame_0, frame_1, flow_u, flow_v, du, dv, p->width,
                                             p->height, p->pitch_bytes, p->hx, p->hy, p->equation_alpha,
                                             p->equation_smoothness, p->equation_data, p->inner_iterations_count, tdu,
                                             tdv, rows);
         if (st != FLOW2D_OK) return st;
-        if (slot && ctx->timing >= 2) FLOW2D_HIP_TRY(mark(ctx, slot));
+        if (per_launch) FLOW2D_HIP_TRY(mark(ctx, slot));
         std::swap(du, tdu);
         std::swap(dv, tdv);
         ++launches;
@@ -109,11 +120,11 @@ int flow2d_solve_level(flow2d_context* ctx, const float* frame_0, const float* f
                                         ksi);
         if (st != FLOW2D_OK) return st;
         for (size_t j = 0; j < p->inner_iterations_count; ++j) {
-            if (slot && ctx->timing >= 2) FLOW2D_HIP_TRY(mark(ctx, slot));
+            if (per_launch) FLOW2D_HIP_TRY(mark(ctx, slot));
             st = flow2d::launch_sweep(ctx, p->data_constancy, frame_0, frame_1, flow_u, flow_v, du, dv, phi, ksi,
                                       p->width, p->height, p->pitch_bytes, p->hx, p->hy, p->equation_alpha, tdu, tdv);
             if (st != FLOW2D_OK) return st;
-            if (slot && ctx->timing >= 2) FLOW2D_HIP_TRY(mark(ctx, slot));
+            if (per_launch) FLOW2D_HIP_TRY(mark(ctx, slot));
             std::swap(du, tdu);
             std::swap(dv, tdv);
             ++launches;
@@ -142,6 +153,14 @@ int flow2d_timing_enable(flow2d_context* ctx, int mode)
 {
     if (!ctx || mode < 0 || mode > 2) return FLOW2D_ERR_INVALID_ARGUMENT;
     ctx->timing = mode;
+    return FLOW2D_OK;
+}
+
+int flow2d_timing_launch_filter(flow2d_context* ctx, size_t min_width, size_t min_height)
+{
+    if (!ctx) return FLOW2D_ERR_INVALID_ARGUMENT;
+    ctx->timing_min_w = min_width;
+    ctx->timing_min_h = min_height;
     return FLOW2D_OK;
 }
 
@@ -177,10 +196,10 @@ int flow2d_timing_get(flow2d_context* ctx, size_t index, flow2d_timing_record* o
 int flow2d_timing_reset(flow2d_context* ctx)
 {
     FLOW2D_ENTER(ctx);
-    for (auto& s : ctx->timings) {
-        (void)hipEventDestroy(s.start);
-        (void)hipEventDestroy(s.stop);
-        for (hipEvent_t ev : s.kernel_events) (void)hipEventDestroy(ev);
+    for (auto& s : ctx->timings) {  // events go back to the pool (destroyed with the context)
+        ctx->event_pool.push_back(s.start);
+        ctx->event_pool.push_back(s.stop);
+        for (hipEvent_t ev : s.kernel_events) ctx->event_pool.push_back(ev);
     }
     ctx->timings.clear();
     return FLOW2D_OK;

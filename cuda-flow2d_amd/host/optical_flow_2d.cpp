@@ -269,6 +269,8 @@ bool OpticalFlow2D::RunPyramid(OperationParameters& params)
     }
 
     flow2d_timing_enable(context_, timing_mode);
+    // per-launch brackets (mode 2) only on the finest level: that is the kernel the roofline is quoted on
+    flow2d_timing_launch_filter(context_, dev_container_size_.width, dev_container_size_.height);
 
     DevicePtr frame_0 = dev_frame_0_, frame_1 = dev_frame_1_, flow_u = dev_flow_u_, flow_v = dev_flow_v_;
     DevicePtr frame_0_res = Acquire(), frame_1_res = Acquire(), flow_du = Acquire(), flow_dv = Acquire();

@@ -203,6 +203,9 @@ typedef struct flow2d_timing_record {
 } flow2d_timing_record;
 
 FLOW2D_API int flow2d_timing_enable(flow2d_context* ctx, int mode);
+/* mode 2 brackets individual launches only for levels of at least min_width x min_height pixels
+ * (default 0 x 0 = every level); smaller levels still get their mode-1 record. */
+FLOW2D_API int flow2d_timing_launch_filter(flow2d_context* ctx, size_t min_width, size_t min_height);
 FLOW2D_API int flow2d_timing_count(flow2d_context* ctx, size_t* count);
 FLOW2D_API int flow2d_timing_get(flow2d_context* ctx, size_t index, flow2d_timing_record* out);
 FLOW2D_API int flow2d_timing_reset(flow2d_context* ctx);
