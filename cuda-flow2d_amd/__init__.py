@@ -361,6 +361,7 @@ def host_lib():
         L.flow2d_host_level_timings.restype = sz
         L.flow2d_host_level_timings.argtypes = [vp, fp, sz]
         L.flow2d_host_reset_timings.argtypes = [vp]
+        L.flow2d_host_use_graph.argtypes = [vp, i]
         L.flow2d_host_missing_key_leaves_outputs.argtypes = [vp, C.c_char_p]
         L.flow2d_host_read_raw.argtypes = [C.c_char_p, sz, sz, i, fp]
         L.flow2d_host_write_outputs.argtypes = [fp, fp, sz, sz, C.c_char_p, C.c_char_p, f]
@@ -428,6 +429,10 @@ class OpticalFlow:
         n = host_lib().flow2d_host_level_timings(self.handle, _fptr(buf), cap)
         return [(int(buf[6 * i]), int(buf[6 * i + 1]), float(buf[6 * i + 2]), float(buf[6 * i + 3]),
                  int(buf[6 * i + 4]), float(buf[6 * i + 5])) for i in range(min(n, cap))]
+
+    def use_graph(self, on=True):
+        """Record the pyramid of a (buffers, parameters) combination once and replay it (HIP graph)."""
+        host_lib().flow2d_host_use_graph(self.handle, int(on))
 
     def reset_timings(self):
         host_lib().flow2d_host_reset_timings(self.handle)

@@ -227,6 +227,51 @@ int flow2d_copy_d2d(flow2d_context* ctx, void* dst_dev, const void* src_dev, siz
     return FLOW2D_OK;
 }
 
+int flow2d_capture_begin(flow2d_context* ctx)
+{
+    FLOW2D_ENTER(ctx);
+    if (ctx->timing != 0) {
+        flow2d::set_last_error_text("flow2d_capture_begin: switch launch timing off before capturing");
+        return FLOW2D_ERR_INVALID_ARGUMENT;
+    }
+    FLOW2D_HIP_TRY(hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
+    return FLOW2D_OK;
+}
+
+int flow2d_capture_end(flow2d_context* ctx, void** out_graph_exec)
+{
+    FLOW2D_ENTER(ctx);
+    if (!out_graph_exec) return FLOW2D_ERR_INVALID_ARGUMENT;
+    *out_graph_exec = nullptr;
+    hipGraph_t graph = nullptr;
+    FLOW2D_HIP_TRY(hipStreamEndCapture(ctx->stream, &graph));
+    hipGraphExec_t exec = nullptr;
+    hipError_t e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(graph);
+    if (e != hipSuccess) {
+        flow2d::set_last_error("hipGraphInstantiate", e);
+        return FLOW2D_ERR_DEVICE;
+    }
+    *out_graph_exec = exec;
+    return FLOW2D_OK;
+}
+
+int flow2d_graph_launch(flow2d_context* ctx, void* graph_exec)
+{
+    FLOW2D_ENTER(ctx);
+    if (!graph_exec) return FLOW2D_ERR_INVALID_ARGUMENT;
+    FLOW2D_HIP_TRY(hipGraphLaunch(static_cast<hipGraphExec_t>(graph_exec), ctx->stream));
+    return FLOW2D_OK;
+}
+
+int flow2d_graph_destroy(flow2d_context* ctx, void* graph_exec)
+{
+    FLOW2D_ENTER(ctx);
+    if (!graph_exec) return FLOW2D_OK;
+    FLOW2D_HIP_TRY(hipGraphExecDestroy(static_cast<hipGraphExec_t>(graph_exec)));
+    return FLOW2D_OK;
+}
+
 int flow2d_event_create(flow2d_context* ctx, void** out_event)
 {
     FLOW2D_ENTER(ctx);

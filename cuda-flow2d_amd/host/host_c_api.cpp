@@ -136,6 +136,11 @@ HOST_API size_t flow2d_host_level_timings(flow2d_host_flow* h, float* triples, s
     return t.size();
 }
 
+HOST_API void flow2d_host_use_graph(flow2d_host_flow* h, int on)
+{
+    if (h) h->flow.use_graph = on != 0;
+}
+
 HOST_API void flow2d_host_reset_timings(flow2d_host_flow* h)
 {
     if (h) h->flow.ResetLevelTimings();

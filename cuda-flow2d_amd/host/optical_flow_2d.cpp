@@ -117,6 +117,7 @@ void OpticalFlow2D::Destroy()
     for (CudaOperationBase* cuop : ops) cuop->Destroy();
     if (context_) {
         if (!all_planes_.empty()) flow2d_synchronize(context_);
+        DropGraphs();
         if (free_planes_.size() != all_planes_.size())
             std::printf("Warning. Not all device memory allocations were freed.\n");
         for (DevicePtr p : all_planes_) flow2d_plane_free(context_, AsPlane(p));
@@ -194,10 +195,70 @@ void OpticalFlow2D::ComputeFlow(Data2D& frame_0, Data2D& frame_1, Data2D& flow_u
     Release(dev_flow_v_);
 }
 
+namespace {
+// Everything a recorded pyramid depends on: the four caller buffers and the nine (+1) parameters.
+std::vector<unsigned char> GraphKey(DevicePtr a, DevicePtr b, DevicePtr c, DevicePtr d, OperationParameters& params)
+{
+    std::vector<unsigned char> key;
+    auto put = [&key](const void* p, size_t n) {
+        const unsigned char* q = static_cast<const unsigned char*>(p);
+        key.insert(key.end(), q, q + n);
+    };
+    const DevicePtr ptrs[4] = {a, b, c, d};
+    put(ptrs, sizeof(ptrs));
+    const char* size_keys[] = {"warp_levels_count", "outer_iterations_count", "inner_iterations_count", "median_radius"};
+    const char* float_keys[] = {"warp_scale_factor", "equation_alpha", "equation_smoothness", "equation_data",
+                                "gaussian_sigma"};
+    for (const char* k : size_keys) {
+        size_t v = ~size_t(0);
+        params.Read<size_t>(k, v);
+        put(&v, sizeof(v));
+    }
+    for (const char* k : float_keys) {
+        float v = -1.f;
+        params.Read<float>(k, v);
+        put(&v, sizeof(v));
+    }
+    int algorithm = FLOW2D_SOLVER_AUTO;
+    params.Read<int>("solver_algorithm", algorithm);
+    put(&algorithm, sizeof(algorithm));
+    return key;
+}
+}  // namespace
+
+void OpticalFlow2D::DropGraphs()
+{
+    for (auto& kv : graphs_)
+        if (kv.second && context_) flow2d_graph_destroy(context_, kv.second);
+    graphs_.clear();
+}
+
 bool OpticalFlow2D::ComputeFlowDevice(DevicePtr dev_frame_0, DevicePtr dev_frame_1, DevicePtr dev_flow_u,
                                       DevicePtr dev_flow_v, OperationParameters& params)
 {
     if (!IsInitialized() || !dev_frame_0 || !dev_frame_1 || !dev_flow_u || !dev_flow_v) return false;
+    if (!use_graph || timing_mode != 0) return QueuePair(dev_frame_0, dev_frame_1, dev_flow_u, dev_flow_v, params);
+
+    std::vector<unsigned char> key = GraphKey(dev_frame_0, dev_frame_1, dev_flow_u, dev_flow_v, params);
+    auto it = graphs_.find(key);
+    if (it == graphs_.end()) {
+        if (graphs_.size() >= kMaxGraphs) DropGraphs();
+        if (CheckFlow2DError(flow2d_capture_begin(context_), "flow2d_capture_begin")) return false;
+        const bool queued = QueuePair(dev_frame_0, dev_frame_1, dev_flow_u, dev_flow_v, params);
+        void* exec = nullptr;
+        const bool ended = !CheckFlow2DError(flow2d_capture_end(context_, &exec), "flow2d_capture_end");
+        if (!queued || !ended) {
+            if (exec) flow2d_graph_destroy(context_, exec);
+            return false;
+        }
+        it = graphs_.emplace(std::move(key), exec).first;
+    }
+    return !CheckFlow2DError(flow2d_graph_launch(context_, it->second), "flow2d_graph_launch");
+}
+
+bool OpticalFlow2D::QueuePair(DevicePtr dev_frame_0, DevicePtr dev_frame_1, DevicePtr dev_flow_u,
+                              DevicePtr dev_flow_v, OperationParameters& params)
+{
     const size_t bytes = dev_container_size_.pitch * dev_container_size_.height;
     dev_frame_0_ = Acquire();
     dev_frame_1_ = Acquire();

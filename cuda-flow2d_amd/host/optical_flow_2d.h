@@ -15,6 +15,7 @@
 #pragma once
 
 #include <cstddef>
+#include <map>
 #include <vector>
 
 #include "cuda_operations_2d.h"
@@ -72,6 +73,11 @@ public:
     bool ComputeFlowDevice(DevicePtr dev_frame_0, DevicePtr dev_frame_1, DevicePtr dev_flow_u, DevicePtr dev_flow_v,
                            OperationParameters& params);
 
+    // When set, ComputeFlowDevice records the whole pyramid of a pair into a HIP graph the first time it
+    // sees a (buffers, parameters) combination and replays it afterwards: one host call instead of
+    // several hundred launches.  Ignored while timing_mode != 0 (events are not captured).
+    bool use_graph = false;
+
     const DataSize3& ContainerSize() const { return dev_container_size_; }
     // Device time of the last ComputeFlow (events around upload..download), milliseconds.
     float LastTotalMs() const { return last_total_ms_; }
@@ -87,6 +93,9 @@ private:
     bool InitMemory();
     bool InitOperations();
     bool RunPyramid(OperationParameters& params);
+    bool QueuePair(DevicePtr dev_frame_0, DevicePtr dev_frame_1, DevicePtr dev_flow_u, DevicePtr dev_flow_v,
+                   OperationParameters& params);
+    void DropGraphs();
     DevicePtr Acquire();
     void Release(DevicePtr p);
 
@@ -97,6 +106,9 @@ private:
     DevicePtr dev_frame_0_ = 0, dev_frame_1_ = 0, dev_flow_u_ = 0, dev_flow_v_ = 0;  // valid inside a run
     flow2d_context* context_ = nullptr;
     float last_total_ms_ = 0.f;
+    // recorded pyramids, keyed by the caller buffers and parameters they were recorded for
+    std::map<std::vector<unsigned char>, void*> graphs_;
+    static constexpr size_t kMaxGraphs = 32;
 
     CudaOperationAdd2D cuop_add_;
     CudaOperationConvolution2D cuop_convolution_;

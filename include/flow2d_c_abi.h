@@ -97,6 +97,16 @@ FLOW2D_API int flow2d_event_synchronize(flow2d_context* ctx, void* event);
 FLOW2D_API int flow2d_event_elapsed_ms(flow2d_context* ctx, void* start_event, void* stop_event, float* out_ms);
 FLOW2D_API int flow2d_event_destroy(flow2d_context* ctx, void* event);
 
+/* ---- stream capture (no counterpart in the reference, which launches eagerly and blocks after every
+ *      sweep).  Everything queued on the context between begin and end is recorded into a HIP graph
+ *      instead of being executed; flow2d_graph_launch replays it with one host call.  Used by the host
+ *      layer to replay a whole pyramid (several hundred launches) for repeated pairs of one size.
+ *      Only stream-ordered calls are legal while capturing (no alloc/free/synchronise/event query). --- */
+FLOW2D_API int flow2d_capture_begin(flow2d_context* ctx);
+FLOW2D_API int flow2d_capture_end(flow2d_context* ctx, void** out_graph_exec);
+FLOW2D_API int flow2d_graph_launch(flow2d_context* ctx, void* graph_exec);
+FLOW2D_API int flow2d_graph_destroy(flow2d_context* ctx, void* graph_exec);
+
 /* ---- kernel launchers: one per `extern "C" __global__` symbol of src/kernels/ -------------- */
 
 /* add_2d (src/kernels/add_2d.cu:33-46): operand_0 += operand_1 on w x h. */

@@ -176,3 +176,40 @@ def test_cli_rub_settings_file(flow2d, oracle, tmp_path):
                             str(out) + "/"], stdout=subprocess.DEVNULL) == 2
     assert subprocess.call([flow2d.CLI_PATH, str(tmp_path / "absent.xml")], stdout=subprocess.DEVNULL) == 3
     assert subprocess.call([flow2d.CLI_PATH, "a", "b", "c"], stdout=subprocess.DEVNULL) == 0  # usage
+
+
+def test_graph_replay_matches_eager(flow2d, oracle, ctx):
+    """A recorded pyramid replayed on new frame contents gives the same bits as eager launches / the oracle."""
+    w, h = 160, 96
+    flow = flow2d.OpticalFlow(w, h, 0, ctx=ctx)
+    try:
+        p = flow.params(4, 0.5, 2, 5, 35.0, 0.001, 0.001, 5, 1.5)
+        f0, f1 = oracle.synthetic_pair(w, h, 1.0, 0.5, seed=2, noise=True)
+        planes = [ctx.plane(w, h, f0), ctx.plane(w, h, f1), ctx.plane(w, h), ctx.plane(w, h)]
+        ptrs = [pl.ptr for pl in planes]
+        flow.compute_flow_device(*ptrs, p)
+        ctx.synchronize()
+        eager_u, eager_v = planes[2].download(), planes[3].download()
+        flow.use_graph(True)
+        for _ in range(3):  # first call records, the others replay
+            planes[2].fill_bytes(0x55)
+            planes[3].fill_bytes(0x55)
+            flow.compute_flow_device(*ptrs, p)
+            ctx.synchronize()
+            assert np.array_equal(planes[2].download(), eager_u) and np.array_equal(planes[3].download(), eager_v)
+        # same buffers, new contents: the replayed graph must compute the new pair
+        g0, g1 = oracle.synthetic_pair(w, h, -1.5, 0.75, seed=4, noise=True)
+        planes[0].upload(g0)
+        planes[1].upload(g1)
+        flow.compute_flow_device(*ptrs, p)
+        ctx.synchronize()
+        ou, ov, _ = oracle.compute_flow(g0, g1, 4, 0.5, 2, 5, 35.0, 0.001, 0.001, 5, 1.5)
+        assert np.array_equal(planes[2].download(), ou) and np.array_equal(planes[3].download(), ov)
+        # different parameters -> a different graph, not a stale replay
+        p2 = flow.params(3, 0.5, 1, 3, 35.0, 0.001, 0.001, 3, 0.45)
+        flow.compute_flow_device(*ptrs, p2)
+        ctx.synchronize()
+        ou, ov, _ = oracle.compute_flow(g0, g1, 3, 0.5, 1, 3, 35.0, 0.001, 0.001, 3, 0.45)
+        assert np.array_equal(planes[2].download(), ou) and np.array_equal(planes[3].download(), ov)
+    finally:
+        flow.close()
