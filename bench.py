@@ -197,7 +197,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     finest = [r for r in flow.level_timings() if (r[0], r[1]) == (w, h)]
-    elapsed = batch.max_over_ranks(elapsed, device="cuda" if world > 1 else "cpu")
+    elapsed = batch.max_over_ranks(elapsed)
 
     if rank == 0:
         pairs_total = args.steps * cfg["pairs_per_rank"] * world

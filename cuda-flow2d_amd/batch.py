@@ -13,7 +13,7 @@ def world_info():
 def init(backend="nccl", device=None):
     """Joins the process group when launched by torch.distributed.run; a no-op for a single process."""
     rank, local_rank, world = world_info()
-    if world > 1:
+    if world > 1 or "RANK" in os.environ:  # under torch.distributed.run even a single rank joins a group
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
@@ -34,22 +34,32 @@ def barrier():
         dist.barrier()
 
 
-def max_over_ranks(value, device="cpu"):
+def _collective_device(device):
+    """Tensors of a collective must live where the backend works: the current GPU for nccl (RCCL), host for gloo."""
+    import torch
+    import torch.distributed as dist
+    if device is not None:
+        return device
+    return torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else "cpu"
+
+
+def max_over_ranks(value, device=None):
     """The slowest rank's value (the bench contract times the whole job by its slowest rank)."""
     import torch
     import torch.distributed as dist
     if not (dist.is_available() and dist.is_initialized()):
         return float(value)
-    t = torch.tensor([float(value)], dtype=torch.float64, device=device)
+    t = torch.tensor([float(value)], dtype=torch.float64, device=_collective_device(device))
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
 
 
-def gather_digests(local, total_pairs, device="cpu"):
+def gather_digests(local, total_pairs, device=None):
     """local: {global_pair_index: float digest}.  Returns the list of all pairs' digests on every rank."""
     import torch
     import torch.distributed as dist
-    mine = torch.zeros(total_pairs, dtype=torch.float64, device=device)
+    initialised = dist.is_available() and dist.is_initialized()
+    mine = torch.zeros(total_pairs, dtype=torch.float64, device=_collective_device(device) if initialised else "cpu")
     for k, d in local.items():
         mine[k] = d
     if dist.is_available() and dist.is_initialized():
