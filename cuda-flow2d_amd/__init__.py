@@ -100,6 +100,7 @@ def hip_lib():
         L.flow2d_gaussian_kernel.argtypes = [f, C.POINTER(f), C.POINTER(i)]
         L.flow2d_convolution_rows.argtypes = [vp, vp, vp, sz, sz, sz, C.POINTER(f), i]
         L.flow2d_convolution_columns.argtypes = [vp, vp, vp, sz, sz, sz, C.POINTER(f), i]
+        L.flow2d_gaussian_blur.argtypes = [vp, vp, vp, sz, sz, sz, C.POINTER(f), i]
         L.flow2d_median_2d.argtypes = [vp, vp, sz, sz, sz, sz, vp]
         L.flow2d_registration_2d.argtypes = [vp, vp, vp, vp, vp, sz, sz, sz, f, f, vp]
         L.flow2d_resample_x.argtypes = [vp, vp, vp, sz, sz, sz, sz]
@@ -256,6 +257,11 @@ class Context:
         _check(hip_lib().flow2d_convolution_columns(self.handle, dst.ptr, src.ptr, w, h, src.pitch,
                                                     t.ctypes.data_as(C.POINTER(C.c_float)), radius),
                "flow2d_convolution_columns")
+
+    def gaussian_blur(self, dst, src, w, h, taps, radius):
+        t = np.ascontiguousarray(taps, np.float32)
+        _check(hip_lib().flow2d_gaussian_blur(self.handle, dst.ptr, src.ptr, w, h, src.pitch,
+                                              t.ctypes.data_as(C.POINTER(C.c_float)), radius), "flow2d_gaussian_blur")
 
     def median(self, src, w, h, window, dst):
         _check(hip_lib().flow2d_median_2d(self.handle, src.ptr, w, h, src.pitch, window, dst.ptr), "flow2d_median_2d")

@@ -66,6 +66,46 @@ __global__ __launch_bounds__(256) void gauss_kernel(float* __restrict__ dst, con
     dst[static_cast<size_t>(y) * pitch + x] = sum;
 }
 
+// Rows pass and columns pass of the Gaussian in one launch.  A 64x4 workgroup owns a 64 x kBlurTile tile:
+// it evaluates the rows pass for the tile's rows plus `radius` rows above and below into LDS (rows outside
+// the image are zero, exactly what the columns pass of the reference sees through its zero padding), then
+// the columns pass reads LDS.  Same taps, same accumulation order, fp32 intermediate: bit-identical to the
+// two-launch form, with the intermediate plane never touching DRAM.
+constexpr int kBlurTile = 32;
+constexpr int kBlurMaxRadius = 25;
+
+__global__ __launch_bounds__(256) void gauss_fused_kernel(float* __restrict__ dst, const float* __restrict__ src,
+                                                          int w, int h, int pitch, int radius, GaussTaps taps)
+{
+    __shared__ float rows[kBlurTile + 2 * kBlurMaxRadius][kBlockX];
+    const int tx = threadIdx.x, ty = threadIdx.y;
+    const int x = blockIdx.x * kBlockX + tx;
+    const int y0 = blockIdx.y * kBlurTile;
+    const int staged = kBlurTile + 2 * radius;
+    for (int i = ty; i < staged; i += kBlockY) {
+        const int y = y0 - radius + i;
+        float sum = 0.f;
+        if (y >= 0 && y < h && x < w) {
+            const float* line = src + static_cast<size_t>(y) * pitch;
+            for (int j = -radius; j <= radius; ++j) {
+                const int xx = x + j;
+                const float s = (xx >= 0 && xx < w) ? line[xx] : 0.f;
+                sum += taps.t[radius - j] * s;
+            }
+        }
+        rows[i][tx] = sum;
+    }
+    __syncthreads();
+    if (x >= w) return;
+    for (int i = ty; i < kBlurTile; i += kBlockY) {
+        const int y = y0 + i;
+        if (y >= h) break;
+        float sum = 0.f;
+        for (int j = -radius; j <= radius; ++j) sum += taps.t[radius - j] * rows[i + radius + j][tx];
+        dst[static_cast<size_t>(y) * pitch + x] = sum;
+    }
+}
+
 // ---- area-weighted resampling: src/kernels/resample_2d.cu:34-75 (x), :77-118 (y) ----------------
 template <bool kAlongX>
 __global__ __launch_bounds__(256) void resample_kernel(const float* __restrict__ in, float* __restrict__ out,
@@ -255,6 +295,23 @@ int flow2d_convolution_columns(flow2d_context* ctx, float* dst, const float* src
                                size_t pitch_bytes, const float* taps, int radius)
 {
     return launch_gauss(ctx, false, dst, src, width, height, pitch_bytes, taps, radius);
+}
+
+int flow2d_gaussian_blur(flow2d_context* ctx, float* dst, const float* src, size_t width, size_t height,
+                         size_t pitch_bytes, const float* taps, int radius)
+{
+    FLOW2D_ENTER(ctx);
+    if (!flow2d::plane_args_ok(dst, width, height, pitch_bytes) ||
+        !flow2d::plane_args_ok(src, width, height, pitch_bytes) || !taps || dst == src)
+        return FLOW2D_ERR_INVALID_ARGUMENT;
+    if (radius < 0 || radius > kBlurMaxRadius) return FLOW2D_ERR_UNSUPPORTED;
+    GaussTaps t;
+    for (int i = 0; i < 51; ++i) t.t[i] = i < 2 * radius + 1 ? taps[i] : 0.f;
+    const dim3 grid(flow2d::div_up(width, kBlockX), flow2d::div_up(height, kBlurTile));
+    gauss_fused_kernel<<<grid, dim3(kBlockX, kBlockY), 0, ctx->stream>>>(dst, src, (int)width, (int)height,
+                                                                        (int)(pitch_bytes / 4), radius, t);
+    FLOW2D_CHECK_LAUNCH();
+    return FLOW2D_OK;
 }
 
 static int launch_resample(flow2d_context* ctx, bool along_x, const float* input, float* output, size_t out_width,

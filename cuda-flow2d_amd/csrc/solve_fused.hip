@@ -42,6 +42,7 @@ struct FusedArgs {
     float* out_dv;
     int w, h, pitch;
     int rows_per_strip;
+    int zero_increment;  // first outer iteration: du = dv = 0, the planes are not read (and need no memset)
     float hx, hy, alpha, e_smooth, e_data;
 };
 
@@ -118,7 +119,7 @@ __device__ __forceinline__ void strip_step(Strip<INNER, GRAD>& s, const FusedArg
         s.n_f0 = a.f0[o];
         s.n_f1 = a.f1[o];
         s.n_uv = v2f{a.u[o], a.v[o]};
-        s.n_duv = v2f{a.du[o], a.dv[o]};
+        s.n_duv = a.zero_increment ? v2f{0.f, 0.f} : v2f{a.du[o], a.dv[o]};
     }
 
     // ---- stage P, row rp = r-1: phi, brightness derivatives, ksi (solve_2d.cu:138-197) -------------------
@@ -304,7 +305,7 @@ __global__ __launch_bounds__(256) void fused_outer_kernel(FusedArgs a)
         s.n_f0 = a.f0[o];
         s.n_f1 = a.f1[o];
         s.n_uv = v2f{a.u[o], a.v[o]};
-        s.n_duv = v2f{a.du[o], a.dv[o]};
+        s.n_duv = a.zero_increment ? v2f{0.f, 0.f} : v2f{a.du[o], a.dv[o]};
     }
     // the last stored row y1-1 leaves the last sweep at input row (y1-1) + 2 + INNER
     const int r_last = y1 - 1 + 2 + INNER;
@@ -382,11 +383,11 @@ int fused_rows_per_strip(const flow2d_context* ctx, size_t w, size_t h, size_t i
 int launch_fused_outer(flow2d_context* ctx, int constancy, const float* f0, const float* f1, const float* u,
                        const float* v, const float* du, const float* dv, size_t w, size_t h, size_t pitch_bytes,
                        float hx, float hy, float alpha, float e_smooth, float e_data, size_t inner, float* out_du,
-                       float* out_dv, int rows_per_strip)
+                       float* out_dv, int rows_per_strip, bool zero_increment)
 {
     if (!fused_supports(inner)) return FLOW2D_ERR_UNSUPPORTED;
     FusedArgs a{f0, f1, u, v, du, dv, out_du, out_dv, (int)w, (int)h, (int)(pitch_bytes / 4), rows_per_strip,
-                hx, hy, alpha, e_smooth, e_data};
+                zero_increment ? 1 : 0, hx, hy, alpha, e_smooth, e_data};
     const int valid = 64 - 2 * ((int)inner + 1);
     const unsigned strips_x = div_up(w, valid);
     const dim3 grid(div_up(strips_x, 4), div_up(h, rows_per_strip));

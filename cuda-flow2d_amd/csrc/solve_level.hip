@@ -19,7 +19,7 @@ int fused_rows_per_strip(const flow2d_context* ctx, size_t w, size_t h, size_t i
 int launch_fused_outer(flow2d_context* ctx, int constancy, const float* f0, const float* f1, const float* u,
                        const float* v, const float* du, const float* dv, size_t w, size_t h, size_t pitch_bytes,
                        float hx, float hy, float alpha, float e_smooth, float e_data, size_t inner, float* out_du,
-                       float* out_dv, int rows_per_strip);
+                       float* out_dv, int rows_per_strip, bool zero_increment);
 }  // namespace flow2d
 
 namespace {
@@ -85,11 +85,14 @@ int flow2d_solve_level(flow2d_context* ctx, const float* frame_0, const float* f
         FLOW2D_HIP_TRY(hipEventRecord(slot->start, ctx->stream));
     }
 
-    // du = dv = 0 over level width x container height (cuda_operation_solve_2d.cpp:229-232)
-    FLOW2D_HIP_TRY(hipMemset2DAsync(flow_du, p->pitch_bytes, 0, p->width * sizeof(float), p->container_height,
-                                    ctx->stream));
-    FLOW2D_HIP_TRY(hipMemset2DAsync(flow_dv, p->pitch_bytes, 0, p->width * sizeof(float), p->container_height,
-                                    ctx->stream));
+    // du = dv = 0 over level width x container height (cuda_operation_solve_2d.cpp:229-232).  The fused path
+    // starts its first outer iteration from zero increments without reading the planes, so it needs no memset.
+    if (algorithm != FLOW2D_SOLVER_FUSED || p->outer_iterations_count == 0) {
+        FLOW2D_HIP_TRY(hipMemset2DAsync(flow_du, p->pitch_bytes, 0, p->width * sizeof(float), p->container_height,
+                                        ctx->stream));
+        FLOW2D_HIP_TRY(hipMemset2DAsync(flow_dv, p->pitch_bytes, 0, p->width * sizeof(float), p->container_height,
+                                        ctx->stream));
+    }
 
     const bool per_launch = slot && ctx->timing >= 2 && p->width >= ctx->timing_min_w && p->height >= ctx->timing_min_h;
     float* du = flow_du;
@@ -107,7 +110,7 @@ int flow2d_solve_level(flow2d_context* ctx, const float* frame_0, const float* f
         int st = flow2d::launch_fused_outer(ctx, p->data_constancy, frame_0, frame_1, flow_u, flow_v, du, dv, p->width,
                                             p->height, p->pitch_bytes, p->hx, p->hy, p->equation_alpha,
                                             p->equation_smoothness, p->equation_data, p->inner_iterations_count, tdu,
-                                            tdv, rows);
+                                            tdv, rows, i == 0);
         if (st != FLOW2D_OK) return st;
         if (per_launch) FLOW2D_HIP_TRY(mark(ctx, slot));
         std::swap(du, tdu);

@@ -64,14 +64,12 @@ void CudaOperationConvolution2D::Execute(OperationParameters& params)
     }
     ComputeGaussianKernel(gaussian_sigma, 3, 1.0f);
     if (kernel_length_ == 0) return;
-    const int radius = static_cast<int>(kernel_radius_);
-    if (Failed(flow2d_convolution_rows(context_, AsPlane(dev_temp), AsPlane(dev_input), data_size.width,
-                                       data_size.height, dev_container_size_.pitch, kernel_, radius),
-               "flow2d_convolution_rows"))
-        return;
-    Failed(flow2d_convolution_columns(context_, AsPlane(dev_output), AsPlane(dev_temp), data_size.width,
-                                      data_size.height, dev_container_size_.pitch, kernel_, radius),
-           "flow2d_convolution_columns");
+    // rows then columns (cuda_operation_convolution_2d.cpp:169-175), fused into one launch: the temp plane
+    // stays untouched, the output is bit-identical to the two-pass form
+    (void)dev_temp;
+    Failed(flow2d_gaussian_blur(context_, AsPlane(dev_output), AsPlane(dev_input), data_size.width, data_size.height,
+                                dev_container_size_.pitch, kernel_, static_cast<int>(kernel_radius_)),
+           "flow2d_gaussian_blur");
 }
 
 // ---- Median ----------------------------------------------------------------------------------------

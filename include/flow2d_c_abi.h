@@ -126,6 +126,13 @@ FLOW2D_API int flow2d_convolution_rows(flow2d_context* ctx, float* dst, const fl
 FLOW2D_API int flow2d_convolution_columns(flow2d_context* ctx, float* dst, const float* src, size_t width,
                                           size_t height, size_t pitch_bytes, const float* taps, int radius);
 
+/* Both passes of the separable Gaussian in one launch (rows pass into LDS, columns pass out of it): the
+ * result equals flow2d_convolution_rows into a temp followed by flow2d_convolution_columns bit for bit,
+ * with half the DRAM traffic.  Replaces the pair of launches of CudaOperationConvolution2D::Execute
+ * (cuda_operation_convolution_2d.cpp:169-175); no temp plane needed. */
+FLOW2D_API int flow2d_gaussian_blur(flow2d_context* ctx, float* dst, const float* src, size_t width, size_t height,
+                                    size_t pitch_bytes, const float* taps, int radius);
+
 /* median_2d (src/kernels/median_2d.cu:87-299): `window` is the window width (3, 5 or 7; the
  * reference calls it "radius"), mirror borders. */
 FLOW2D_API int flow2d_median_2d(flow2d_context* ctx, const float* input, size_t width, size_t height,

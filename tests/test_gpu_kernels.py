@@ -29,7 +29,7 @@ def test_add(ctx, oracle, w, h, cw, ch):
     assert np.all(got[h:, :] == 7.0) and np.all(got[:, w:] == 7.0)
 
 
-@pytest.mark.parametrize("sigma", [0.45, 1.5, 3.0])
+@pytest.mark.parametrize("sigma", [0.45, 1.5, 3.0, 8.3])
 @pytest.mark.parametrize("w,h,cw,ch", SIZES)
 def test_gaussian(ctx, flow2d, oracle, w, h, cw, ch, sigma):
     f0, *_ = level_fields(oracle, w, h, 2)
@@ -39,7 +39,11 @@ def test_gaussian(ctx, flow2d, oracle, w, h, cw, ch, sigma):
     src, tmp, dst = up(ctx, f0, cw, ch, 5.0), ctx.plane(cw, ch), ctx.plane(cw, ch)
     ctx.convolution_rows(tmp, src, w, h, taps, r)
     ctx.convolution_columns(dst, tmp, w, h, taps, r)
-    assert np.array_equal(dst.download(w, h), oracle.convolution(f0, w, h, sigma))
+    want = oracle.convolution(f0, w, h, sigma)
+    assert np.array_equal(dst.download(w, h), want)
+    fused = ctx.plane(cw, ch).fill_bytes(0x7f)  # both passes in one launch
+    ctx.gaussian_blur(fused, src, w, h, taps, r)
+    assert np.array_equal(fused.download(w, h), want)
 
 
 @pytest.mark.parametrize("w,h,ow,oh", [(100, 70, 80, 64), (100, 70, 37, 20), (100, 70, 13, 9), (100, 70, 5, 4),
