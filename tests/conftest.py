@@ -16,8 +16,11 @@ def pytest_configure(config):
 
 @pytest.fixture(scope="session")
 def flow2d():
-    """The product package (ctypes plumbing over the C-ABI)."""
-    return importlib.import_module("cuda-flow2d_amd")
+    """The product package (ctypes plumbing over the C-ABI).  The native libraries are built in-tree by
+    __graft_entry__.build(); a fresh checkout builds them here once (make is a no-op when up to date)."""
+    mod = importlib.import_module("cuda-flow2d_amd")
+    mod.build()
+    return mod
 
 
 @pytest.fixture(scope="session")
