@@ -122,6 +122,9 @@ def main():
     ap.add_argument("--algorithm", type=int, default=0, help="flow2d_solver_algorithm: 0 auto, 1 per-sweep, 2 fused")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="launch every step eagerly instead of replaying HIP graphs")
+    ap.add_argument("--pipeline", type=int, default=2,
+                    help="independent pairs in flight per GPU when a step holds a single pair: consecutive steps go to "
+                         "alternating streams so one pair's launch-bound coarse levels overlap the next pair's fine levels")
     args = ap.parse_args()
     cfg = WORKLOADS[args.workload]
 
@@ -144,7 +147,7 @@ def main():
     # "lanes": independent (stream, OpticalFlow2D, plane pool) triples.  A rank with several pairs per step
     # spreads them over up to 4 lanes so the launch-bound coarse levels of one pair overlap another pair's work.
     w, h = cfg["w"], cfg["h"]
-    n_lanes = min(4, cfg["pairs_per_rank"])
+    n_lanes = max(1, min(4, cfg["pairs_per_rank"] * args.pipeline))
     lanes = []
     for _ in range(n_lanes):
         c = flow2d.Context(local_rank)
@@ -162,10 +165,12 @@ def main():
         else:
             dx, dy = cfg["dx"], cfg["dy"]
         f0, f1 = synthetic_pair(w, h, dx, dy)
-        lane = lanes[n % n_lanes]
-        c = lane["ctx"]
-        lane["pairs"].append((c.plane(w, h, f0), c.plane(w, h, f1), c.plane(w, h), c.plane(w, h)))
+        targets = [lanes[n % n_lanes]] if cfg["pairs_per_rank"] > 1 else lanes  # single pair: every lane has a copy
+        for lane in targets:
+            c = lane["ctx"]
+            lane["pairs"].append((c.plane(w, h, f0), c.plane(w, h, f1), c.plane(w, h), c.plane(w, h)))
     free_b, total_b = ctx.mem_info()
+    single = cfg["pairs_per_rank"] == 1
 
     def barrier():
         batch.barrier()
@@ -173,27 +178,33 @@ def main():
             lane["ctx"].synchronize()
         torch.cuda.synchronize()
 
-    def step(instrumented):
+    def step(index, instrumented):
         """One pass over this rank's pairs.  Replayed from recorded HIP graphs, except the instrumented pass,
-        which launches eagerly with events around every level's solve and every finest-level solver launch."""
-        for lane in lanes:
-            lane["flow"].use_graph(not instrumented and not args.no_graph)
-        for k in range(max(len(l["pairs"]) for l in lanes)):
+        which launches eagerly with events around every level's solve and every finest-level solver launch.
+        With one pair per step, step `index` goes to stream index mod n_lanes, so consecutive steps overlap."""
+        active = [lanes[index % n_lanes]] if single else lanes
+        if instrumented:  # the instrumented pass runs alone on lane 0 so its launch durations are undisturbed
             for lane in lanes:
+                lane["ctx"].synchronize()
+            active = [lanes[0]] if single else lanes
+        for lane in active:
+            lane["flow"].use_graph(not instrumented and not args.no_graph)
+        for k in range(max(len(l["pairs"]) for l in active)):
+            for lane in active:
                 if k < len(lane["pairs"]):
                     pf0, pf1, pu, pv = lane["pairs"][k]
                     lane["flow"].compute_flow_device(pf0.ptr, pf1.ptr, pu.ptr, pv.ptr, params,
                                                      2 if instrumented else 0)
 
-    for _ in range(max(args.warmup, 1)):
-        step(False)  # also records the graphs
+    for k in range(max(args.warmup, 1) * n_lanes):
+        step(k, False)  # also records the graphs of every lane
     if args.warmup > 0:
-        step(True)
+        step(0, True)
     flow.reset_timings()
     barrier()
     t0 = time.perf_counter()
     for k in range(args.steps):
-        step(k == args.steps - 1)  # the last timed step is the instrumented one (roofline sample)
+        step(k, k == args.steps - 1)  # the last timed step is the instrumented one (roofline sample)
     barrier()
     elapsed = time.perf_counter() - t0
     finest = [r for r in flow.level_timings() if (r[0], r[1]) == (w, h)]
