@@ -21,7 +21,7 @@ HOST_LIB_PATH = os.path.join(_HERE, "host", "libflow2d_host.so")
 CLI_PATH = os.path.join(_HERE, "host", "flow2d")
 
 GREY, GRADIENT = 0, 1
-SOLVER_AUTO, SOLVER_PER_SWEEP, SOLVER_FUSED = 0, 1, 2
+SOLVER_AUTO, SOLVER_PER_SWEEP, SOLVER_FUSED, SOLVER_SINGLE_WORKGROUP = 0, 1, 2, 3
 
 STATUS = {0: "ok", 1: "invalid argument", 2: "no usable HIP device", 3: "HIP runtime error",
           4: "out of device memory", 5: "unsupported parameter"}

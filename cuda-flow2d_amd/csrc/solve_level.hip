@@ -14,6 +14,10 @@ int launch_phi_ksi(flow2d_context* ctx, const float* f0, const float* f1, const 
 int launch_sweep(flow2d_context* ctx, int constancy, const float* f0, const float* f1, const float* u, const float* v,
                  const float* du, const float* dv, const float* phi, const float* ksi, size_t w, size_t h,
                  size_t pitch_bytes, float hx, float hy, float alpha, float* tdu, float* tdv);
+bool small_level_supports(size_t w, size_t h);
+int launch_small_level(flow2d_context* ctx, int constancy, const float* f0, const float* f1, const float* u,
+                       const float* v, size_t w, size_t h, size_t pitch_bytes, float hx, float hy, float alpha,
+                       float e_smooth, float e_data, size_t outer, size_t inner, float* out_du, float* out_dv);
 bool fused_supports(size_t inner);
 int fused_rows_per_strip(const flow2d_context* ctx, size_t w, size_t h, size_t inner);
 int launch_fused_outer(flow2d_context* ctx, int constancy, const float* f0, const float* f1, const float* u,
@@ -62,16 +66,24 @@ int flow2d_solve_level(flow2d_context* ctx, const float* frame_0, const float* f
         return FLOW2D_ERR_INVALID_ARGUMENT;
     if (p->data_constancy != FLOW2D_CONSTANCY_GREY && p->data_constancy != FLOW2D_CONSTANCY_GRADIENT)
         return FLOW2D_ERR_UNSUPPORTED;
-    if (p->algorithm < FLOW2D_SOLVER_AUTO || p->algorithm > FLOW2D_SOLVER_FUSED) return FLOW2D_ERR_INVALID_ARGUMENT;
+    if (p->algorithm < FLOW2D_SOLVER_AUTO || p->algorithm > FLOW2D_SOLVER_SINGLE_WORKGROUP)
+        return FLOW2D_ERR_INVALID_ARGUMENT;
 
     int algorithm = p->algorithm;
     if (algorithm == FLOW2D_SOLVER_AUTO) {
         // Below ~512^2 both forms are launch/latency bound and the per-sweep kernels are marginally
         // quicker (measured on MI355X, profiles/r01_*); above, the fused kernel wins by 1.7-2.9x.
+        // Up to 64 x 32 the whole level runs in one launch on one CU (solve_small.hip; measured 0.06-0.10 ms
+        // against 0.16-0.19 ms for 60 per-sweep launches; at 64 x 64 four pixels per thread spill and lose).
         const bool big = p->width * p->height >= 512 * 512 && p->inner_iterations_count >= 2;
-        algorithm = (big && flow2d::fused_supports(p->inner_iterations_count)) ? FLOW2D_SOLVER_FUSED
-                                                                               : FLOW2D_SOLVER_PER_SWEEP;
+        if (flow2d::small_level_supports(p->width, p->height) && p->height <= 32)
+            algorithm = FLOW2D_SOLVER_SINGLE_WORKGROUP;
+        else
+            algorithm = (big && flow2d::fused_supports(p->inner_iterations_count)) ? FLOW2D_SOLVER_FUSED
+                                                                                   : FLOW2D_SOLVER_PER_SWEEP;
     }
+    if (algorithm == FLOW2D_SOLVER_SINGLE_WORKGROUP && !flow2d::small_level_supports(p->width, p->height))
+        return FLOW2D_ERR_UNSUPPORTED;
     if (algorithm == FLOW2D_SOLVER_FUSED && !flow2d::fused_supports(p->inner_iterations_count))
         return FLOW2D_ERR_UNSUPPORTED;
 
@@ -87,7 +99,7 @@ int flow2d_solve_level(flow2d_context* ctx, const float* frame_0, const float* f
 
     // du = dv = 0 over level width x container height (cuda_operation_solve_2d.cpp:229-232).  The fused path
     // starts its first outer iteration from zero increments without reading the planes, so it needs no memset.
-    if (algorithm != FLOW2D_SOLVER_FUSED || p->outer_iterations_count == 0) {
+    if (algorithm == FLOW2D_SOLVER_PER_SWEEP || (algorithm == FLOW2D_SOLVER_FUSED && p->outer_iterations_count == 0)) {
         FLOW2D_HIP_TRY(hipMemset2DAsync(flow_du, p->pitch_bytes, 0, p->width * sizeof(float), p->container_height,
                                         ctx->stream));
         FLOW2D_HIP_TRY(hipMemset2DAsync(flow_dv, p->pitch_bytes, 0, p->width * sizeof(float), p->container_height,
@@ -100,6 +112,16 @@ int flow2d_solve_level(flow2d_context* ctx, const float* frame_0, const float* f
     float* tdu = temp_du;
     float* tdv = temp_dv;
     int launches = 0;
+    if (algorithm == FLOW2D_SOLVER_SINGLE_WORKGROUP) {
+        if (per_launch) FLOW2D_HIP_TRY(mark(ctx, slot));
+        int st = flow2d::launch_small_level(ctx, p->data_constancy, frame_0, frame_1, flow_u, flow_v, p->width, p->height,
+                                            p->pitch_bytes, p->hx, p->hy, p->equation_alpha, p->equation_smoothness,
+                                            p->equation_data, p->outer_iterations_count, p->inner_iterations_count,
+                                            du, dv);
+        if (st != FLOW2D_OK) return st;
+        if (per_launch) FLOW2D_HIP_TRY(mark(ctx, slot));
+        ++launches;
+    }
     static const int rows_env = std::getenv("FLOW2D_FUSED_ROWS") ? std::atoi(std::getenv("FLOW2D_FUSED_ROWS")) : 0;
     for (size_t i = 0; algorithm == FLOW2D_SOLVER_FUSED && i < p->outer_iterations_count; ++i) {
         // one launch per outer iteration: phi/ksi and all inner sweeps in one pass (solve_fused.hip);
@@ -146,7 +168,10 @@ int flow2d_solve_level(flow2d_context* ctx, const float* frame_0, const float* f
         slot->rec.kernel_launches = launches;
         slot->rec.elapsed_ms = -1.f;
         slot->rec.kernel_ms = -1.f;
-        const double per_px = algorithm == FLOW2D_SOLVER_FUSED ? 32.0 + 40.0 * p->inner_iterations_count : 40.0;
+        double per_px = 40.0;  // one Jacobi sweep
+        if (algorithm == FLOW2D_SOLVER_FUSED) per_px = 32.0 + 40.0 * p->inner_iterations_count;
+        if (algorithm == FLOW2D_SOLVER_SINGLE_WORKGROUP)
+            per_px = p->outer_iterations_count * (32.0 + 40.0 * p->inner_iterations_count);
         slot->rec.algorithmic_bytes_per_launch = per_px * static_cast<double>(p->width) * static_cast<double>(p->height);
     }
     return FLOW2D_OK;

@@ -180,7 +180,9 @@ FLOW2D_API int flow2d_solve_2d_grad(flow2d_context* ctx, const float* frame_0, c
 typedef enum flow2d_solver_algorithm {
     FLOW2D_SOLVER_AUTO = 0,      /* library picks the fastest bit-exact path for the level size */
     FLOW2D_SOLVER_PER_SWEEP = 1, /* one launch per reference kernel launch (K6, K7/K9) */
-    FLOW2D_SOLVER_FUSED = 2      /* one launch per outer iteration: phi/ksi + all inner sweeps fused */
+    FLOW2D_SOLVER_FUSED = 2,     /* one launch per outer iteration: phi/ksi + all inner sweeps fused (inner <= 5) */
+    FLOW2D_SOLVER_SINGLE_WORKGROUP = 3 /* the whole level (all outer x inner iterations) in one launch on one
+                                          CU; levels up to 64 x 64 pixels */
 } flow2d_solver_algorithm;
 
 typedef struct flow2d_solve_params {

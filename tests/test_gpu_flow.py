@@ -109,7 +109,7 @@ def test_device_resident_entry_matches_host_entry(flow2d, oracle, make_flow, ctx
         ou, ov, _ = oracle.compute_flow(f0, f1, 4, 0.5, 3, 5, 35.0, 0.001, 0.001, 5, 1.5)
         assert np.array_equal(u, ou) and np.array_equal(v, ov)
         assert [t[:2] for t in times] == [(25, 15), (50, 30), (100, 60), (200, 120)]
-        assert all(t[2] > 0 and t[4] == 15 for t in times)  # small levels: per-sweep launches
+        assert all(t[2] > 0 for t in times) and [t[4] for t in times] == [1, 1, 15, 15]  # <= 64x32: one launch
         assert all(t[3] < 0 for t in times[:-1]) and 0 < times[-1][3] <= times[-1][2] * 1.05  # launches timed on the finest level only
         assert times[-1][5] == 40.0 * 200 * 120
         # input frames are left untouched

@@ -126,9 +126,35 @@ def test_solve_level(ctx, oracle, w, h, cw, ch, outer, inner, constancy, algorit
     assert np.array_equal(rdv.download(w, h), odv)
     # which pair holds the result: per-sweep = the reference's swap parity (cuda_operation_solve_2d.cpp:288-289),
     # fused = one swap per outer iteration; either way the library reports it
-    fused = algorithm == 2 or (algorithm == 0 and w * h >= 512 * 512 and inner >= 2)
-    launches = outer if fused else outer * inner
+    single = algorithm == 0 and w <= 64 and h <= 32
+    fused = algorithm == 2 or (algorithm == 0 and not single and w * h >= 512 * 512 and inner >= 2)
+    launches = 0 if single else (outer if fused else outer * inner)
     assert (rdu is tdu) == (launches % 2 == 1)
+
+
+@pytest.mark.parametrize("constancy", [0, 1])
+@pytest.mark.parametrize("outer,inner", [(2, 3), (3, 5), (1, 7), (2, 0), (0, 3)])
+@pytest.mark.parametrize("w,h", [(5, 4), (16, 8), (64, 16), (33, 17), (64, 32), (40, 33), (64, 64), (52, 61), (2, 2)])
+def test_solve_level_single_workgroup(ctx, flow2d, oracle, w, h, outer, inner, constancy):
+    """The whole-level kernel (levels up to 64 x 64, any iteration counts) against the oracle."""
+    cw, ch = 64, 64
+    f0, f1, u, v, _, _ = level_fields(oracle, w, h, 9)
+    hx, hy = np.float32(cw / w), np.float32(ch / h)
+    d = [up(ctx, a, cw, ch) for a in (f0, f1, u, v)]
+    du, dv, phi, ksi, tdu, tdv = (ctx.plane(cw, ch).fill_bytes(0x7f) for _ in range(6))
+    rdu, rdv = ctx.solve_level(*d, du, dv, phi, ksi, tdu, tdv, w, h, hx, hy, 3.5, 0.001, 0.001, outer, inner,
+                               constancy, flow2d.SOLVER_SINGLE_WORKGROUP)
+    odu, odv, _, _ = oracle.solve_level(f0, f1, u, v, w, h, hx, hy, 3.5, 0.001, 0.001, outer, inner, constancy)
+    assert rdu is du
+    assert np.array_equal(rdu.download(w, h), odu) and np.array_equal(rdv.download(w, h), odv)
+
+
+def test_solve_level_single_workgroup_rejects_large_levels(ctx, flow2d, oracle):
+    w, h = 65, 40
+    planes = [ctx.plane(w, h).fill_bytes(0) for _ in range(10)]
+    with pytest.raises(flow2d.Flow2DError) as e:
+        ctx.solve_level(*planes, w, h, 1.0, 1.0, 3.5, 0.001, 0.001, 1, 1, 0, flow2d.SOLVER_SINGLE_WORKGROUP)
+    assert e.value.status == 5
 
 
 def test_solve_level_fused_rejects_long_inner_loops(ctx, flow2d, oracle):
