@@ -373,6 +373,12 @@ def host_lib():
         L.flow2d_host_write_outputs.argtypes = [fp, fp, sz, sz, C.c_char_p, C.c_char_p, f]
         L.flow2d_host_convert_to_rgb.argtypes = [f, f, C.POINTER(i)]
         L.flow2d_host_load_settings.argtypes = [C.c_char_p, C.POINTER(HostSettings)]
+        L.flow2d_host_operator_create.restype = vp
+        L.flow2d_host_operator_create.argtypes = [C.c_char_p, sz, sz, sz, i, i]
+        L.flow2d_host_operator_name.restype = C.c_char_p
+        L.flow2d_host_operator_name.argtypes = [vp]
+        L.flow2d_host_operator_execute.argtypes = [vp, C.POINTER(C.c_char_p), C.POINTER(vp), sz]
+        L.flow2d_host_operator_destroy.argtypes = [vp]
         _host = L
     return _host
 
@@ -477,3 +483,38 @@ def load_settings(path):
     s = HostSettings()
     rc = host_lib().flow2d_host_load_settings(path.encode(), C.byref(s))
     return s if rc == 0 else None
+
+
+class Operator:
+    """One of the reference's six operator classes (CudaOperation*2D) behind its Initialize/Execute bag API.
+
+    execute(**bag): every value is a ctypes object (c_ulonglong device pointer, c_size_t, c_float, DataSize3...)
+    whose address is pushed under its keyword, exactly like OperationParameters::PushValuePtr."""
+
+    def __init__(self, kind, container_width, container_height, pitch_bytes, constancy=GREY, ctx=None,
+                 omit_container_size=False):
+        L = host_lib()
+        if ctx is not None:
+            L.flow2d_host_adopt_context(ctx.handle)
+        self.handle = L.flow2d_host_operator_create(kind.encode(), container_width, container_height, pitch_bytes,
+                                                    constancy, int(omit_container_size))
+        if not self.handle:
+            raise Flow2DError(1, "CudaOperation%s2D::Initialize" % kind.capitalize())
+
+    @property
+    def name(self):
+        return host_lib().flow2d_host_operator_name(self.handle).decode()
+
+    def execute(self, **bag):
+        keys = (C.c_char_p * len(bag))(*[k.encode() for k in bag])
+        vals = (C.c_void_p * len(bag))(*[C.cast(C.pointer(v), C.c_void_p) for v in bag.values()])
+        host_lib().flow2d_host_operator_execute(self.handle, keys, vals, len(bag))
+
+    def close(self):
+        if self.handle:
+            host_lib().flow2d_host_operator_destroy(self.handle)
+            self.handle = None
+
+
+class DataSize3(C.Structure):
+    _fields_ = [("width", C.c_size_t), ("height", C.c_size_t), ("pitch", C.c_size_t)]

@@ -228,3 +228,71 @@ HOST_API int flow2d_host_load_settings(const char* path, flow2d_host_settings* o
     std::snprintf(out->dataConstancy, sizeof(out->dataConstancy), "%s", s.dataConstancy.c_str());
     return 0;
 }
+
+// ---- operator-level access: the reference's plugin API (CudaOperationBase::Initialize / Execute with a
+// string-keyed bag of void*) driven from the tests.  `kind`: add, convolution, median, registration, resample,
+// solve.  The bag is given as parallel arrays of keys and pointers to the values (exactly what PushValuePtr takes).
+#include <memory>
+#include <string>
+
+struct flow2d_host_operator {
+    std::unique_ptr<CudaOperationBase> op;
+    DataSize3 container;
+    DataConstancy constancy;
+    flow2d_context* ctx;
+};
+
+HOST_API flow2d_host_operator* flow2d_host_operator_create(const char* kind, size_t container_width,
+                                                           size_t container_height, size_t pitch_bytes, int constancy,
+                                                           int omit_container_size)
+{
+    auto h = std::make_unique<flow2d_host_operator>();
+    const std::string k = kind ? kind : "";
+    if (k == "add") h->op.reset(new CudaOperationAdd2D());
+    else if (k == "convolution") h->op.reset(new CudaOperationConvolution2D());
+    else if (k == "median") h->op.reset(new CudaOperationMedian2D());
+    else if (k == "registration") h->op.reset(new CudaOperationRegistration2D());
+    else if (k == "resample") h->op.reset(new CudaOperationResample2D());
+    else if (k == "solve") h->op.reset(new CudaOperationSolve2D());
+    else return nullptr;
+    h->container = {container_width, container_height, pitch_bytes};
+    h->constancy = static_cast<DataConstancy>(constancy);
+    h->ctx = CurrentDeviceContext();
+    OperationParameters init;
+    if (!omit_container_size) init.PushValuePtr("container_size", &h->container);
+    init.PushValuePtr("data_constancy", &h->constancy);
+    if (!h->op->Initialize(&init)) return nullptr;
+    return h.release();
+}
+
+HOST_API const char* flow2d_host_operator_name(flow2d_host_operator* h) { return h ? h->op->GetName() : ""; }
+
+HOST_API void flow2d_host_operator_execute(flow2d_host_operator* h, const char* const* keys, void* const* values,
+                                           size_t count)
+{
+    if (!h) return;
+    OperationParameters bag;
+    for (size_t i = 0; i < count; ++i) bag.PushValuePtr(keys[i], values[i]);
+    h->op->Execute(bag);
+}
+
+HOST_API void flow2d_host_operator_destroy(flow2d_host_operator* h)
+{
+    if (!h) return;
+    h->op->Destroy();
+    delete h;
+}
+
+// OperationParameters semantics (operation_parameters.cpp:28-47): no overwrite, nullptr for a missing key.
+HOST_API int flow2d_host_bag_selftest(void)
+{
+    OperationParameters bag;
+    int a = 1, b = 2;
+    if (!bag.PushValuePtr("k", &a)) return 1;
+    if (bag.PushValuePtr("k", &b)) return 2;            // an existing key is kept
+    if (bag.GetValuePtr("k") != &a) return 3;
+    if (bag.GetValuePtr("missing") != nullptr) return 4;
+    bag.Clear();
+    if (bag.GetValuePtr("k") != nullptr) return 5;
+    return 0;
+}
