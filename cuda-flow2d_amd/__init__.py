@@ -46,7 +46,7 @@ class SolveParams(C.Structure):
         ("container_height", C.c_size_t), ("hx", C.c_float), ("hy", C.c_float),
         ("equation_alpha", C.c_float), ("equation_smoothness", C.c_float), ("equation_data", C.c_float),
         ("outer_iterations_count", C.c_size_t), ("inner_iterations_count", C.c_size_t),
-        ("data_constancy", C.c_int), ("algorithm", C.c_int),
+        ("data_constancy", C.c_int), ("algorithm", C.c_int), ("sor_omega", C.c_float),
     ]
 
 
@@ -108,6 +108,7 @@ def hip_lib():
         L.flow2d_compute_phi_ksi.argtypes = [vp] * 7 + [sz, sz, sz, f, f, f, f, vp, vp]
         L.flow2d_solve_2d.argtypes = [vp] * 9 + [sz, sz, sz, f, f, f, vp, vp]
         L.flow2d_solve_2d_grad.argtypes = [vp] * 9 + [sz, sz, sz, f, f, f, vp, vp]
+        L.flow2d_solve_2d_sor.argtypes = [vp] * 9 + [sz, sz, sz, f, f, f, f, i]
         L.flow2d_solve_level.argtypes = [vp] * 11 + [C.POINTER(SolveParams), C.POINTER(i)]
         L.flow2d_timing_enable.argtypes = [vp, i]
         L.flow2d_timing_launch_filter.argtypes = [vp, sz, sz]
@@ -288,11 +289,15 @@ class Context:
         _check(fn(self.handle, f0.ptr, f1.ptr, u.ptr, v.ptr, du.ptr, dv.ptr, phi.ptr, ksi.ptr, w, h, f0.pitch, hx, hy,
                   alpha, tdu.ptr, tdv.ptr), "flow2d_solve_2d*")
 
+    def sor_iteration(self, f0, f1, u, v, du, dv, phi, ksi, w, h, hx, hy, alpha, omega, constancy=GREY):
+        _check(hip_lib().flow2d_solve_2d_sor(self.handle, f0.ptr, f1.ptr, u.ptr, v.ptr, du.ptr, dv.ptr, phi.ptr, ksi.ptr,
+                                             w, h, f0.pitch, hx, hy, alpha, omega, constancy), "flow2d_solve_2d_sor")
+
     def solve_level(self, f0, f1, u, v, du, dv, phi, ksi, tdu, tdv, w, h, hx, hy, alpha, e_smooth, e_data, outer,
-                    inner, constancy=GREY, algorithm=SOLVER_AUTO, container_height=None):
+                    inner, constancy=GREY, algorithm=SOLVER_AUTO, container_height=None, sor_omega=0.0):
         """Returns (du_plane, dv_plane) holding the result (the library owns the ping-pong)."""
         p = SolveParams(w, h, f0.pitch, container_height or f0.height, hx, hy, alpha, e_smooth, e_data, outer, inner,
-                        constancy, algorithm)
+                        constancy, algorithm, sor_omega)
         flag = C.c_int(0)
         _check(hip_lib().flow2d_solve_level(self.handle, f0.ptr, f1.ptr, u.ptr, v.ptr, du.ptr, dv.ptr, phi.ptr,
                                             ksi.ptr, tdu.ptr, tdv.ptr, C.byref(p), C.byref(flag)),
@@ -325,6 +330,7 @@ class HostParams(C.Structure):
         ("outer_iterations_count", C.c_size_t), ("inner_iterations_count", C.c_size_t),
         ("equation_alpha", C.c_float), ("equation_smoothness", C.c_float), ("equation_data", C.c_float),
         ("median_radius", C.c_size_t), ("gaussian_sigma", C.c_float), ("solver_algorithm", C.c_int),
+        ("sor_omega", C.c_float),
     ]
 
 
@@ -406,8 +412,10 @@ class OpticalFlow:
         self.pitch = L.flow2d_host_flow_pitch(self.handle)
 
     @staticmethod
-    def params(levels, scale, outer, inner, alpha, e_smooth, e_data, median_radius, sigma, algorithm=SOLVER_AUTO):
-        return HostParams(levels, scale, outer, inner, alpha, e_smooth, e_data, median_radius, sigma, algorithm)
+    def params(levels, scale, outer, inner, alpha, e_smooth, e_data, median_radius, sigma, algorithm=SOLVER_AUTO,
+               sor_omega=0.0):
+        return HostParams(levels, scale, outer, inner, alpha, e_smooth, e_data, median_radius, sigma, algorithm,
+                          sor_omega)
 
     def max_warp_level(self, width, height, scale):
         return host_lib().flow2d_host_max_warp_level(self.handle, width, height, scale)

@@ -69,12 +69,16 @@ __global__ __launch_bounds__(256) void phi_ksi_kernel(const float* __restrict__ 
 }
 
 // The pointwise Jacobi update shared by solve_2d (solve_2d.cu:332-374) and solve_2d_grad (:889-931).
+// SOR = false: Jacobi, the reference's sweep (reads du/dv, writes the separate tdu/tdv planes).
+// SOR = true: opt-in relaxation in place (tdu == du, tdv == dv) of the pixels of one colour; their four
+// neighbours have the other colour, so a half-sweep only reads values it does not write.
+template <bool SOR = false>
 __device__ __forceinline__ void jacobi_update(const float* __restrict__ u, const float* __restrict__ v,
-                                              const float* __restrict__ du, const float* __restrict__ dv,
-                                              const float* __restrict__ phi, const float* __restrict__ ksi,
-                                              const Neighbourhood& n, int x, int y, int w, int h, float hx, float hy,
-                                              float alpha, float J11, float J22, float J12, float J13, float J23,
-                                              float* __restrict__ tdu, float* __restrict__ tdv)
+                                              const float* du, const float* dv, const float* __restrict__ phi,
+                                              const float* __restrict__ ksi, const Neighbourhood& n, int x, int y,
+                                              int w, int h, float hx, float hy, float alpha, float J11, float J22,
+                                              float J12, float J13, float J23, float* tdu, float* tdv,
+                                              float omega = 1.f)
 {
     const float hx_2 = alpha / (hx * hx);
     const float hy_2 = alpha / (hy * hy);
@@ -96,8 +100,12 @@ __device__ __forceinline__ void jacobi_update(const float* __restrict__ u, const
                                 v[n.u] + dv[n.u], v[n.c]);
     float r_du, r_dv;
     const float k = ksi[n.c];
-    point_update(k, update_denominator(k, J11, sumH), update_denominator(k, J22, sumH), J12, J13, J23, sumU, sumV,
-                 dv[n.c], r_du, r_dv);
+    if (SOR)
+        point_update_sor(k, update_denominator(k, J11, sumH), update_denominator(k, J22, sumH), J12, J13, J23, sumU,
+                         sumV, du[n.c], dv[n.c], omega, r_du, r_dv);
+    else
+        point_update(k, update_denominator(k, J11, sumH), update_denominator(k, J22, sumH), J12, J13, J23, sumU, sumV,
+                     dv[n.c], r_du, r_dv);
     tdu[n.c] = r_du;
     tdv[n.c] = r_dv;
 }
@@ -175,6 +183,60 @@ __global__ __launch_bounds__(512) void sweep_grad_kernel(const float* __restrict
     jacobi_update(u, v, du, dv, phi, ksi, n, x, y, w, h, hx, hy, alpha, J11, J22, J12, J13, J23, tdu, tdv);
 }
 
+// ---- opt-in red-black SOR half-sweeps (no counterpart in the reference; BASELINE.json names the scheme) ---
+// One launch relaxes the pixels with (x + y) % 2 == colour in place.  A full iteration = colour 0 then colour 1.
+__global__ __launch_bounds__(256) void sor_grey_kernel(const float* __restrict__ f0, const float* __restrict__ f1,
+                                                       const float* __restrict__ u, const float* __restrict__ v,
+                                                       float* du, float* dv, const float* __restrict__ phi,
+                                                       const float* __restrict__ ksi, int w, int h, int pitch,
+                                                       float hx, float hy, float alpha, float omega, int colour)
+{
+    const int x = blockIdx.x * kBlockX + threadIdx.x;
+    const int y = blockIdx.y * kBlockY + threadIdx.y;
+    if (x >= w || y >= h || ((x + y) & 1) != colour) return;
+    const Neighbourhood n = neighbourhood(x, y, w, h, pitch);
+    float fx, fy, ft;
+    image_derivatives(f0, f1, n, hx, hy, fx, fy, ft);
+    jacobi_update<true>(u, v, du, dv, phi, ksi, n, x, y, w, h, hx, hy, alpha, fx * fx, fy * fy, fx * fy, fx * ft,
+                        fy * ft, du, dv, omega);
+}
+
+__global__ __launch_bounds__(512) void sor_grad_kernel(const float* __restrict__ f0, const float* __restrict__ f1,
+                                                       const float* __restrict__ u, const float* __restrict__ v,
+                                                       float* du, float* dv, const float* __restrict__ phi,
+                                                       const float* __restrict__ ksi, int w, int h, int pitch,
+                                                       float hx, float hy, float alpha, float omega, int colour)
+{
+    __shared__ float s_fx[kGradTileY][kBlockX];
+    __shared__ float s_fy[kGradTileY][kBlockX];
+    __shared__ float s_ft[kGradTileY][kBlockX];
+    const int tx = threadIdx.x, ty = threadIdx.y;
+    const int x = blockIdx.x * kBlockX + tx;
+    const int y = blockIdx.y * kGradTileY + ty;
+    const bool inside = x < w && y < h;
+    Neighbourhood n{};
+    if (inside) {
+        n = neighbourhood(x, y, w, h, pitch);
+        image_derivatives(f0, f1, n, hx, hy, s_fx[ty][tx], s_fy[ty][tx], s_ft[ty][tx]);
+    }
+    __syncthreads();
+    if (!inside || ((x + y) & 1) != colour) return;
+    const int xa = (tx % kGradTileX == 0) ? tx : tx - 1;
+    const int xb = (tx % kGradTileX == kGradTileX - 1 || x == w - 1) ? tx : tx + 1;
+    const int ya = (ty == 0) ? ty : ty - 1;
+    const int yb = (ty == kGradTileY - 1 || y == h - 1) ? ty : ty + 1;
+    const float hx_1 = 1.0 / (2.0 * hx);
+    const float hy_1 = 1.0 / (2.0 * hy);
+    const float fxx = (s_fx[ty][xb] - s_fx[ty][xa]) * hx_1;
+    const float fxy = (s_fx[yb][tx] - s_fx[ya][tx]) * hy_1;
+    const float fyy = (s_fy[yb][tx] - s_fy[ya][tx]) * hy_1;
+    const float fxt = (s_ft[ty][xb] - s_ft[ty][xa]) * hx_1;
+    const float fyt = (s_ft[yb][tx] - s_ft[ya][tx]) * hy_1;
+    float J11, J22, J12, J13, J23;
+    flow2d_math::gradient_tensor(fxx, fxy, fyy, fxt, fyt, J11, J22, J12, J13, J23);
+    jacobi_update<true>(u, v, du, dv, phi, ksi, n, x, y, w, h, hx, hy, alpha, J11, J22, J12, J13, J23, du, dv, omega);
+}
+
 bool solver_planes_ok(const float* const* planes, int count, size_t w, size_t h, size_t pitch_bytes)
 {
     for (int i = 0; i < count; ++i)
@@ -215,6 +277,26 @@ int launch_sweep(flow2d_context* ctx, int constancy, const float* f0, const floa
     return FLOW2D_OK;
 }
 
+// One red-black SOR iteration (two half-sweeps) in place on du / dv.
+int launch_sor_iteration(flow2d_context* ctx, int constancy, const float* f0, const float* f1, const float* u,
+                         const float* v, float* du, float* dv, const float* phi, const float* ksi, size_t w, size_t h,
+                         size_t pitch_bytes, float hx, float hy, float alpha, float omega)
+{
+    for (int colour = 0; colour < 2; ++colour) {
+        if (constancy == FLOW2D_CONSTANCY_GRADIENT) {
+            const dim3 grid(div_up(w, kBlockX), div_up(h, kGradTileY));
+            sor_grad_kernel<<<grid, dim3(kBlockX, kGradTileY), 0, ctx->stream>>>(
+                f0, f1, u, v, du, dv, phi, ksi, (int)w, (int)h, (int)(pitch_bytes / 4), hx, hy, alpha, omega, colour);
+        } else {
+            const dim3 grid(div_up(w, kBlockX), div_up(h, kBlockY));
+            sor_grey_kernel<<<grid, dim3(kBlockX, kBlockY), 0, ctx->stream>>>(
+                f0, f1, u, v, du, dv, phi, ksi, (int)w, (int)h, (int)(pitch_bytes / 4), hx, hy, alpha, omega, colour);
+        }
+        FLOW2D_CHECK_LAUNCH();
+    }
+    return FLOW2D_OK;
+}
+
 }  // namespace flow2d
 
 extern "C" {
@@ -248,6 +330,24 @@ static int sweep_entry(flow2d_context* ctx, int constancy, const float* frame_0,
         if (planes[i] == temp_du || planes[i] == temp_dv) return FLOW2D_ERR_INVALID_ARGUMENT;
     return flow2d::launch_sweep(ctx, constancy, frame_0, frame_1, flow_u, flow_v, flow_du, flow_dv, phi, ksi, width,
                                 height, pitch_bytes, hx, hy, alpha, temp_du, temp_dv);
+}
+
+int flow2d_solve_2d_sor(flow2d_context* ctx, const float* frame_0, const float* frame_1, const float* flow_u,
+                        const float* flow_v, float* flow_du, float* flow_dv, const float* phi, const float* ksi,
+                        size_t width, size_t height, size_t pitch_bytes, float hx, float hy, float equation_alpha,
+                        float omega, int data_constancy)
+{
+    FLOW2D_ENTER(ctx);
+    const float* planes[] = {frame_0, frame_1, flow_u, flow_v, flow_du, flow_dv, phi, ksi};
+    if (!solver_planes_ok(planes, 8, width, height, pitch_bytes) || !(hx > 0.f) || !(hy > 0.f) || flow_du == flow_dv ||
+        !(omega > 0.f) || !(omega < 2.f))
+        return FLOW2D_ERR_INVALID_ARGUMENT;
+    for (int i = 0; i < 8; ++i)
+        if (i != 4 && i != 5 && (planes[i] == flow_du || planes[i] == flow_dv)) return FLOW2D_ERR_INVALID_ARGUMENT;
+    if (data_constancy != FLOW2D_CONSTANCY_GREY && data_constancy != FLOW2D_CONSTANCY_GRADIENT)
+        return FLOW2D_ERR_UNSUPPORTED;
+    return flow2d::launch_sor_iteration(ctx, data_constancy, frame_0, frame_1, flow_u, flow_v, flow_du, flow_dv, phi,
+                                        ksi, width, height, pitch_bytes, hx, hy, equation_alpha, omega);
 }
 
 int flow2d_solve_2d(flow2d_context* ctx, const float* frame_0, const float* frame_1, const float* flow_u,

@@ -14,6 +14,9 @@ int launch_phi_ksi(flow2d_context* ctx, const float* f0, const float* f1, const 
 int launch_sweep(flow2d_context* ctx, int constancy, const float* f0, const float* f1, const float* u, const float* v,
                  const float* du, const float* dv, const float* phi, const float* ksi, size_t w, size_t h,
                  size_t pitch_bytes, float hx, float hy, float alpha, float* tdu, float* tdv);
+int launch_sor_iteration(flow2d_context* ctx, int constancy, const float* f0, const float* f1, const float* u,
+                         const float* v, float* du, float* dv, const float* phi, const float* ksi, size_t w, size_t h,
+                         size_t pitch_bytes, float hx, float hy, float alpha, float omega);
 bool small_level_supports(size_t w, size_t h);
 int launch_small_level(flow2d_context* ctx, int constancy, const float* f0, const float* f1, const float* u,
                        const float* v, size_t w, size_t h, size_t pitch_bytes, float hx, float hy, float alpha,
@@ -69,7 +72,10 @@ int flow2d_solve_level(flow2d_context* ctx, const float* frame_0, const float* f
     if (p->algorithm < FLOW2D_SOLVER_AUTO || p->algorithm > FLOW2D_SOLVER_SINGLE_WORKGROUP)
         return FLOW2D_ERR_INVALID_ARGUMENT;
 
-    int algorithm = p->algorithm;
+    const bool sor = p->sor_omega != 0.f;
+    if (sor && (!(p->sor_omega > 0.f) || !(p->sor_omega < 2.f))) return FLOW2D_ERR_INVALID_ARGUMENT;
+    if (sor && p->algorithm != FLOW2D_SOLVER_AUTO && p->algorithm != FLOW2D_SOLVER_PER_SWEEP) return FLOW2D_ERR_UNSUPPORTED;
+    int algorithm = sor ? FLOW2D_SOLVER_PER_SWEEP : p->algorithm;
     if (algorithm == FLOW2D_SOLVER_AUTO) {
         // Below ~512^2 both forms are launch/latency bound and the per-sweep kernels are marginally
         // quicker (measured on MI355X, profiles/r01_*); above, the fused kernel wins by 1.7-2.9x.
@@ -144,7 +150,14 @@ int flow2d_solve_level(flow2d_context* ctx, const float* frame_0, const float* f
                                         p->pitch_bytes, p->hx, p->hy, p->equation_smoothness, p->equation_data, phi,
                                         ksi);
         if (st != FLOW2D_OK) return st;
-        for (size_t j = 0; j < p->inner_iterations_count; ++j) {
+        for (size_t j = 0; sor && j < p->inner_iterations_count; ++j) {  // opt-in: in place, no ping-pong
+            st = flow2d::launch_sor_iteration(ctx, p->data_constancy, frame_0, frame_1, flow_u, flow_v, du, dv, phi, ksi,
+                                              p->width, p->height, p->pitch_bytes, p->hx, p->hy, p->equation_alpha,
+                                              p->sor_omega);
+            if (st != FLOW2D_OK) return st;
+            launches += 2;
+        }
+        for (size_t j = 0; !sor && j < p->inner_iterations_count; ++j) {
             if (per_launch) FLOW2D_HIP_TRY(mark(ctx, slot));
             st = flow2d::launch_sweep(ctx, p->data_constancy, frame_0, frame_1, flow_u, flow_v, du, dv, phi, ksi,
                                       p->width, p->height, p->pitch_bytes, p->hx, p->hy, p->equation_alpha, tdu, tdv);

@@ -54,6 +54,18 @@ __device__ __forceinline__ void point_update(float ksi, float den_u, float den_v
     dv_new = (ksi * (-J23 - J12 * du_new) + sumV) / den_v;
 }
 
+// Opt-in successive over-relaxation of the same 2x2 point system (NOT in the reference, which is Jacobi with
+// omega = 1): the Gauss-Seidel value is blended with the old one, and dv sees the relaxed du.
+__device__ __forceinline__ void point_update_sor(float ksi, float den_u, float den_v, float J12, float J13, float J23,
+                                                 float sumU, float sumV, float du_old, float dv_old, float omega,
+                                                 float& du_new, float& dv_new)
+{
+    const float gs_du = (ksi * (-J13 - J12 * dv_old) + sumU) / den_u;
+    du_new = (1.f - omega) * du_old + omega * gs_du;
+    const float gs_dv = (ksi * (-J23 - J12 * du_new) + sumV) / den_v;
+    dv_new = (1.f - omega) * dv_old + omega * gs_dv;
+}
+
 // x / d for the grid-spacing divisors (2h, 4h).  When d is a power of two, x * (1/d) is the same
 // correctly rounded value as x / d (1/d is exact and both round the same real number), so the caller
 // may pass inv_d and pow2 = true to replace the ~10-instruction division by one multiply.

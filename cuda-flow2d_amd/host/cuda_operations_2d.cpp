@@ -208,6 +208,8 @@ void CudaOperationSolve2D::Execute(OperationParameters& params)
     FLOW2D_PARAM_OR_RETURN(params, DataConstancy, data_constancy, "data_constancy");
     int algorithm = FLOW2D_SOLVER_AUTO;
     params.Read<int>("solver_algorithm", algorithm);
+    float sor_omega = 0.f;  // superset key: opt-in red-black SOR instead of the reference's Jacobi sweeps
+    params.Read<float>("solver_sor_omega", sor_omega);
 
     // The reference picks the sweep kernel at Initialize and only the LDS size at Execute
     // (cuda_operation_solve_2d.cpp:65-82,181-198); the kernel chosen at Initialize wins.
@@ -218,6 +220,7 @@ void CudaOperationSolve2D::Execute(OperationParameters& params)
     p.container_height = dev_container_size_.height;
     p.data_constancy = init_constancy_ == DataConstancy::Gradient ? FLOW2D_CONSTANCY_GRADIENT : FLOW2D_CONSTANCY_GREY;
     p.algorithm = algorithm;
+    p.sor_omega = sor_omega;
 
     void *ev_start = nullptr, *ev_stop = nullptr;
     if (!silent) {

@@ -58,7 +58,8 @@ public:
 // that after return the result is in the caller's dev_flow_du / dev_flow_dv variables);
 // data_constancy (DataConstancy), outer_iterations_count, inner_iterations_count (size_t),
 // equation_alpha, equation_smoothness, equation_data, hx, hy (float), data_size (DataSize3).
-// Optional superset key: solver_algorithm (int, flow2d_solver_algorithm).
+// Optional superset keys: solver_algorithm (int, flow2d_solver_algorithm), solver_sor_omega (float; opt-in
+// red-black SOR with that factor instead of Jacobi sweeps -- no parity with the reference).
 // cuda_operation_solve_2d.cpp:106-314
 class CudaOperationSolve2D : public CudaOperationBase {
 public:

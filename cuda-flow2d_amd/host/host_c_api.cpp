@@ -23,6 +23,7 @@ struct flow2d_host_params {
     size_t median_radius;
     float gaussian_sigma;
     int solver_algorithm;
+    float sor_omega;
 };
 
 struct flow2d_host_flow {
@@ -43,6 +44,7 @@ void FillBag(OperationParameters& bag, flow2d_host_params& p)
     bag.PushValuePtr("median_radius", &p.median_radius);
     bag.PushValuePtr("gaussian_sigma", &p.gaussian_sigma);
     bag.PushValuePtr("solver_algorithm", &p.solver_algorithm);
+    bag.PushValuePtr("solver_sor_omega", &p.sor_omega);
 }
 }  // namespace
 
@@ -154,7 +156,7 @@ HOST_API int flow2d_host_missing_key_leaves_outputs(flow2d_host_flow* h, const c
     Data2D f0(h->width, h->height), f1(h->width, h->height), u(h->width, h->height), v(h->width, h->height);
     const size_t n = h->width * h->height;
     for (size_t i = 0; i < n; ++i) u.DataPtr()[i] = v.DataPtr()[i] = 77.f;
-    flow2d_host_params p = {3, 0.5f, 1, 1, 3.5f, 0.001f, 0.001f, 5, 0.45f, 0};
+    flow2d_host_params p = {3, 0.5f, 1, 1, 3.5f, 0.001f, 0.001f, 5, 0.45f, 0, 0.f};
     OperationParameters full, bag;
     FillBag(full, p);
     const char* keys[] = {"warp_levels_count", "warp_scale_factor", "outer_iterations_count",

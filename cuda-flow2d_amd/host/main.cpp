@@ -7,7 +7,8 @@
 // exit codes: 1 no device, 2 frame load failed, 3 settings error, 255 cannot write PPM/amp, 0 otherwise.
 // Documented supersets: imageType="8-bit" selects the u8 reader; inputPath is tried as
 // a prefix before the bare file name; argc == 6 no longer dereferences argv[6]; no blocking getchar();
-// options --u8, --gradient, --device N, --verbose may precede the positional arguments.
+// options --u8, --gradient, --device N, --verbose, --sor OMEGA (opt-in red-black SOR, no reference parity)
+// may precede the positional arguments.
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -43,6 +44,7 @@ int main(int argc, char** argv)
     // optional flags first (supersets), then the reference's positional forms
     bool force_u8 = false, verbose = false;
     int device = 0;
+    float sor_omega = 0.f;
     DataConstancy data_constancy = DataConstancy::Grey;
     std::vector<char*> args = {argv[0]};
     for (int i = 1; i < argc; ++i) {
@@ -50,6 +52,7 @@ int main(int argc, char** argv)
         else if (!std::strcmp(argv[i], "--gradient")) data_constancy = DataConstancy::Gradient;
         else if (!std::strcmp(argv[i], "--verbose")) verbose = true;
         else if (!std::strcmp(argv[i], "--device") && i + 1 < argc) device = std::atoi(argv[++i]);
+        else if (!std::strcmp(argv[i], "--sor") && i + 1 < argc) sor_omega = static_cast<float>(std::atof(argv[++i]));
         else args.push_back(argv[i]);
     }
     const int nargs = static_cast<int>(args.size());
@@ -141,6 +144,7 @@ int main(int argc, char** argv)
         params.PushValuePtr("equation_data", &equation_data);
         params.PushValuePtr("median_radius", &median_radius);
         params.PushValuePtr("gaussian_sigma", &gaussian_sigma);
+        if (sor_omega != 0.f) params.PushValuePtr("solver_sor_omega", &sor_omega);
         optical_flow.ComputeFlow(frame_0, frame_1, flow_u, flow_v, params);
 
         const std::string suffix = "-" + std::to_string(width) + "-" + std::to_string(height) + ".raw";

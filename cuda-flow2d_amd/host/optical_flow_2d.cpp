@@ -222,6 +222,9 @@ std::vector<unsigned char> GraphKey(DevicePtr a, DevicePtr b, DevicePtr c, Devic
     int algorithm = FLOW2D_SOLVER_AUTO;
     params.Read<int>("solver_algorithm", algorithm);
     put(&algorithm, sizeof(algorithm));
+    float sor_omega = 0.f;
+    params.Read<float>("solver_sor_omega", sor_omega);
+    put(&sor_omega, sizeof(sor_omega));
     return key;
 }
 }  // namespace
@@ -309,6 +312,8 @@ bool OpticalFlow2D::RunPyramid(OperationParameters& params)
         }
     int solver_algorithm = FLOW2D_SOLVER_AUTO;
     params.Read<int>("solver_algorithm", solver_algorithm);
+    float solver_sor_omega = 0.f;
+    params.Read<float>("solver_sor_omega", solver_sor_omega);
 
     DataSize3 original_size = {dev_container_size_.width, dev_container_size_.height, 0};
     const size_t max_level = GetMaxWarpLevel(original_size.width, original_size.height, warp_scale_factor);
@@ -441,6 +446,7 @@ bool OpticalFlow2D::RunPyramid(OperationParameters& params)
             op.PushValuePtr("hx", &hx);
             op.PushValuePtr("hy", &hy);
             op.PushValuePtr("solver_algorithm", &solver_algorithm);
+            op.PushValuePtr("solver_sor_omega", &solver_sor_omega);
             cuop_solve_.silent = true;  // per-level printing would need a host wait; timings are collected instead
             cuop_solve_.Execute(op);
             Release(phi);

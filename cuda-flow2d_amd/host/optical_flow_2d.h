@@ -7,7 +7,8 @@
 // ComputeFlow bag keys and pointee types (optical_flow_2d.cpp:160-168): warp_levels_count size_t,
 // warp_scale_factor float, outer_iterations_count size_t, inner_iterations_count size_t,
 // equation_alpha float, equation_smoothness float, equation_data float, median_radius size_t,
-// gaussian_sigma float.  Optional superset key: solver_algorithm int (flow2d_solver_algorithm).
+// gaussian_sigma float.  Optional superset keys: solver_algorithm int (flow2d_solver_algorithm),
+// solver_sor_omega float (opt-in red-black SOR; the default 0 keeps the reference's Jacobi sweeps).
 //
 // MI355X-first differences (results unchanged): every launch of a pair is queued on one HIP stream
 // with no host synchronisation until the flow is copied back (the reference blocks after every

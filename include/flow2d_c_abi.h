@@ -170,6 +170,15 @@ FLOW2D_API int flow2d_solve_2d_grad(flow2d_context* ctx, const float* frame_0, c
                                     size_t height, size_t pitch_bytes, float hx, float hy, float equation_alpha,
                                     float* temp_du, float* temp_dv);
 
+/* Opt-in red-black successive over-relaxation: ONE iteration = the pixels with even (x + y), then the odd
+ * ones, relaxed in place on flow_du / flow_dv with factor omega in (0, 2).  NOT a reference kernel: the
+ * reference relaxes with Jacobi sweeps, so this mode has no parity with it at equal iteration
+ * counts; it exists because BASELINE.json names the scheme, and is checked against its own oracle restatement. */
+FLOW2D_API int flow2d_solve_2d_sor(flow2d_context* ctx, const float* frame_0, const float* frame_1,
+                                   const float* flow_u, const float* flow_v, float* flow_du, float* flow_dv,
+                                   const float* phi, const float* ksi, size_t width, size_t height, size_t pitch_bytes,
+                                   float hx, float hy, float equation_alpha, float omega, int data_constancy);
+
 /* ---- the solver's fixed-point loop of one level -------------------------------------------
  * Replaces the launch loop of CudaOperationSolve2D::Execute
  * (src/cuda_operations/2d/cuda_operation_solve_2d.cpp:229-300): zero du/dv (level width x
@@ -197,6 +206,9 @@ typedef struct flow2d_solve_params {
     size_t inner_iterations_count;
     int data_constancy;          /* flow2d_constancy */
     int algorithm;               /* flow2d_solver_algorithm */
+    float sor_omega;             /* 0 (default): Jacobi sweeps as in the reference.  In (0, 2): every inner iteration
+                                    is one red-black SOR iteration instead (opt-in, no reference parity; per-sweep
+                                    launches only; the result stays in flow_du / flow_dv). */
 } flow2d_solve_params;
 
 FLOW2D_API int flow2d_solve_level(flow2d_context* ctx, const float* frame_0, const float* frame_1,

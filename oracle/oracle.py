@@ -41,6 +41,7 @@ class FlowParams(C.Structure):
         ("median_radius", C.c_size_t),
         ("gaussian_sigma", C.c_float),
         ("data_constancy", C.c_int),
+        ("sor_omega", C.c_float),
     ]
 
 
@@ -93,6 +94,8 @@ def lib():
         L.oracle_compute_phi_ksi.argtypes = [fp] * 6 + [sz, sz, sz, f, f, f, f, fp, fp]
         L.oracle_solve_2d.argtypes = [fp] * 8 + [sz, sz, sz, f, f, f, fp, fp]
         L.oracle_solve_2d_grad.argtypes = [fp] * 8 + [sz, sz, sz, f, f, f, fp, fp]
+        L.oracle_solve_2d_sor.argtypes = [fp] * 8 + [sz, sz, sz, f, f, f, f, C.c_int]
+        L.oracle_solve_level_sor.argtypes = [fp] * 8 + [sz, sz, sz, sz, f, f, f, f, f, sz, sz, C.c_int, f]
         L.oracle_add_2d.argtypes = [fp, fp, sz, sz, sz]
         L.oracle_median_2d.restype = C.c_int
         L.oracle_median_2d.argtypes = [fp, sz, sz, sz, sz, fp]
@@ -209,6 +212,21 @@ def solve_sweep(f0, f1, u, v, du, dv, phi, ksi, w, h, hx, hy, alpha, constancy=G
     return tdu, tdv
 
 
+def sor_iteration(f0, f1, u, v, du, dv, phi, ksi, w, h, hx, hy, alpha, omega, constancy=GREY):
+    """One opt-in red-black SOR iteration (not a reference kernel); returns the relaxed (du, dv)."""
+    du, dv = du.copy(), dv.copy()
+    lib().oracle_solve_2d_sor(_p(f0), _p(f1), _p(u), _p(v), _p(du), _p(dv), _p(phi), _p(ksi), w, h, _pitch(f0), hx, hy,
+                              alpha, omega, constancy)
+    return du, dv
+
+
+def solve_level_sor(f0, f1, u, v, w, h, hx, hy, alpha, e_smooth, e_data, outer, inner, omega, constancy=GREY):
+    du, dv, phi, ksi = (np.zeros_like(f0) for _ in range(4))
+    lib().oracle_solve_level_sor(_p(f0), _p(f1), _p(u), _p(v), _p(du), _p(dv), _p(phi), _p(ksi), w, h, _pitch(f0),
+                                 f0.shape[0], hx, hy, alpha, e_smooth, e_data, outer, inner, constancy, omega)
+    return du, dv
+
+
 def add(op0, op1, w, h):
     out = op0.copy()
     lib().oracle_add_2d(_p(out), _p(op1), w, h, _pitch(op0))
@@ -239,7 +257,7 @@ def solve_level(f0, f1, u, v, w, h, hx, hy, alpha, e_smooth, e_data, outer, inne
 
 
 def compute_flow(frame_0, frame_1, levels, scale, outer, inner, alpha, e_smooth, e_data, median_radius, sigma,
-                 constancy=GREY, dump=None):
+                 constancy=GREY, dump=None, sor_omega=0.0):
     """Whole coarse-to-fine loop (optical_flow_2d.cpp:142-569) on tight H x W images.
 
     dump: optional callable(tag:str, level:int, plane:np.ndarray[h,w]) called per stage.
@@ -249,7 +267,7 @@ def compute_flow(frame_0, frame_1, levels, scale, outer, inner, alpha, e_smooth,
     H, W = f0.shape
     u = np.zeros((H, W), np.float32)
     v = np.zeros((H, W), np.float32)
-    p = FlowParams(levels, scale, outer, inner, alpha, e_smooth, e_data, median_radius, sigma, constancy)
+    p = FlowParams(levels, scale, outer, inner, alpha, e_smooth, e_data, median_radius, sigma, constancy, sor_omega)
 
     def _cb(tag, level, ptr, w, h, pitch, _user):
         arr = np.ctypeslib.as_array(ptr, shape=(h * pitch,))[: (h - 1) * pitch + w]

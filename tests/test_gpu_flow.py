@@ -213,3 +213,18 @@ def test_graph_replay_matches_eager(flow2d, oracle, ctx):
         assert np.array_equal(planes[2].download(), ou) and np.array_equal(planes[3].download(), ov)
     finally:
         flow.close()
+
+
+@pytest.mark.parametrize("constancy", [0, 1])
+def test_opt_in_sor_pyramid(flow2d, oracle, make_flow, constancy):
+    """The opt-in red-black SOR mode end to end (bag key solver_sor_omega) against its oracle restatement.
+    This mode has no counterpart in the reference (Jacobi), so it is not part of the reference-parity claim."""
+    w, h = 192, 128
+    f0, f1 = oracle.synthetic_pair(w, h, 1.5, -0.75, seed=6, noise=True)
+    flow = make_flow(w, h, constancy)
+    p = flow.params(4, 0.5, 3, 4, 35.0, 0.001, 0.001, 5, 1.5, sor_omega=1.4)
+    u, v, _ = flow.compute_flow(f0, f1, p)
+    ou, ov, _ = oracle.compute_flow(f0, f1, 4, 0.5, 3, 4, 35.0, 0.001, 0.001, 5, 1.5, constancy, sor_omega=1.4)
+    assert np.array_equal(u, ou) and np.array_equal(v, ov)
+    ju, jv, _ = oracle.compute_flow(f0, f1, 4, 0.5, 3, 4, 35.0, 0.001, 0.001, 5, 1.5, constancy)
+    assert not np.array_equal(ou, ju)  # it really is a different relaxation

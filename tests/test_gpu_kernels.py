@@ -169,3 +169,39 @@ def test_solve_level_fused_rejects_long_inner_loops(ctx, flow2d, oracle):
     rdu, rdv = ctx.solve_level(*d, du, dv, phi, ksi, tdu, tdv, w, h, 1.0, 1.0, 3.5, 0.001, 0.001, 1, 7, 0, 0)
     odu, odv, _, _ = oracle.solve_level(f0, f1, u, v, w, h, 1.0, 1.0, 3.5, 0.001, 0.001, 1, 7, 0)
     assert np.array_equal(rdu.download(w, h), odu) and np.array_equal(rdv.download(w, h), odv)
+
+
+# ---- opt-in red-black SOR (no reference counterpart; checked against its own oracle restatement) ---------------
+@pytest.mark.parametrize("constancy", [0, 1])
+@pytest.mark.parametrize("omega", [1.0, 1.5])
+@pytest.mark.parametrize("w,h,cw,ch", SIZES[:4])
+def test_sor_iteration_and_level(ctx, oracle, w, h, cw, ch, omega, constancy):
+    f0, f1, u, v, du, dv = level_fields(oracle, w, h, 31)
+    hx, hy = np.float32(1.25), np.float32(1.1)
+    d = [up(ctx, a, cw, ch, 3.0) for a in (f0, f1, u, v, du, dv)]
+    phi, ksi, tdu, tdv = (ctx.plane(cw, ch) for _ in range(4))
+    ctx.compute_phi_ksi(*d, w, h, hx, hy, 0.001, 0.001, phi, ksi)
+    ophi, oksi = oracle.compute_phi_ksi(f0, f1, u, v, du, dv, w, h, hx, hy, 0.001, 0.001)
+    ctx.sor_iteration(*d, phi, ksi, w, h, hx, hy, 35.0, omega, constancy)
+    odu, odv = oracle.sor_iteration(f0, f1, u, v, du, dv, ophi, oksi, w, h, hx, hy, 35.0, omega, constancy)
+    got = d[4].download()
+    assert np.array_equal(got[:h, :w], odu) and np.array_equal(d[5].download(w, h), odv)
+    assert np.all(got[h:, :] == 3.0) and np.all(got[:, w:] == 3.0)  # in place, level rectangle only
+    # the level loop with SOR iterations: result stays in du / dv
+    rdu, rdv = ctx.solve_level(*d[:4], d[4], d[5], phi, ksi, tdu, tdv, w, h, hx, hy, 3.5, 0.001, 0.001, 2, 3, constancy,
+                               0, sor_omega=omega)
+    assert rdu is d[4]
+    odu, odv = oracle.solve_level_sor(f0, f1, u, v, w, h, hx, hy, 3.5, 0.001, 0.001, 2, 3, omega, constancy)
+    assert np.array_equal(rdu.download(w, h), odu) and np.array_equal(rdv.download(w, h), odv)
+
+
+def test_sor_rejects_bad_omega_and_fused(ctx, flow2d):
+    w, h = 64, 48
+    planes = [ctx.plane(w, h).fill_bytes(0) for _ in range(10)]
+    for omega in (2.0, -0.5):
+        with pytest.raises(flow2d.Flow2DError) as e:
+            ctx.solve_level(*planes, w, h, 1.0, 1.0, 3.5, 0.001, 0.001, 1, 1, 0, 0, sor_omega=omega)
+        assert e.value.status == 1
+    with pytest.raises(flow2d.Flow2DError) as e:  # the fused kernels are Jacobi only
+        ctx.solve_level(*planes, w, h, 1.0, 1.0, 3.5, 0.001, 0.001, 1, 1, 0, 2, sor_omega=1.2)
+    assert e.value.status == 5

@@ -121,3 +121,32 @@ def test_translation_is_recovered(oracle):
     inner = (slice(16, -16), slice(16, -16))
     assert abs(float(np.median(u[inner])) - 1.5) < 0.25
     assert abs(float(np.median(v[inner])) + 0.75) < 0.15
+
+
+def test_sor_converges_to_the_jacobi_fixed_point_faster(oracle):
+    """Property of the opt-in mode: for frozen robust weights, red-black SOR reaches the fixed point of the
+    linear system that the reference's Jacobi sweeps approach, in far fewer iterations."""
+    w, h = 48, 40
+    f0, f1, u, v, _, _ = level_fields(oracle, w, h, 41)
+    z = np.zeros_like(f0)
+    phi, ksi = oracle.compute_phi_ksi(f0, f1, u * 0, v * 0, z, z, w, h, 1.0, 1.0, 0.5, 0.5)
+    u0, v0 = u * 0, v * 0
+
+    def jacobi(n):
+        du, dv = z.copy(), z.copy()
+        for _ in range(n):
+            du, dv = oracle.solve_sweep(f0, f1, u0, v0, du, dv, phi, ksi, w, h, 1.0, 1.0, 3.5)
+        return du, dv
+
+    def sor(n, omega):
+        du, dv = z.copy(), z.copy()
+        for _ in range(n):
+            du, dv = oracle.sor_iteration(f0, f1, u0, v0, du, dv, phi, ksi, w, h, 1.0, 1.0, 3.5, omega)
+        return du, dv
+
+    ref_du, ref_dv = jacobi(4000)
+    err = lambda a: float(np.abs(a[0] - ref_du).max() + np.abs(a[1] - ref_dv).max())
+    assert err(jacobi(8000)) < 1e-4                      # the long Jacobi run has converged
+    assert err(sor(300, 1.7)) < 1e-3                     # SOR gets there in 300 iterations ...
+    assert err(jacobi(300)) > 5 * err(sor(300, 1.7))     # ... where Jacobi is still far away
+    assert err(sor(300, 1.0)) < err(jacobi(300))         # plain red-black Gauss-Seidel also beats Jacobi
