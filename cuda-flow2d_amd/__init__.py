@@ -115,8 +115,6 @@ def hip_lib():
         L.flow2d_timing_count.argtypes = [vp, C.POINTER(sz)]
         L.flow2d_timing_get.argtypes = [vp, sz, C.POINTER(TimingRecord)]
         L.flow2d_timing_reset.argtypes = [vp]
-        for name in dir(L):
-            pass
         _hip = L
     return _hip
 
