@@ -130,6 +130,9 @@ def main():
 
     flow2d = importlib.import_module("cuda-flow2d_amd")
     batch = importlib.import_module("cuda-flow2d_amd.batch")
+    if not (os.path.exists(flow2d.HIP_LIB_PATH) and os.path.exists(flow2d.HOST_LIB_PATH)):
+        if int(os.environ.get("LOCAL_RANK", "0")) == 0:
+            flow2d.build()  # checkout without the in-tree libraries (normally built by __graft_entry__.build())
     rank, local_rank, world = batch.world_info()
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
