@@ -133,6 +133,12 @@ def main():
     if not (os.path.exists(flow2d.HIP_LIB_PATH) and os.path.exists(flow2d.HOST_LIB_PATH)):
         if int(os.environ.get("LOCAL_RANK", "0")) == 0:
             flow2d.build()  # checkout without the in-tree libraries (normally built by __graft_entry__.build())
+        else:
+            for _ in range(600):  # the other ranks wait for rank 0's build
+                if os.path.exists(flow2d.HIP_LIB_PATH) and os.path.exists(flow2d.HOST_LIB_PATH):
+                    break
+                time.sleep(0.5)
+            time.sleep(1.0)
     rank, local_rank, world = batch.world_info()
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
