@@ -122,7 +122,7 @@ def main():
     ap.add_argument("--algorithm", type=int, default=0, help="flow2d_solver_algorithm: 0 auto, 1 per-sweep, 2 fused")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="launch every step eagerly instead of replaying HIP graphs")
-    ap.add_argument("--pipeline", type=int, default=2,
+    ap.add_argument("--pipeline", type=int, default=4,
                     help="independent pairs in flight per GPU when a step holds a single pair: consecutive steps go to "
                          "alternating streams so one pair's launch-bound coarse levels overlap the next pair's fine levels")
     args = ap.parse_args()
