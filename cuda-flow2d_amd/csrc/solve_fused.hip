@@ -46,6 +46,19 @@ struct FusedArgs {
     float hx, hy, alpha, e_smooth, e_data;
 };
 
+// Plane rows are fetched with buffer loads: a 128-bit descriptor per plane in scalar registers, the row offset
+// as the scalar offset, the lane's column as a 32-bit vector offset.  Half the address payload of a global
+// load with per-lane 64-bit addresses, and no vector address arithmetic.
+using rsrc_t = __amdgpu_buffer_rsrc_t;
+__device__ __forceinline__ rsrc_t plane_rsrc(const float* plane, unsigned bytes)
+{
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(plane), 0, bytes, 0x00020000);
+}
+__device__ __forceinline__ float plane_load(rsrc_t r, unsigned col_bytes, unsigned row_bytes)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, col_bytes, row_bytes, 0));
+}
+
 // lane i receives lane i-1 (wave_shr:1) / lane i+1 (wave_shl:1); the end lanes of the wave receive 0
 // (bound_ctrl), which only ever reaches halo columns.  No "old" operand, so the move can fold into the
 // consuming VALU instruction.
@@ -115,11 +128,16 @@ __device__ __forceinline__ void strip_step(Strip<INNER, GRAD>& s, const FusedArg
     s.duvw[s0] = s.n_duv;
     {  // prefetch row r+1 (clamped: rows outside the image are never used by a stored pixel)
         const int rn = min(max(r + 1, 0), h - 1);
-        const size_t o = static_cast<size_t>(rn) * a.pitch + xc;
-        s.n_f0 = a.f0[o];
-        s.n_f1 = a.f1[o];
-        s.n_uv = v2f{a.u[o], a.v[o]};
-        s.n_duv = a.zero_increment ? v2f{0.f, 0.f} : v2f{a.du[o], a.dv[o]};
+        const unsigned row_bytes = static_cast<unsigned>(rn) * static_cast<unsigned>(a.pitch) * 4u;
+        const unsigned col_bytes = static_cast<unsigned>(xc) * 4u;
+        const unsigned plane_bytes = static_cast<unsigned>(h) * static_cast<unsigned>(a.pitch) * 4u;
+        s.n_f0 = plane_load(plane_rsrc(a.f0, plane_bytes), col_bytes, row_bytes);
+        s.n_f1 = plane_load(plane_rsrc(a.f1, plane_bytes), col_bytes, row_bytes);
+        s.n_uv = v2f{plane_load(plane_rsrc(a.u, plane_bytes), col_bytes, row_bytes),
+                     plane_load(plane_rsrc(a.v, plane_bytes), col_bytes, row_bytes)};
+        s.n_duv = a.zero_increment ? v2f{0.f, 0.f}
+                                   : v2f{plane_load(plane_rsrc(a.du, plane_bytes), col_bytes, row_bytes),
+                                         plane_load(plane_rsrc(a.dv, plane_bytes), col_bytes, row_bytes)};
     }
 
     // ---- stage P, row rp = r-1: phi, brightness derivatives, ksi (solve_2d.cu:138-197) -------------------
