@@ -4,9 +4,17 @@
 // sorts the window with a per-thread insertion sort; selection is order-free, so any exact
 // selection network gives the same value (ties only differ in the sign of zero).
 //
-// Here the window lives in registers and goes through a Batcher odd-even merge network whose
-// comparator list is generated at compile time; comparators that cannot influence the median
-// are removed by the compiler's dead-code elimination.  One wave = 64 consecutive pixels of a row.
+// Generic kernel (any r): the window lives in registers and goes through a Batcher odd-even merge network
+// whose comparator list is generated at compile time; comparators that cannot influence the median are
+// removed by the compiler's dead-code elimination.  One wave = 64 consecutive pixels of a row.
+//
+// r = 5 (the reference's default) has a streaming kernel: a wave owns 64 columns and walks down the image.
+// Per image row it loads ONE value per lane, takes the four horizontal neighbours from the adjacent lanes
+// (DPP), sorts the 5-tuple (9 comparators) and keeps the sorted tuples of six consecutive rows in
+// registers.  Two vertically adjacent medians share four of their five rows, so each step merges those four
+// sorted tuples once and finishes both medians from there (median5_pair_network.inc, 81 comparators for two
+// pixels, generated and exhaustively verified by tools/gen_median_network.py).  Per pixel: 1 load instead
+// of 25 and about 50 comparators instead of 104.
 #include <array>
 #include <utility>
 
@@ -98,6 +106,176 @@ __global__ __launch_bounds__(256) void median_kernel(const float* __restrict__ i
     out[static_cast<size_t>(y) * pitch + x] = v[N / 2];
 }
 
+// ---- r = 5, streaming -----------------------------------------------------------------------------------------
+struct MedianPairOp {
+    int copy, a, b;
+};
+#include "median5_pair_network.inc"
+
+template <size_t... I>
+__device__ __forceinline__ void run_pair_program(float (&v)[kMedianPairWires], std::index_sequence<I...>)
+{
+    (
+        [&] {
+            constexpr MedianPairOp op = kMedianPairProgram[I];
+            if constexpr (op.copy) {
+                v[op.b] = v[op.a];
+            } else {
+                const float lo = fminf(v[op.a], v[op.b]);
+                const float hi = fmaxf(v[op.a], v[op.b]);
+                v[op.a] = lo;
+                v[op.b] = hi;
+            }
+        }(),
+        ...);
+}
+
+__device__ __forceinline__ void sort5(float (&t)[5])
+{
+    auto cx = [&](int a, int b) {
+        const float lo = fminf(t[a], t[b]), hi = fmaxf(t[a], t[b]);
+        t[a] = lo;
+        t[b] = hi;
+    };
+    cx(0, 1); cx(3, 4); cx(2, 4); cx(2, 3); cx(0, 3); cx(0, 2); cx(1, 4); cx(1, 3); cx(1, 2);
+}
+
+__device__ __forceinline__ float lane_left(float v)  // lane i <- lane i-1
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x138, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float lane_right(float v)  // lane i <- lane i+1
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x130, 0xf, 0xf, true));
+}
+
+constexpr int kStreamValid = 60;  // lanes 2..61 of a wave have both neighbours on either side
+
+// the values a lane loads for one image row: its own column, or (EDGE) the five mirrored columns
+template <bool EDGE>
+struct RowLoad {
+    float v[EDGE ? 5 : 1];
+};
+
+template <bool EDGE>
+__device__ __forceinline__ RowLoad<EDGE> load_row(const float* __restrict__ in, int row, int h, int pitch, int xc,
+                                                  const int (&xm)[5])
+{
+    const float* line = in + static_cast<size_t>(min(max(mirror_index(row, h), 0), h - 1)) * pitch;
+    RowLoad<EDGE> r;
+    if (EDGE) {
+#pragma unroll
+        for (int i = 0; i < 5; ++i) r.v[i] = line[xm[i]];
+    } else {
+        r.v[0] = line[xc];
+    }
+    return r;
+}
+
+// sorted 5-tuple (x-2 .. x+2) of the loaded row
+template <bool EDGE>
+__device__ __forceinline__ void sorted_tuple(const RowLoad<EDGE>& r, float (&t)[5])
+{
+    if (EDGE) {
+#pragma unroll
+        for (int i = 0; i < 5; ++i) t[i] = r.v[i];
+    } else {
+        const float c = r.v[0];
+        const float l1 = lane_left(c), r1 = lane_right(c);
+        t[0] = lane_left(l1);
+        t[1] = l1;
+        t[2] = c;
+        t[3] = r1;
+        t[4] = lane_right(r1);
+    }
+    sort5(t);
+}
+
+// One wave, one strip of 64 columns, rows [y0, y1).  Step I of three (the ring of six row slots advances by
+// two rows per step, so three steps bring every slot back to its place and all indices are constants).
+template <bool EDGE, int I>
+__device__ __forceinline__ void median5_step(float (&ring)[6][5], RowLoad<EDGE> (&next)[2], const float* __restrict__ in,
+                                             float* __restrict__ out, int ya, int y1, int h, int pitch, int x, int xc,
+                                             const int (&xm)[5], bool lane_stores)
+{
+    // rows ya+2 and ya+3 were requested one step ago; request the two after them before working
+    sorted_tuple<EDGE>(next[0], ring[(2 * I + 4) % 6]);
+    sorted_tuple<EDGE>(next[1], ring[(2 * I + 5) % 6]);
+    next[0] = load_row<EDGE>(in, ya + 4, h, pitch, xc, xm);
+    next[1] = load_row<EDGE>(in, ya + 5, h, pitch, xc, xm);
+    float v[kMedianPairWires];
+#pragma unroll
+    for (int g = 0; g < 6; ++g)
+#pragma unroll
+        for (int e = 0; e < 5; ++e) v[5 * g + e] = ring[(2 * I + g) % 6][e];
+#pragma unroll
+    for (int i = 30; i < kMedianPairWires; ++i) v[i] = 0.f;
+    run_pair_program(v, std::make_index_sequence<kMedianPairOps>{});
+    if (lane_stores) {
+        out[static_cast<size_t>(ya) * pitch + x] = v[kMedianPairOutA];
+        if (ya + 1 < y1) out[static_cast<size_t>(ya + 1) * pitch + x] = v[kMedianPairOutB];
+    }
+}
+
+template <bool EDGE>
+__device__ __forceinline__ void median5_strip(const float* __restrict__ in, float* __restrict__ out, int w, int h, int pitch,
+                                              int x, int y0, int y1, bool lane_stores)
+{
+    const int xc = min(max(x, 0), w - 1);
+    int xm[5];
+#pragma unroll
+    for (int i = 0; i < 5; ++i) xm[i] = min(max(mirror_index(x + i - 2, w), 0), w - 1);
+    float ring[6][5];
+    // rows y0-2 .. y0+1 fill slots 0..3; rows y0+2, y0+3 are the first pair in flight
+    {
+        RowLoad<EDGE> first[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) first[g] = load_row<EDGE>(in, y0 - 2 + g, h, pitch, xc, xm);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) sorted_tuple<EDGE>(first[g], ring[g]);
+#pragma unroll
+        for (int e = 0; e < 5; ++e) ring[4][e] = ring[5][e] = 0.f;
+    }
+    RowLoad<EDGE> next[2] = {load_row<EDGE>(in, y0 + 2, h, pitch, xc, xm), load_row<EDGE>(in, y0 + 3, h, pitch, xc, xm)};
+    for (int ya = y0; ya < y1; ya += 6) {
+        median5_step<EDGE, 0>(ring, next, in, out, ya, y1, h, pitch, x, xc, xm, lane_stores);
+        if (ya + 2 >= y1) break;
+        median5_step<EDGE, 1>(ring, next, in, out, ya + 2, y1, h, pitch, x, xc, xm, lane_stores);
+        if (ya + 4 >= y1) break;
+        median5_step<EDGE, 2>(ring, next, in, out, ya + 4, y1, h, pitch, x, xc, xm, lane_stores);
+    }
+}
+
+__global__ __launch_bounds__(256) void median5_stream_kernel(const float* __restrict__ in, int w, int h, int pitch,
+                                                             int rows_per_strip, float* __restrict__ out)
+{
+    const int lane = threadIdx.x & 63;
+    const int strip = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int x_first = strip * kStreamValid - 2;
+    if (strip * kStreamValid >= w) return;
+    const int x = x_first + lane;
+    const int y0 = blockIdx.y * rows_per_strip;
+    const int y1 = min(y0 + rows_per_strip, h);
+    const bool lane_stores = lane >= 2 && lane < 62 && x < w;
+    // a wave whose 64 columns lie inside the image takes its horizontal neighbours from the adjacent lanes;
+    // at the left and right image border the mirrored columns are loaded instead
+    const bool edge = x_first < 0 || x_first + 63 > w - 1;
+    if (__builtin_amdgcn_readfirstlane(edge))
+        median5_strip<true>(in, out, w, h, pitch, x, y0, y1, lane_stores);
+    else
+        median5_strip<false>(in, out, w, h, pitch, x, y0, y1, lane_stores);
+}
+
+// rows per strip: even, tall enough that the four start-up rows are noise, short enough to fill the chip
+int median5_rows_per_strip(const flow2d_context* ctx, size_t w, size_t h)
+{
+    const long strips_x = flow2d::div_up(w, kStreamValid);
+    const long want_waves = (ctx->num_cus > 0 ? ctx->num_cus : 256) * 4 * 4;  // four waves per SIMD
+    long rows = 64;
+    while (rows > 8 && strips_x * (long)flow2d::div_up(h, rows) < want_waves) rows /= 2;
+    return (int)rows;
+}
+
 }  // namespace
 
 extern "C" int flow2d_median_2d(flow2d_context* ctx, const float* input, size_t width, size_t height,
@@ -113,6 +291,13 @@ extern "C" int flow2d_median_2d(flow2d_context* ctx, const float* input, size_t 
     const dim3 grid(flow2d::div_up(width, kBlockX), flow2d::div_up(height, kBlockY));
     const dim3 block(kBlockX, kBlockY);
     const int w = (int)width, h = (int)height, pitch = (int)(pitch_bytes / 4);
+    if (window == 5 && width >= 8 && height >= 8) {  // mirrored rows/columns up to 3 beyond the border stay inside
+        const int rows = median5_rows_per_strip(ctx, width, height);
+        const dim3 sgrid(flow2d::div_up(flow2d::div_up(width, kStreamValid), 4), flow2d::div_up(height, rows));
+        median5_stream_kernel<<<sgrid, 256, 0, ctx->stream>>>(input, w, h, pitch, rows, output);
+        FLOW2D_CHECK_LAUNCH();
+        return FLOW2D_OK;
+    }
     switch (window) {
         case 3: median_kernel<3><<<grid, block, 0, ctx->stream>>>(input, w, h, pitch, output); break;
         case 5: median_kernel<5><<<grid, block, 0, ctx->stream>>>(input, w, h, pitch, output); break;

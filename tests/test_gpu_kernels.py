@@ -99,6 +99,18 @@ def test_median(ctx, oracle, w, h, cw, ch, window):
     assert np.array_equal(dst.download(w, h), oracle.median(u, w, h, window))
 
 
+@pytest.mark.parametrize("w,h,cw,ch", [(700, 133, 704, 140), (1000, 300, 1024, 300), (61, 200, 64, 200), (8, 8, 8, 8)])
+def test_median5_streaming_strips(ctx, oracle, w, h, cw, ch):
+    """Window 5 runs the streaming kernel: interior strips (lane neighbours), border strips (mirrored loads),
+    odd heights, strip heights from 8 to 64 rows."""
+    _, _, u, *_ = level_fields(oracle, w, h, 16)
+    u[::7, ::3] = 0.0
+    u[1::5, :] = np.round(u[1::5, :] * 4) / 4  # many ties
+    src, dst = up(ctx, u, cw, ch, -5.0), ctx.plane(cw, ch)
+    ctx.median(src, w, h, 5, dst)
+    assert np.array_equal(dst.download(w, h), oracle.median(u, w, h, 5))
+
+
 def test_median_rejects_bad_window(ctx, flow2d, oracle):
     src, dst = ctx.plane(32, 32), ctx.plane(32, 32)
     for bad in (0, 1, 2, 4, 9):
