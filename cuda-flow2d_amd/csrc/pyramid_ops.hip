@@ -6,6 +6,7 @@
 // every global access of a wave is one contiguous 256-byte row segment; blocks are 64x4.
 // All arithmetic follows the reference's operation order (no FMA contraction) -- see each kernel.
 #include <cmath>
+#include <utility>
 
 #include "common.hpp"
 
@@ -104,6 +105,117 @@ __global__ __launch_bounds__(256) void gauss_fused_kernel(float* __restrict__ ds
         for (int j = -radius; j <= radius; ++j) sum += taps.t[radius - j] * rows[i + radius + j][tx];
         dst[static_cast<size_t>(y) * pitch + x] = sum;
     }
+}
+
+// Streaming form of the same two passes for small radii (R <= kBlurStreamMaxRadius, i.e. sigma < 2.4): a wave
+// owns 64 columns and walks down the image.  Per image row every lane loads ONE value, fetches the R values
+// on either side from the adjacent lanes (chained DPP shifts; the shift-in value 0 is exactly the reference's
+// zero padding at the image border, and columns right of the image are loaded as 0), forms the rows-pass sum
+// and keeps the sums of the last 2R+1 rows in registers; the columns pass of output row y runs as soon as row
+// y+R has gone through the rows pass.  Same taps, same accumulation order (j = -R..R, sum += tap * value,
+// fp32, no FMA): bit-identical to the two launches, one load and one store per pixel.
+constexpr int kBlurStreamMaxRadius = 6;
+
+__device__ __forceinline__ float blur_lane_left(float v)  // lane i <- lane i-1, 0 into lane 0
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x138, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float blur_lane_right(float v)  // lane i <- lane i+1, 0 into lane 63
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x130, 0xf, 0xf, true));
+}
+
+// rows pass of one image row at this lane's column, from the lane's own value c
+template <int R>
+__device__ __forceinline__ float blur_row_sum(float c, const GaussTaps& taps)
+{
+    float left[R + 1], right[R + 1];
+    left[0] = right[0] = c;
+#pragma unroll
+    for (int k = 1; k <= R; ++k) {
+        left[k] = blur_lane_left(left[k - 1]);
+        right[k] = blur_lane_right(right[k - 1]);
+    }
+    float sum = 0.f;
+#pragma unroll
+    for (int j = -R; j <= R; ++j) sum += taps.t[R - j] * (j < 0 ? left[-j] : right[j]);
+    return sum;
+}
+
+// Step J of 2R+1: image row `ry` enters ring slot J, output row ry - R leaves.
+template <int R, int J>
+__device__ __forceinline__ void blur_step(float (&ring)[2 * R + 1], float& next, float* __restrict__ dst,
+                                          const float* __restrict__ src, int ry, int y0, int y1, int h, int pitch,
+                                          int xc, bool in_image, bool lane_stores, const GaussTaps& taps)
+{
+    constexpr int N = 2 * R + 1;
+    const float c = next;  // row ry, requested one step ago
+    {
+        const int rn = ry + 1;
+        const float v = src[static_cast<size_t>(min(max(rn, 0), h - 1)) * pitch + xc];
+        next = (in_image && rn >= 0 && rn < h) ? v : 0.f;
+    }
+    ring[J] = blur_row_sum<R>(c, taps);
+    const int yo = ry - R;
+    if (yo >= y0 && yo < y1) {  // wave-uniform
+        float sum = 0.f;
+#pragma unroll
+        for (int j = -R; j <= R; ++j) sum += taps.t[R - j] * ring[(J + N - R + j) % N];  // row yo + j
+        if (lane_stores) dst[static_cast<size_t>(yo) * pitch + xc] = sum;
+    }
+}
+
+template <int R, size_t... Js>
+__device__ __forceinline__ void blur_steps(float (&ring)[2 * R + 1], float& next, float* __restrict__ dst,
+                                           const float* __restrict__ src, int ry, int y0, int y1, int h, int pitch,
+                                           int xc, bool in_image, bool lane_stores, const GaussTaps& taps,
+                                           std::index_sequence<Js...>)
+{
+    (blur_step<R, static_cast<int>(Js)>(ring, next, dst, src, ry + static_cast<int>(Js), y0, y1, h, pitch, xc, in_image,
+                                        lane_stores, taps),
+     ...);
+}
+
+template <int R>
+__global__ __launch_bounds__(256) void gauss_stream_kernel(float* __restrict__ dst, const float* __restrict__ src, int w,
+                                                           int h, int pitch, int rows_per_strip, GaussTaps taps)
+{
+    constexpr int N = 2 * R + 1, kValid = 64 - 2 * R;
+    const int lane = threadIdx.x & 63;
+    const int strip = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (strip * kValid >= w) return;
+    const int x = strip * kValid - R + lane;
+    const int xc = min(max(x, 0), w - 1);
+    const bool in_image = x >= 0 && x < w;
+    const bool lane_stores = lane >= R && lane < 64 - R && x < w;
+    const int y0 = blockIdx.y * rows_per_strip;
+    const int y1 = min(y0 + rows_per_strip, h);
+    float ring[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) ring[i] = 0.f;
+    // rows y0-R .. y1-1+R go through the rows pass (rows outside the image are zero rows)
+    const int r_first = y0 - R, r_last = y1 - 1 + R;
+    float next;
+    {
+        const float v = src[static_cast<size_t>(min(max(r_first, 0), h - 1)) * pitch + xc];
+        next = (in_image && r_first >= 0 && r_first < h) ? v : 0.f;
+    }
+    for (int ry = r_first; ry <= r_last; ry += N)
+        blur_steps<R>(ring, next, dst, src, ry, y0, y1, h, pitch, xc, in_image, lane_stores, taps,
+                      std::make_index_sequence<N>{});
+}
+
+template <int R>
+void launch_gauss_stream(flow2d_context* ctx, float* dst, const float* src, size_t width, size_t height,
+                         size_t pitch_bytes, const GaussTaps& t)
+{
+    const long strips = flow2d::div_up(width, 64 - 2 * R);
+    const long want_waves = (ctx->num_cus > 0 ? ctx->num_cus : 256) * 4 * 4;  // four waves per SIMD
+    long rows = 128;
+    while (rows > 16 && strips * (long)flow2d::div_up(height, rows) < want_waves) rows /= 2;
+    const dim3 grid(flow2d::div_up(strips, 4), flow2d::div_up(height, rows));
+    gauss_stream_kernel<R><<<grid, 256, 0, ctx->stream>>>(dst, src, (int)width, (int)height, (int)(pitch_bytes / 4),
+                                                          (int)rows, t);
 }
 
 // ---- area-weighted resampling: src/kernels/resample_2d.cu:34-75 (x), :77-118 (y) ----------------
@@ -307,9 +419,20 @@ int flow2d_gaussian_blur(flow2d_context* ctx, float* dst, const float* src, size
     if (radius < 0 || radius > kBlurMaxRadius) return FLOW2D_ERR_UNSUPPORTED;
     GaussTaps t;
     for (int i = 0; i < 51; ++i) t.t[i] = i < 2 * radius + 1 ? taps[i] : 0.f;
-    const dim3 grid(flow2d::div_up(width, kBlockX), flow2d::div_up(height, kBlurTile));
-    gauss_fused_kernel<<<grid, dim3(kBlockX, kBlockY), 0, ctx->stream>>>(dst, src, (int)width, (int)height,
-                                                                        (int)(pitch_bytes / 4), radius, t);
+    static_assert(kBlurStreamMaxRadius == 6, "one case per streamed radius");
+    switch (radius) {
+        case 1: launch_gauss_stream<1>(ctx, dst, src, width, height, pitch_bytes, t); break;
+        case 2: launch_gauss_stream<2>(ctx, dst, src, width, height, pitch_bytes, t); break;
+        case 3: launch_gauss_stream<3>(ctx, dst, src, width, height, pitch_bytes, t); break;
+        case 4: launch_gauss_stream<4>(ctx, dst, src, width, height, pitch_bytes, t); break;
+        case 5: launch_gauss_stream<5>(ctx, dst, src, width, height, pitch_bytes, t); break;
+        case 6: launch_gauss_stream<6>(ctx, dst, src, width, height, pitch_bytes, t); break;
+        default: {
+            const dim3 grid(flow2d::div_up(width, kBlockX), flow2d::div_up(height, kBlurTile));
+            gauss_fused_kernel<<<grid, dim3(kBlockX, kBlockY), 0, ctx->stream>>>(dst, src, (int)width, (int)height,
+                                                                                (int)(pitch_bytes / 4), radius, t);
+        }
+    }
     FLOW2D_CHECK_LAUNCH();
     return FLOW2D_OK;
 }

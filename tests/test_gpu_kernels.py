@@ -29,7 +29,7 @@ def test_add(ctx, oracle, w, h, cw, ch):
     assert np.all(got[h:, :] == 7.0) and np.all(got[:, w:] == 7.0)
 
 
-@pytest.mark.parametrize("sigma", [0.45, 1.5, 3.0, 8.3])
+@pytest.mark.parametrize("sigma", [0.45, 0.7, 1.0, 1.5, 1.9, 2.2, 3.0, 8.3])  # radii 1..6 stream, larger ones tile
 @pytest.mark.parametrize("w,h,cw,ch", SIZES)
 def test_gaussian(ctx, flow2d, oracle, w, h, cw, ch, sigma):
     f0, *_ = level_fields(oracle, w, h, 2)
@@ -44,6 +44,17 @@ def test_gaussian(ctx, flow2d, oracle, w, h, cw, ch, sigma):
     fused = ctx.plane(cw, ch).fill_bytes(0x7f)  # both passes in one launch
     ctx.gaussian_blur(fused, src, w, h, taps, r)
     assert np.array_equal(fused.download(w, h), want)
+
+
+@pytest.mark.parametrize("sigma", [0.45, 1.5, 2.2])
+@pytest.mark.parametrize("w,h,cw,ch", [(700, 133, 704, 140), (1000, 300, 1024, 300), (57, 200, 64, 200)])
+def test_gaussian_streaming_strips(ctx, flow2d, oracle, w, h, cw, ch, sigma):
+    """Several column strips and row strips of the one-launch blur; container larger than the level."""
+    f0, *_ = level_fields(oracle, w, h, 12)
+    taps, r = flow2d.gaussian_kernel(sigma)
+    src, dst = up(ctx, f0, cw, ch, 5.0), ctx.plane(cw, ch).fill_bytes(0x7f)
+    ctx.gaussian_blur(dst, src, w, h, taps, r)
+    assert np.array_equal(dst.download(w, h), oracle.convolution(f0, w, h, sigma))
 
 
 @pytest.mark.parametrize("w,h,ow,oh", [(100, 70, 80, 64), (100, 70, 37, 20), (100, 70, 13, 9), (100, 70, 5, 4),
