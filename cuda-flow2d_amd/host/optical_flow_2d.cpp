@@ -267,14 +267,24 @@ bool OpticalFlow2D::QueuePair(DevicePtr dev_frame_0, DevicePtr dev_frame_1, Devi
     dev_frame_1_ = Acquire();
     dev_flow_u_ = Acquire();
     dev_flow_v_ = Acquire();
-    // the pyramid consumes its frame planes (blur and level-0 swaps), so work on copies
-    bool ok = !CheckFlow2DError(flow2d_copy_d2d(context_, AsPlane(dev_frame_0_), AsPlane(dev_frame_0), bytes), "copy") &&
-              !CheckFlow2DError(flow2d_copy_d2d(context_, AsPlane(dev_frame_1_), AsPlane(dev_frame_1), bytes), "copy");
-    ok = ok && RunPyramid(params);
-    if (ok) {
-        ok = !CheckFlow2DError(flow2d_copy_d2d(context_, AsPlane(dev_flow_u), AsPlane(dev_flow_u_), bytes), "copy") &&
-             !CheckFlow2DError(flow2d_copy_d2d(context_, AsPlane(dev_flow_v), AsPlane(dev_flow_v_), bytes), "copy");
+    // The pyramid consumes its frame planes (level-0 swaps), so without a pre-blur it works on copies; with one
+    // the blur is the only reader of the frames and reads the caller's planes in place.  The flow of the last
+    // level leaves through its median, which writes the caller's planes directly.
+    float gaussian_sigma = 0.f;
+    params.Read<float>("gaussian_sigma", gaussian_sigma);
+    const bool frames_in_place = gaussian_sigma > 0.f;
+    bool ok = true;
+    if (frames_in_place) {
+        caller_frame_0_ = dev_frame_0;
+        caller_frame_1_ = dev_frame_1;
+    } else {
+        ok = !CheckFlow2DError(flow2d_copy_d2d(context_, AsPlane(dev_frame_0_), AsPlane(dev_frame_0), bytes), "copy") &&
+             !CheckFlow2DError(flow2d_copy_d2d(context_, AsPlane(dev_frame_1_), AsPlane(dev_frame_1), bytes), "copy");
     }
+    caller_flow_u_ = dev_flow_u;
+    caller_flow_v_ = dev_flow_v;
+    ok = ok && RunPyramid(params);
+    caller_frame_0_ = caller_frame_1_ = caller_flow_u_ = caller_flow_v_ = 0;
     Release(dev_frame_0_);
     Release(dev_frame_1_);
     Release(dev_flow_u_);
@@ -342,7 +352,21 @@ bool OpticalFlow2D::RunPyramid(OperationParameters& params)
     DevicePtr frame_0_res = Acquire(), frame_1_res = Acquire(), flow_du = Acquire(), flow_dv = Acquire();
     OperationParameters op;
 
-    if (gaussian_sigma > 0.0) {  // optical_flow_2d.cpp:218-246: blur into the flow planes, then swap roles
+    if (gaussian_sigma > 0.0 && caller_frame_0_) {  // frames still in the caller's planes: blur them into ours
+        DevicePtr temp = Acquire();
+        DevicePtr sources[2] = {caller_frame_0_, caller_frame_1_};
+        DevicePtr* targets[2] = {&frame_0, &frame_1};
+        for (int i = 0; i < 2; ++i) {
+            op.Clear();
+            op.PushValuePtr("dev_input", &sources[i]);
+            op.PushValuePtr("dev_output", targets[i]);
+            op.PushValuePtr("dev_temp", &temp);
+            op.PushValuePtr("data_size", &original_size);
+            op.PushValuePtr("gaussian_sigma", &gaussian_sigma);
+            cuop_convolution_.Execute(op);
+        }
+        Release(temp);
+    } else if (gaussian_sigma > 0.0) {  // optical_flow_2d.cpp:218-246: blur into the flow planes, then swap roles
         DevicePtr temp = Acquire();
         DevicePtr* io[2][2] = {{&frame_0, &flow_u}, {&frame_1, &flow_v}};
         for (auto& pair : io) {
@@ -470,14 +494,17 @@ bool OpticalFlow2D::RunPyramid(OperationParameters& params)
         {  // median of u and v after every level, the finest included
             DevicePtr temp = Acquire();
             DevicePtr* fields[2] = {&flow_u, &flow_v};
-            for (DevicePtr* field : fields) {
+            DevicePtr caller_out[2] = {caller_flow_u_, caller_flow_v_};
+            for (int i = 0; i < 2; ++i) {
+                // the last median of a ComputeFlowDevice run delivers the result into the caller's plane
+                const bool deliver = level == 0 && caller_out[i] != 0;
                 op.Clear();
-                op.PushValuePtr("dev_input", field);
-                op.PushValuePtr("dev_output", &temp);
+                op.PushValuePtr("dev_input", fields[i]);
+                op.PushValuePtr("dev_output", deliver ? &caller_out[i] : &temp);
                 op.PushValuePtr("data_size", &current_size);
                 op.PushValuePtr("radius", &median_radius);
                 cuop_median_.Execute(op);
-                std::swap(*field, temp);
+                if (!deliver) std::swap(*fields[i], temp);
             }
             Release(temp);
         }

@@ -105,6 +105,9 @@ private:
     std::vector<DevicePtr> all_planes_;
     std::vector<DevicePtr> free_planes_;
     DevicePtr dev_frame_0_ = 0, dev_frame_1_ = 0, dev_flow_u_ = 0, dev_flow_v_ = 0;  // valid inside a run
+    // ComputeFlowDevice only: the caller's planes.  With a pre-blur the frames are read once (by the blur), so
+    // they are read in place instead of copied; the last level's median writes the caller's flow planes.
+    DevicePtr caller_frame_0_ = 0, caller_frame_1_ = 0, caller_flow_u_ = 0, caller_flow_v_ = 0;
     flow2d_context* context_ = nullptr;
     float last_total_ms_ = 0.f;
     // recorded pyramids, keyed by the caller buffers and parameters they were recorded for
