@@ -90,6 +90,14 @@ def cpu_baseline(cfg, budget_s=20.0):
                                     0.001, 0.001, cfg["median"], cfg["sigma"], cfg["constancy"])
     t = time.perf_counter() - t0
     px_iters = side * side * cfg["outer"] * cfg["inner"]
+    # the same code on ONE thread (SURVEY 8d asks for both), on the small calibration crop
+    O.set_threads(1)
+    f0s, f1s = synthetic_pair(probe, probe, cfg["dx"], cfg["dy"])
+    t0 = time.perf_counter()
+    O.compute_flow(f0s, f1s, cfg["levels"], cfg["scale"], cfg["outer"], cfg["inner"], cfg["alpha"], 0.001, 0.001,
+                   cfg["median"], cfg["sigma"], cfg["constancy"])
+    t_single = time.perf_counter() - t0
+    O.set_threads(threads)
     return {
         "value": round(px_iters / t / 1e6, 2),
         "unit": "Mpixel*iters/s",
@@ -98,6 +106,8 @@ def cpu_baseline(cfg, budget_s=20.0):
         "sample": "%dx%d crop of the workload's synthetic pair, same levels/outer/inner/constancy, one full "
                   "pyramid, %.2f s wall on %d OpenMP threads" % (side, side, t, threads),
         "finest_level_solve_mpix_iters_per_s": round(px_iters / t_finest / 1e6, 2) if t_finest > 0 else None,
+        "single_thread": {"value": round(probe * probe * cfg["outer"] * cfg["inner"] / t_single / 1e6, 2),
+                          "sample": "%dx%d crop, %.2f s wall on 1 thread" % (probe, probe, t_single)},
     }
 
 
