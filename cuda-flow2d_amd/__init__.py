@@ -20,7 +20,9 @@ HIP_LIB_PATH = os.path.join(_HERE, "csrc", "libflow2d_hip.so")
 HOST_LIB_PATH = os.path.join(_HERE, "host", "libflow2d_host.so")
 CLI_PATH = os.path.join(_HERE, "host", "flow2d")
 
-GREY, GRADIENT = 0, 1
+GREY, GRADIENT, GRADIENT_UNTILED = 0, 1, 2  # flow2d_constancy; 2 = true-neighbour gradient term (not in the reference)
+HOST_LOG_DERIVATIVES = "LogDerivatives"  # the reference's third DataConstancy; the host layer refuses it
+_HOST_CONSTANCY = {GREY: 0, GRADIENT: 1, GRADIENT_UNTILED: 3, HOST_LOG_DERIVATIVES: 2}  # enum class DataConstancy
 SOLVER_AUTO, SOLVER_PER_SWEEP, SOLVER_FUSED, SOLVER_SINGLE_WORKGROUP = 0, 1, 2, 3
 
 STATUS = {0: "ok", 1: "invalid argument", 2: "no usable HIP device", 3: "HIP runtime error",
@@ -108,6 +110,7 @@ def hip_lib():
         L.flow2d_compute_phi_ksi.argtypes = [vp] * 7 + [sz, sz, sz, f, f, f, f, vp, vp]
         L.flow2d_solve_2d.argtypes = [vp] * 9 + [sz, sz, sz, f, f, f, vp, vp]
         L.flow2d_solve_2d_grad.argtypes = [vp] * 9 + [sz, sz, sz, f, f, f, vp, vp]
+        L.flow2d_solve_2d_grad_untiled.argtypes = [vp] * 9 + [sz, sz, sz, f, f, f, vp, vp]
         L.flow2d_solve_2d_sor.argtypes = [vp] * 9 + [sz, sz, sz, f, f, f, f, i]
         L.flow2d_solve_level.argtypes = [vp] * 11 + [C.POINTER(SolveParams), C.POINTER(i)]
         L.flow2d_timing_enable.argtypes = [vp, i]
@@ -283,7 +286,8 @@ class Context:
                "flow2d_compute_phi_ksi")
 
     def solve_sweep(self, f0, f1, u, v, du, dv, phi, ksi, w, h, hx, hy, alpha, tdu, tdv, constancy=GREY):
-        fn = hip_lib().flow2d_solve_2d_grad if constancy == GRADIENT else hip_lib().flow2d_solve_2d
+        fn = {GREY: hip_lib().flow2d_solve_2d, GRADIENT: hip_lib().flow2d_solve_2d_grad,
+              GRADIENT_UNTILED: hip_lib().flow2d_solve_2d_grad_untiled}[constancy]
         _check(fn(self.handle, f0.ptr, f1.ptr, u.ptr, v.ptr, du.ptr, dv.ptr, phi.ptr, ksi.ptr, w, h, f0.pitch, hx, hy,
                   alpha, tdu.ptr, tdv.ptr), "flow2d_solve_2d*")
 
@@ -402,7 +406,7 @@ class OpticalFlow:
         elif L.flow2d_host_init_device(device) != 0:
             raise Flow2DError(2, "InitDeviceContext")
         self.width, self.height = width, height
-        self.handle = L.flow2d_host_flow_create(width, height, constancy, int(silent))
+        self.handle = L.flow2d_host_flow_create(width, height, _HOST_CONSTANCY[constancy], int(silent))
         if not self.handle:
             if self._adopted:
                 L.flow2d_host_adopt_context(None)

@@ -183,6 +183,62 @@ __global__ __launch_bounds__(512) void sweep_grad_kernel(const float* __restrict
     jacobi_update(u, v, du, dv, phi, ksi, n, x, y, w, h, hx, hy, alpha, J11, J22, J12, J13, J23, tdu, tdv);
 }
 
+// ---- gradient constancy with true neighbours (FLOW2D_CONSTANCY_GRADIENT_UNTILED; not a reference kernel) ------
+// Same motion tensor as solve_2d_grad, but the second derivatives are central differences of fx, fy, ft over the
+// real neighbours x+-1, y+-1 (reflected at the image border like every other neighbour of the solver) instead of
+// being cut at the reference's 16x8 launch tiles.  This per-sweep form simply evaluates fx, fy, ft at the four
+// neighbours (all L1/L2 hits); the fused and single-workgroup kernels keep them in registers / LDS.
+__device__ __forceinline__ void untiled_gradient_tensor(const float* __restrict__ f0, const float* __restrict__ f1, int x,
+                                                        int y, int w, int h, int pitch, float hx, float hy, float& J11,
+                                                        float& J22, float& J12, float& J13, float& J23)
+{
+    const int xa = mirror_index(x - 1, w), xb = mirror_index(x + 1, w);
+    const int ya = mirror_index(y - 1, h), yb = mirror_index(y + 1, h);
+    float fx_a, fy_a, ft_a, fx_b, fy_b, ft_b, fx_u, fy_u, ft_u, fx_d, fy_d, ft_d;
+    image_derivatives(f0, f1, neighbourhood(xa, y, w, h, pitch), hx, hy, fx_a, fy_a, ft_a);
+    image_derivatives(f0, f1, neighbourhood(xb, y, w, h, pitch), hx, hy, fx_b, fy_b, ft_b);
+    image_derivatives(f0, f1, neighbourhood(x, ya, w, h, pitch), hx, hy, fx_u, fy_u, ft_u);
+    image_derivatives(f0, f1, neighbourhood(x, yb, w, h, pitch), hx, hy, fx_d, fy_d, ft_d);
+    const float hx_1 = 1.0 / (2.0 * hx);  // double, rounded to float, as in solve_2d.cu:868-869
+    const float hy_1 = 1.0 / (2.0 * hy);
+    const float fxx = (fx_b - fx_a) * hx_1;
+    const float fxy = (fx_d - fx_u) * hy_1;
+    const float fyy = (fy_d - fy_u) * hy_1;
+    const float fxt = (ft_b - ft_a) * hx_1;
+    const float fyt = (ft_d - ft_u) * hy_1;
+    flow2d_math::gradient_tensor(fxx, fxy, fyy, fxt, fyt, J11, J22, J12, J13, J23);
+}
+
+__global__ __launch_bounds__(256) void sweep_grad_untiled_kernel(
+    const float* __restrict__ f0, const float* __restrict__ f1, const float* __restrict__ u, const float* __restrict__ v,
+    const float* __restrict__ du, const float* __restrict__ dv, const float* __restrict__ phi,
+    const float* __restrict__ ksi, int w, int h, int pitch, float hx, float hy, float alpha, float* __restrict__ tdu,
+    float* __restrict__ tdv)
+{
+    const int x = blockIdx.x * kBlockX + threadIdx.x;
+    const int y = blockIdx.y * kBlockY + threadIdx.y;
+    if (x >= w || y >= h) return;
+    float J11, J22, J12, J13, J23;
+    untiled_gradient_tensor(f0, f1, x, y, w, h, pitch, hx, hy, J11, J22, J12, J13, J23);
+    jacobi_update(u, v, du, dv, phi, ksi, neighbourhood(x, y, w, h, pitch), x, y, w, h, hx, hy, alpha, J11, J22, J12,
+                  J13, J23, tdu, tdv);
+}
+
+__global__ __launch_bounds__(256) void sor_grad_untiled_kernel(const float* __restrict__ f0, const float* __restrict__ f1,
+                                                               const float* __restrict__ u, const float* __restrict__ v,
+                                                               float* du, float* dv, const float* __restrict__ phi,
+                                                               const float* __restrict__ ksi, int w, int h, int pitch,
+                                                               float hx, float hy, float alpha, float omega, int colour)
+{
+    const int x = blockIdx.x * kBlockX + threadIdx.x;
+    const int y = blockIdx.y * kBlockY + threadIdx.y;
+    if (x >= w || y >= h || ((x + y) & 1) != colour) return;
+    float J11, J22, J12, J13, J23;
+    untiled_gradient_tensor(f0, f1, x, y, w, h, pitch, hx, hy, J11, J22, J12, J13, J23);
+    jacobi_update<true>(u, v, du, dv, phi, ksi, neighbourhood(x, y, w, h, pitch), x, y, w, h, hx, hy, alpha, J11, J22,
+                        J12, J13, J23, du, dv, omega);
+}
+
 // ---- opt-in red-black SOR half-sweeps (no counterpart in the reference; BASELINE.json names the scheme) ---
 // One launch relaxes the pixels with (x + y) % 2 == colour in place.  A full iteration = colour 0 then colour 1.
 __global__ __launch_bounds__(256) void sor_grey_kernel(const float* __restrict__ f0, const float* __restrict__ f1,
@@ -268,6 +324,10 @@ int launch_sweep(flow2d_context* ctx, int constancy, const float* f0, const floa
         const dim3 grid(div_up(w, kBlockX), div_up(h, kGradTileY));
         sweep_grad_kernel<<<grid, dim3(kBlockX, kGradTileY), 0, ctx->stream>>>(
             f0, f1, u, v, du, dv, phi, ksi, (int)w, (int)h, (int)(pitch_bytes / 4), hx, hy, alpha, tdu, tdv);
+    } else if (constancy == FLOW2D_CONSTANCY_GRADIENT_UNTILED) {
+        const dim3 grid(div_up(w, kBlockX), div_up(h, kBlockY));
+        sweep_grad_untiled_kernel<<<grid, dim3(kBlockX, kBlockY), 0, ctx->stream>>>(
+            f0, f1, u, v, du, dv, phi, ksi, (int)w, (int)h, (int)(pitch_bytes / 4), hx, hy, alpha, tdu, tdv);
     } else {
         const dim3 grid(div_up(w, kBlockX), div_up(h, kBlockY));
         sweep_grey_kernel<<<grid, dim3(kBlockX, kBlockY), 0, ctx->stream>>>(
@@ -286,6 +346,10 @@ int launch_sor_iteration(flow2d_context* ctx, int constancy, const float* f0, co
         if (constancy == FLOW2D_CONSTANCY_GRADIENT) {
             const dim3 grid(div_up(w, kBlockX), div_up(h, kGradTileY));
             sor_grad_kernel<<<grid, dim3(kBlockX, kGradTileY), 0, ctx->stream>>>(
+                f0, f1, u, v, du, dv, phi, ksi, (int)w, (int)h, (int)(pitch_bytes / 4), hx, hy, alpha, omega, colour);
+        } else if (constancy == FLOW2D_CONSTANCY_GRADIENT_UNTILED) {
+            const dim3 grid(div_up(w, kBlockX), div_up(h, kBlockY));
+            sor_grad_untiled_kernel<<<grid, dim3(kBlockX, kBlockY), 0, ctx->stream>>>(
                 f0, f1, u, v, du, dv, phi, ksi, (int)w, (int)h, (int)(pitch_bytes / 4), hx, hy, alpha, omega, colour);
         } else {
             const dim3 grid(div_up(w, kBlockX), div_up(h, kBlockY));
@@ -344,7 +408,8 @@ int flow2d_solve_2d_sor(flow2d_context* ctx, const float* frame_0, const float* 
         return FLOW2D_ERR_INVALID_ARGUMENT;
     for (int i = 0; i < 8; ++i)
         if (i != 4 && i != 5 && (planes[i] == flow_du || planes[i] == flow_dv)) return FLOW2D_ERR_INVALID_ARGUMENT;
-    if (data_constancy != FLOW2D_CONSTANCY_GREY && data_constancy != FLOW2D_CONSTANCY_GRADIENT)
+    if (data_constancy != FLOW2D_CONSTANCY_GREY && data_constancy != FLOW2D_CONSTANCY_GRADIENT &&
+        data_constancy != FLOW2D_CONSTANCY_GRADIENT_UNTILED)
         return FLOW2D_ERR_UNSUPPORTED;
     return flow2d::launch_sor_iteration(ctx, data_constancy, frame_0, frame_1, flow_u, flow_v, flow_du, flow_dv, phi,
                                         ksi, width, height, pitch_bytes, hx, hy, equation_alpha, omega);
@@ -366,6 +431,15 @@ int flow2d_solve_2d_grad(flow2d_context* ctx, const float* frame_0, const float*
 {
     return sweep_entry(ctx, FLOW2D_CONSTANCY_GRADIENT, frame_0, frame_1, flow_u, flow_v, flow_du, flow_dv, phi, ksi,
                        width, height, pitch_bytes, hx, hy, equation_alpha, temp_du, temp_dv);
+}
+
+int flow2d_solve_2d_grad_untiled(flow2d_context* ctx, const float* frame_0, const float* frame_1, const float* flow_u,
+                                 const float* flow_v, const float* flow_du, const float* flow_dv, const float* phi,
+                                 const float* ksi, size_t width, size_t height, size_t pitch_bytes, float hx, float hy,
+                                 float equation_alpha, float* temp_du, float* temp_dv)
+{
+    return sweep_entry(ctx, FLOW2D_CONSTANCY_GRADIENT_UNTILED, frame_0, frame_1, flow_u, flow_v, flow_du, flow_dv, phi,
+                       ksi, width, height, pitch_bytes, hx, hy, equation_alpha, temp_du, temp_dv);
 }
 
 }  // extern "C"

@@ -84,7 +84,9 @@ __device__ __forceinline__ v2f from_left2(v2f v) { return v2f{from_left(v.x), fr
 __device__ __forceinline__ v2f from_right2(v2f v) { return v2f{from_right(v.x), from_right(v.y)}; }
 __device__ __forceinline__ v2f pick2(bool c, v2f a, v2f b) { return v2f{c ? a.x : b.x, c ? a.y : b.y}; }
 
-template <int INNER, bool GRAD>
+// GRAD: 0 brightness constancy, 1 gradient constancy with the reference's 16x8 tile rule, 2 gradient constancy with
+// true neighbours (FLOW2D_CONSTANCY_GRADIENT_UNTILED)
+template <int INNER, int GRAD>
 struct Strip {
     static constexpr int kHalo = INNER + 1;
     static constexpr int kValid = 64 - 2 * kHalo;
@@ -108,7 +110,7 @@ struct Strip {
 // EDGE = false: the strip touches no image border, so the reflect substitutions (a v_cndmask per
 // neighbour fetch) are compiled out; EDGE = true keeps them.  Chosen per wave (wave-uniform branch).
 // POW2: 2h and 4h are powers of two, so dividing by them is an exact multiply by the reciprocal.
-template <int INNER, bool GRAD, bool EDGE, bool POW2, int J>
+template <int INNER, int GRAD, bool EDGE, bool POW2, int J>
 __device__ __forceinline__ void strip_step(Strip<INNER, GRAD>& s, const FusedArgs& a, int r, int x, int xc, bool at_l,
                                            bool at_r, bool lane_stores, int y0, int y1, v2f xpm, float hx_2,
                                            float hy_2)
@@ -208,19 +210,28 @@ __device__ __forceinline__ void strip_step(Strip<INNER, GRAD>& s, const FusedArg
         } else {
             // second derivatives inside the reference's 16x8 blocks, own value replicated at block and
             // image edges (solve_2d.cu:816-841,872-876); fx/fy/ft rings: s1 = row r-1, s2 = r-2, s0 = r-3
-            const int tx = x & 15, ty = rw & 7;
-            const bool x_lo = (tx == 0), x_hi = (tx == 15) || (x == w - 1);
-            const bool y_lo = (ty == 0), y_hi = (ty == 7) || (rw == h - 1);
             const float fxc = s.fxw[s2], fyc = s.fyw[s2], ftc = s.ftw[s2];
             // cross-lane reads first, with every lane active; select afterwards (a DPP read under a
             // divergent branch would see disabled source lanes)
             const float fx_l0 = from_left(fxc), fx_r0 = from_right(fxc);
             const float ft_l0 = from_left(ftc), ft_r0 = from_right(ftc);
-            const float fx_l = x_lo ? fxc : fx_l0, fx_r = x_hi ? fxc : fx_r0;
-            const float ft_l = x_lo ? ftc : ft_l0, ft_r = x_hi ? ftc : ft_r0;
-            const float fx_u = y_lo ? fxc : s.fxw[s0], fx_d = y_hi ? fxc : s.fxw[s1];
-            const float fy_u = y_lo ? fyc : s.fyw[s0], fy_d = y_hi ? fyc : s.fyw[s1];
-            const float ft_u = y_lo ? ftc : s.ftw[s0], ft_d = y_hi ? ftc : s.ftw[s1];
+            float fx_l, fx_r, ft_l, ft_r, fx_u, fx_d, fy_u, fy_d, ft_u, ft_d;
+            if (GRAD == 1) {  // the reference's tile rule: own value at the 16x8 block edge and at the image edge
+                const int tx = x & 15, ty = rw & 7;
+                const bool x_lo = (tx == 0), x_hi = (tx == 15) || (x == w - 1);
+                const bool y_lo = (ty == 0), y_hi = (ty == 7) || (rw == h - 1);
+                fx_l = x_lo ? fxc : fx_l0, fx_r = x_hi ? fxc : fx_r0;
+                ft_l = x_lo ? ftc : ft_l0, ft_r = x_hi ? ftc : ft_r0;
+                fx_u = y_lo ? fxc : s.fxw[s0], fx_d = y_hi ? fxc : s.fxw[s1];
+                fy_u = y_lo ? fyc : s.fyw[s0], fy_d = y_hi ? fyc : s.fyw[s1];
+                ft_u = y_lo ? ftc : s.ftw[s0], ft_d = y_hi ? ftc : s.ftw[s1];
+            } else {  // true neighbours, reflected at the image border like the first derivatives
+                fx_l = at_l ? fx_r0 : fx_l0, fx_r = at_r ? fx_l0 : fx_r0;
+                ft_l = at_l ? ft_r0 : ft_l0, ft_r = at_r ? ft_l0 : ft_r0;
+                fx_u = top ? s.fxw[s1] : s.fxw[s0], fx_d = bot ? s.fxw[s0] : s.fxw[s1];
+                fy_u = top ? s.fyw[s1] : s.fyw[s0], fy_d = bot ? s.fyw[s0] : s.fyw[s1];
+                ft_u = top ? s.ftw[s1] : s.ftw[s0], ft_d = bot ? s.ftw[s0] : s.ftw[s1];
+            }
             const float hx_1 = 1.0 / (2.0 * a.hx);  // double, rounded to float (solve_2d.cu:868-869)
             const float hy_1 = 1.0 / (2.0 * a.hy);
             const float fxx = (fx_r - fx_l) * hx_1;
@@ -271,7 +282,7 @@ __device__ __forceinline__ void strip_step(Strip<INNER, GRAD>& s, const FusedArg
     }
 }
 
-template <int INNER, bool GRAD, bool EDGE, bool POW2, size_t... Js>
+template <int INNER, int GRAD, bool EDGE, bool POW2, size_t... Js>
 __device__ __forceinline__ void strip_steps(Strip<INNER, GRAD>& s, const FusedArgs& a, int r_base, int x, int xc,
                                             bool at_l, bool at_r, bool lane_stores, int y0, int y1, v2f xpm,
                                             float hx_2, float hy_2, std::index_sequence<Js...>)
@@ -281,7 +292,7 @@ __device__ __forceinline__ void strip_steps(Strip<INNER, GRAD>& s, const FusedAr
      ...);
 }
 
-template <int INNER, bool GRAD, bool POW2>
+template <int INNER, int GRAD, bool POW2>
 __global__ __launch_bounds__(256) void fused_outer_kernel(FusedArgs a)
 {
     using S = Strip<INNER, GRAD>;
@@ -341,7 +352,7 @@ __global__ __launch_bounds__(256) void fused_outer_kernel(FusedArgs a)
     }
 }
 
-template <bool GRAD, bool POW2>
+template <int GRAD, bool POW2>
 int launch_for_inner(int inner, dim3 grid, hipStream_t stream, const FusedArgs& a)
 {
     switch (inner) {
@@ -410,11 +421,16 @@ int launch_fused_outer(flow2d_context* ctx, int constancy, const float* f0, cons
     const unsigned strips_x = div_up(w, valid);
     const dim3 grid(div_up(strips_x, 4), div_up(h, rows_per_strip));
     const bool pow2 = is_power_of_two(hx) && is_power_of_two(hy);
-    const bool grad = constancy == FLOW2D_CONSTANCY_GRADIENT;
-    const int rc = grad ? (pow2 ? launch_for_inner<true, true>((int)inner, grid, ctx->stream, a)
-                                : launch_for_inner<true, false>((int)inner, grid, ctx->stream, a))
-                        : (pow2 ? launch_for_inner<false, true>((int)inner, grid, ctx->stream, a)
-                                : launch_for_inner<false, false>((int)inner, grid, ctx->stream, a));
+    int rc;
+    if (constancy == FLOW2D_CONSTANCY_GRADIENT)
+        rc = pow2 ? launch_for_inner<1, true>((int)inner, grid, ctx->stream, a)
+                  : launch_for_inner<1, false>((int)inner, grid, ctx->stream, a);
+    else if (constancy == FLOW2D_CONSTANCY_GRADIENT_UNTILED)
+        rc = pow2 ? launch_for_inner<2, true>((int)inner, grid, ctx->stream, a)
+                  : launch_for_inner<2, false>((int)inner, grid, ctx->stream, a);
+    else
+        rc = pow2 ? launch_for_inner<0, true>((int)inner, grid, ctx->stream, a)
+                  : launch_for_inner<0, false>((int)inner, grid, ctx->stream, a);
     if (rc) return FLOW2D_ERR_UNSUPPORTED;
     FLOW2D_CHECK_LAUNCH();
     return FLOW2D_OK;

@@ -67,7 +67,8 @@ int flow2d_solve_level(flow2d_context* ctx, const float* frame_0, const float* f
     }
     if (p->width < 2 || p->height < 2 || p->container_height < p->height || !(p->hx > 0.f) || !(p->hy > 0.f))
         return FLOW2D_ERR_INVALID_ARGUMENT;
-    if (p->data_constancy != FLOW2D_CONSTANCY_GREY && p->data_constancy != FLOW2D_CONSTANCY_GRADIENT)
+    if (p->data_constancy != FLOW2D_CONSTANCY_GREY && p->data_constancy != FLOW2D_CONSTANCY_GRADIENT &&
+        p->data_constancy != FLOW2D_CONSTANCY_GRADIENT_UNTILED)
         return FLOW2D_ERR_UNSUPPORTED;
     if (p->algorithm < FLOW2D_SOLVER_AUTO || p->algorithm > FLOW2D_SOLVER_SINGLE_WORKGROUP)
         return FLOW2D_ERR_INVALID_ARGUMENT;

@@ -33,6 +33,7 @@ struct SmallArgs {
     int w, h, pitch;
     int outer, inner;
     float hx, hy, alpha, e_smooth, e_data;
+    int untiled;  // gradient constancy only: true neighbours instead of the reference's 16x8 tile rule
 };
 
 __device__ __forceinline__ int at(int x, int y) { return (y + 1) * kStride + (x + 1); }
@@ -124,10 +125,11 @@ __global__ __launch_bounds__(1024) void small_level_kernel(SmallArgs a)
             const int y = y_base + j;
             gJ11[j % kJ] = gJ22[j % kJ] = gJ12[j % kJ] = gJ13[j % kJ] = gJ23[j % kJ] = 0.f;
             if (ok[j]) {
-                const int xa = ((x & 15) == 0) ? x : x - 1;
-                const int xb = ((x & 15) == 15 || x == w - 1) ? x : x + 1;
-                const int ya = ((y & 7) == 0) ? y : y - 1;
-                const int yb = ((y & 7) == 7 || y == h - 1) ? y : y + 1;
+                // tile rule of the reference, or (untiled mode) the true neighbours reflected at the border
+                const int xa = a.untiled ? mirror_index(x - 1, w) : (((x & 15) == 0) ? x : x - 1);
+                const int xb = a.untiled ? mirror_index(x + 1, w) : (((x & 15) == 15 || x == w - 1) ? x : x + 1);
+                const int ya = a.untiled ? mirror_index(y - 1, h) : (((y & 7) == 0) ? y : y - 1);
+                const int yb = a.untiled ? mirror_index(y + 1, h) : (((y & 7) == 7 || y == h - 1) ? y : y + 1);
                 const float fxx = (P_du[at(xb, y)] - P_du[at(xa, y)]) * hx_1;
                 const float fxy = (P_du[at(x, yb)] - P_du[at(x, ya)]) * hy_1;
                 const float fyy = (P_dv[at(x, yb)] - P_dv[at(x, ya)]) * hy_1;
@@ -258,9 +260,10 @@ int launch_small_level(flow2d_context* ctx, int constancy, const float* f0, cons
 {
     if (!small_level_supports(w, h)) return FLOW2D_ERR_UNSUPPORTED;
     SmallArgs a{f0, f1, u, v, out_du, out_dv, (int)w, (int)h, (int)(pitch_bytes / 4), (int)outer, (int)inner,
-                hx, hy, alpha, e_smooth, e_data};
+                hx, hy, alpha, e_smooth, e_data, 0};
     const dim3 block(kMaxSide, 1024 / kMaxSide);
-    const bool grad = constancy == FLOW2D_CONSTANCY_GRADIENT;
+    const bool grad = constancy != FLOW2D_CONSTANCY_GREY;
+    a.untiled = constancy == FLOW2D_CONSTANCY_GRADIENT_UNTILED ? 1 : 0;
     const int px = h <= 16 ? 1 : (h <= 32 ? 2 : 4);
     if (px == 1)
         grad ? small_level_kernel<true, 1><<<1, block, 0, ctx->stream>>>(a)

@@ -218,7 +218,9 @@ void CudaOperationSolve2D::Execute(OperationParameters& params)
     p.height = data_size.height;
     p.pitch_bytes = dev_container_size_.pitch;
     p.container_height = dev_container_size_.height;
-    p.data_constancy = init_constancy_ == DataConstancy::Gradient ? FLOW2D_CONSTANCY_GRADIENT : FLOW2D_CONSTANCY_GREY;
+    p.data_constancy = init_constancy_ == DataConstancy::Gradient          ? FLOW2D_CONSTANCY_GRADIENT
+                       : init_constancy_ == DataConstancy::GradientUntiled ? FLOW2D_CONSTANCY_GRADIENT_UNTILED
+                                                                           : FLOW2D_CONSTANCY_GREY;
     p.algorithm = algorithm;
     p.sor_omega = sor_omega;
 

@@ -7,7 +7,10 @@
 enum class Methods { OpticalFlow, Correlation };
 
 // LogDerivatives is accepted by the type but not implemented by the MI355X path (out of scope).
-enum class DataConstancy { Grey, Gradient, LogDerivatives };
+// Grey, Gradient, LogDerivatives: the reference's values (src/data_types/data_structs.h:27).  GradientUntiled is an
+// opt-in extra of this implementation (flow2d_c_abi.h, FLOW2D_CONSTANCY_GRADIENT_UNTILED): gradient constancy whose
+// second derivatives use the true neighbours instead of the reference's 16x8 launch tiles.
+enum class DataConstancy { Grey, Gradient, LogDerivatives, GradientUntiled };
 
 struct DataSize3 {
     size_t width;

@@ -50,6 +50,7 @@ int main(int argc, char** argv)
     for (int i = 1; i < argc; ++i) {
         if (!std::strcmp(argv[i], "--u8")) force_u8 = true;
         else if (!std::strcmp(argv[i], "--gradient")) data_constancy = DataConstancy::Gradient;
+        else if (!std::strcmp(argv[i], "--gradient-untiled")) data_constancy = DataConstancy::GradientUntiled;
         else if (!std::strcmp(argv[i], "--verbose")) verbose = true;
         else if (!std::strcmp(argv[i], "--device") && i + 1 < argc) device = std::atoi(argv[++i]);
         else if (!std::strcmp(argv[i], "--sor") && i + 1 < argc) sor_omega = static_cast<float>(std::atof(argv[++i]));
@@ -117,6 +118,7 @@ int main(int argc, char** argv)
         gaussian_sigma = settings.sigma;
         if (settings.imageType == "8-bit") u8 = true;
         if (settings.dataConstancy == "gradient") data_constancy = DataConstancy::Gradient;
+        if (settings.dataConstancy == "gradient-untiled") data_constancy = DataConstancy::GradientUntiled;
     } else {
         std::cout << "Usage: " << args[0] << " <settings file>. Otherwise settings.xml in the current directory is used"
                   << std::endl;

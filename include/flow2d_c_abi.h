@@ -44,11 +44,16 @@ typedef enum flow2d_status {
     FLOW2D_ERR_UNSUPPORTED = 5       /* e.g. median window not in {3,5,7}, Gaussian longer than 51 taps */
 } flow2d_status;
 
-/* Mirrors `enum class DataConstancy` (src/data_types/data_structs.h:27). LogDerivatives (value 2)
- * is out of scope and reported as FLOW2D_ERR_UNSUPPORTED. */
+/* Data term.  GREY and GRADIENT are `enum class DataConstancy` Grey and Gradient of the reference
+ * (src/data_types/data_structs.h:27); its LogDerivatives mode is out of scope (the host layer refuses it).
+ * GRADIENT_UNTILED is an extra, opt-in mode with no counterpart in the reference: the gradient-constancy
+ * tensor of solve_2d_grad with its second derivatives taken over the true neighbours (reflected at the image
+ * border) instead of being cut at the reference's 16x8 launch tiles.  Results differ from
+ * GRADIENT at tile edges by design. */
 typedef enum flow2d_constancy {
     FLOW2D_CONSTANCY_GREY = 0,
-    FLOW2D_CONSTANCY_GRADIENT = 1
+    FLOW2D_CONSTANCY_GRADIENT = 1,
+    FLOW2D_CONSTANCY_GRADIENT_UNTILED = 2
 } flow2d_constancy;
 
 typedef struct flow2d_context flow2d_context; /* opaque: device ordinal + stream + scratch */
@@ -161,6 +166,14 @@ FLOW2D_API int flow2d_solve_2d(flow2d_context* ctx, const float* frame_0, const 
                                const float* flow_v, const float* flow_du, const float* flow_dv, const float* phi,
                                const float* ksi, size_t width, size_t height, size_t pitch_bytes, float hx, float hy,
                                float equation_alpha, float* temp_du, float* temp_dv);
+
+/* One Jacobi sweep with the opt-in FLOW2D_CONSTANCY_GRADIENT_UNTILED data term (no reference counterpart;
+ * same arguments as flow2d_solve_2d_grad). */
+FLOW2D_API int flow2d_solve_2d_grad_untiled(flow2d_context* ctx, const float* frame_0, const float* frame_1,
+                                            const float* flow_u, const float* flow_v, const float* flow_du,
+                                            const float* flow_dv, const float* phi, const float* ksi, size_t width,
+                                            size_t height, size_t pitch_bytes, float hx, float hy,
+                                            float equation_alpha, float* temp_du, float* temp_dv);
 
 /* solve_2d_grad (src/kernels/solve_2d.cu:683-952): one Jacobi sweep, gradient constancy, including
  * the reference's 16x8 block rule for the second derivatives. */

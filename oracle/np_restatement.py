@@ -161,17 +161,22 @@ def _tensor_grey(f0, f1, hx, hy):
 
 
 def _tensor_grad(f0, f1, hx, hy, tile=(16, 8)):
-    """solve_2d.cu:795-884: second derivatives inside 16x8 blocks with edge replication."""
+    """solve_2d.cu:795-884: second derivatives inside 16x8 blocks with edge replication.
+    tile=None: true neighbours with the reflect rule at the image border (constancy 2, not a reference mode)."""
     fx, fy, ft = _derivs(f0, f1, hx, hy)
     h, w = f0.shape
     hx_1 = F(1.0 / (2.0 * float(hx)))
     hy_1 = F(1.0 / (2.0 * float(hy)))
     xs = np.arange(w)
     ys = np.arange(h)
-    xa = np.where(xs % tile[0] == 0, xs, xs - 1)
-    xb = np.where((xs % tile[0] == tile[0] - 1) | (xs == w - 1), xs, xs + 1)
-    ya = np.where(ys % tile[1] == 0, ys, ys - 1)
-    yb = np.where((ys % tile[1] == tile[1] - 1) | (ys == h - 1), ys, ys + 1)
+    if tile is None:
+        reflect = lambda i, n: np.where(np.abs(i) >= n, 2 * n - np.abs(i) - 2, np.abs(i))
+        xa, xb, ya, yb = reflect(xs - 1, w), reflect(xs + 1, w), reflect(ys - 1, h), reflect(ys + 1, h)
+    else:
+        xa = np.where(xs % tile[0] == 0, xs, xs - 1)
+        xb = np.where((xs % tile[0] == tile[0] - 1) | (xs == w - 1), xs, xs + 1)
+        ya = np.where(ys % tile[1] == 0, ys, ys - 1)
+        yb = np.where((ys % tile[1] == tile[1] - 1) | (ys == h - 1), ys, ys + 1)
     fxx = (fx[:, xb] - fx[:, xa]) * hx_1
     fxy = (fx[yb, :] - fx[ya, :]) * hy_1
     fyy = (fy[yb, :] - fy[ya, :]) * hy_1
@@ -185,7 +190,10 @@ def solve_sweep(f0, f1, u, v, du, dv, phi, ksi, hx, hy, alpha, gradient=False):
     """solve_2d.cu:200-377 (Grey) / :683-952 (Gradient): one Jacobi sweep."""
     hx, hy, alpha = F(hx), F(hy), F(alpha)
     h, w = f0.shape
-    J11, J22, J12, J13, J23 = (_tensor_grad if gradient else _tensor_grey)(f0, f1, hx, hy)
+    if gradient == 2:  # untiled
+        J11, J22, J12, J13, J23 = _tensor_grad(f0, f1, hx, hy, tile=None)
+    else:
+        J11, J22, J12, J13, J23 = (_tensor_grad if gradient else _tensor_grey)(f0, f1, hx, hy)
     hx_2 = alpha / (hx * hx)
     hy_2 = alpha / (hy * hy)
     xs = np.arange(w)[None, :]

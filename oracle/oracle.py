@@ -18,7 +18,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, "libflow2d_oracle.so")
 _lib = None
 
-GREY, GRADIENT = 0, 1
+GREY, GRADIENT, GRADIENT_UNTILED = 0, 1, 2  # 2: true neighbours instead of the 16x8 tile rule (not a reference mode)
 
 
 def build(force=False):
@@ -94,6 +94,7 @@ def lib():
         L.oracle_compute_phi_ksi.argtypes = [fp] * 6 + [sz, sz, sz, f, f, f, f, fp, fp]
         L.oracle_solve_2d.argtypes = [fp] * 8 + [sz, sz, sz, f, f, f, fp, fp]
         L.oracle_solve_2d_grad.argtypes = [fp] * 8 + [sz, sz, sz, f, f, f, fp, fp]
+        L.oracle_solve_2d_grad_untiled.argtypes = [fp] * 8 + [sz, sz, sz, f, f, f, fp, fp]
         L.oracle_solve_2d_sor.argtypes = [fp] * 8 + [sz, sz, sz, f, f, f, f, C.c_int]
         L.oracle_solve_level_sor.argtypes = [fp] * 8 + [sz, sz, sz, sz, f, f, f, f, f, sz, sz, C.c_int, f]
         L.oracle_add_2d.argtypes = [fp, fp, sz, sz, sz]
@@ -206,7 +207,8 @@ def compute_phi_ksi(f0, f1, u, v, du, dv, w, h, hx, hy, e_smooth, e_data):
 def solve_sweep(f0, f1, u, v, du, dv, phi, ksi, w, h, hx, hy, alpha, constancy=GREY):
     tdu = np.zeros_like(f0)
     tdv = np.zeros_like(f0)
-    fn = lib().oracle_solve_2d_grad if constancy == GRADIENT else lib().oracle_solve_2d
+    fn = {GREY: lib().oracle_solve_2d, GRADIENT: lib().oracle_solve_2d_grad,
+          GRADIENT_UNTILED: lib().oracle_solve_2d_grad_untiled}[constancy]
     fn(_p(f0), _p(f1), _p(u), _p(v), _p(du), _p(dv), _p(phi), _p(ksi), w, h, _pitch(f0), hx, hy, alpha, _p(tdu),
        _p(tdv))
     return tdu, tdv

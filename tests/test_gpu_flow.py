@@ -79,6 +79,8 @@ def test_small_pair_against_golden(flow2d, make_flow, constancy, name):
 @pytest.mark.parametrize("w,h,levels,scale,outer,inner,median,sigma,constancy", [
     (256, 192, 5, 0.5, 10, 5, 5, 1.5, 0),    # config-2 shaped, small
     (256, 128, 4, 0.5, 3, 5, 5, 1.5, 1),     # gradient constancy, every level a 16x8 multiple
+    (256, 128, 4, 0.5, 3, 5, 5, 1.5, 2),     # gradient constancy over true neighbours (opt-in, not in the reference)
+    (100, 70, 6, 0.8, 2, 3, 5, 0.45, 2),
     (131, 77, 30, 0.9, 2, 2, 3, 0.0, 0),     # no pre-blur, median 3, deep pyramid down to 4-5 px
     (64, 48, 3, 0.7, 1, 1, 7, 0.45, 0),      # median 7
     (96, 64, 3, 0.6, 2, 3, 1, 0.45, 1),      # median width 1 = copy
@@ -141,7 +143,7 @@ def test_boundary_error_behaviour(flow2d, make_flow):
         assert flow.missing_key_leaves_outputs(key) == 1
     # LogDerivatives is refused at Initialize
     with pytest.raises(flow2d.Flow2DError):
-        flow2d.OpticalFlow(64, 48, 2)
+        flow2d.OpticalFlow(64, 48, flow2d.HOST_LOG_DERIVATIVES)
     # no usable level (scale >= 1) is an input error: outputs keep the poison value of the facade
     f = np.zeros((48, 64), np.float32)
     u, v, _ = flow.compute_flow(f, f, flow.params(3, 1.0, 1, 1, 3.5, 0.001, 0.001, 5, 0.45))
@@ -215,7 +217,7 @@ def test_graph_replay_matches_eager(flow2d, oracle, ctx):
         flow.close()
 
 
-@pytest.mark.parametrize("constancy", [0, 1])
+@pytest.mark.parametrize("constancy", [0, 1, 2])
 def test_opt_in_sor_pyramid(flow2d, oracle, make_flow, constancy):
     """The opt-in red-black SOR mode end to end (bag key solver_sor_omega) against its oracle restatement.
     This mode has no counterpart in the reference (Jacobi), so it is not part of the reference-parity claim."""

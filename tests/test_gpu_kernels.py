@@ -93,7 +93,7 @@ def test_phi_ksi_and_sweeps(ctx, flow2d, oracle, w, h, cw, ch, hx, hy):
     ophi, oksi = oracle.compute_phi_ksi(f0, f1, u, v, du, dv, w, h, hx, hy, 0.001, 0.001)
     assert np.array_equal(phi.download(w, h), ophi)
     assert np.array_equal(ksi.download(w, h), oksi)
-    for constancy in (flow2d.GREY, flow2d.GRADIENT):
+    for constancy in (flow2d.GREY, flow2d.GRADIENT, flow2d.GRADIENT_UNTILED):
         ctx.solve_sweep(*d, phi, ksi, w, h, hx, hy, 35.0, tdu, tdv, constancy)
         odu, odv = oracle.solve_sweep(f0, f1, u, v, du, dv, ophi, oksi, w, h, hx, hy, 35.0, constancy)
         assert np.array_equal(tdu.download(w, h), odu), "du constancy %d" % constancy
@@ -134,7 +134,7 @@ def test_median_rejects_bad_window(ctx, flow2d, oracle):
 
 
 @pytest.mark.parametrize("algorithm", [1, 2, 0])
-@pytest.mark.parametrize("constancy", [0, 1])
+@pytest.mark.parametrize("constancy", [0, 1, 2])  # 2 = gradient term over true neighbours (not in the reference)
 @pytest.mark.parametrize("outer,inner", [(2, 3), (3, 2), (1, 5), (2, 1), (1, 4)])
 @pytest.mark.parametrize("w,h,cw,ch", SIZES[:4] + [(300, 150, 320, 160), (52, 64, 64, 64), (53, 65, 64, 80), (640, 520, 640, 520)])
 def test_solve_level(ctx, oracle, w, h, cw, ch, outer, inner, constancy, algorithm):
@@ -155,7 +155,7 @@ def test_solve_level(ctx, oracle, w, h, cw, ch, outer, inner, constancy, algorit
     assert (rdu is tdu) == (launches % 2 == 1)
 
 
-@pytest.mark.parametrize("constancy", [0, 1])
+@pytest.mark.parametrize("constancy", [0, 1, 2])  # 2 = gradient term over true neighbours (not in the reference)
 @pytest.mark.parametrize("outer,inner", [(2, 3), (3, 5), (1, 7), (2, 0), (0, 3)])
 @pytest.mark.parametrize("w,h", [(5, 4), (16, 8), (64, 16), (33, 17), (64, 32), (40, 33), (64, 64), (52, 61), (2, 2)])
 def test_solve_level_single_workgroup(ctx, flow2d, oracle, w, h, outer, inner, constancy):
@@ -195,7 +195,7 @@ def test_solve_level_fused_rejects_long_inner_loops(ctx, flow2d, oracle):
 
 
 # ---- opt-in red-black SOR (no reference counterpart; checked against its own oracle restatement) ---------------
-@pytest.mark.parametrize("constancy", [0, 1])
+@pytest.mark.parametrize("constancy", [0, 1, 2])  # 2 = gradient term over true neighbours (not in the reference)
 @pytest.mark.parametrize("omega", [1.0, 1.5])
 @pytest.mark.parametrize("w,h,cw,ch", SIZES[:4])
 def test_sor_iteration_and_level(ctx, oracle, w, h, cw, ch, omega, constancy):

@@ -82,9 +82,9 @@ def test_cross_kernels(oracle, w, h):
         phi, ksi = oracle.compute_phi_ksi(f0, f1, u, v, du, dv, w, h, hx, hy, 0.001, 0.001)
         phi2, ksi2 = N.compute_phi_ksi(f0, f1, u, v, du, dv, hx, hy, 0.001, 0.001)
         assert np.array_equal(phi, phi2) and np.array_equal(ksi, ksi2)
-        for g in (0, 1):
+        for g in (0, 1, 2):  # 2 = Gradient with true neighbours (the product's extra mode)
             a, b = oracle.solve_sweep(f0, f1, u, v, du, dv, phi, ksi, w, h, hx, hy, 35.0, g)
-            a2, b2 = N.solve_sweep(f0, f1, u, v, du, dv, phi, ksi, hx, hy, 35.0, bool(g))
+            a2, b2 = N.solve_sweep(f0, f1, u, v, du, dv, phi, ksi, hx, hy, 35.0, g)
             assert np.array_equal(a, a2) and np.array_equal(b, b2)
     for r in (3, 5, 7):
         assert np.array_equal(oracle.median(u, w, h, r), N.median(u, r))
@@ -98,12 +98,12 @@ def test_cross_upsample(oracle):
     assert np.array_equal(oracle.resample(big, 37, 20, 100, 70), N.resample(f0, 100, 70))
 
 
-@pytest.mark.parametrize("gradient", [0, 1])
+@pytest.mark.parametrize("gradient", [0, 1, 2])
 def test_cross_end_to_end(oracle, gradient):
     from oracle import np_restatement as N
     f0, f1, *_ = level_fields(oracle, 100, 70, 13)
     uo, vo, _ = oracle.compute_flow(f0, f1, 6, 0.8, 2, 3, 3.5, 0.001, 0.001, 5, 0.45, gradient)
-    un, vn = N.compute_flow(f0, f1, 6, 0.8, 2, 3, 3.5, 0.001, 0.001, 5, 0.45, bool(gradient))
+    un, vn = N.compute_flow(f0, f1, 6, 0.8, 2, 3, 3.5, 0.001, 0.001, 5, 0.45, gradient)
     assert np.array_equal(uo, un) and np.array_equal(vo, vn)
 
 
