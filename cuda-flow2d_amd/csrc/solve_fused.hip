@@ -43,6 +43,12 @@ struct FusedArgs {
     int w, h, pitch;
     int rows_per_strip;
     int zero_increment;  // first outer iteration: du = dv = 0, the planes are not read (and need no memset)
+    // More sweeps per outer iteration than one launch holds: a later launch of the same outer iteration rebuilds
+    // the coefficients from the same du/dv (identical arithmetic, identical values) and continues the sweeps
+    // from the previous launch's result in start_du/start_dv.
+    const float* start_du;
+    const float* start_dv;
+    int continue_sweeps;
     float hx, hy, alpha, e_smooth, e_data;
 };
 
@@ -105,12 +111,17 @@ struct Strip {
     // prefetched input row
     float n_f0, n_f1;
     v2f n_uv, n_duv;
+    // continue_sweeps only: the sweeps' starting increment of row r-2 (start_cur) and the row fetched for the
+    // next step (n_start)
+    v2f start_cur, n_start;
 };
 
 // EDGE = false: the strip touches no image border, so the reflect substitutions (a v_cndmask per
 // neighbour fetch) are compiled out; EDGE = true keeps them.  Chosen per wave (wave-uniform branch).
 // POW2: 2h and 4h are powers of two, so dividing by them is an exact multiply by the reciprocal.
-template <int INNER, int GRAD, bool EDGE, bool POW2, int J>
+// CONT: the launch continues the sweeps of an outer iteration (FusedArgs::continue_sweeps); a template value so
+// that the ordinary launch carries none of it.
+template <int INNER, int GRAD, bool EDGE, bool POW2, bool CONT, int J>
 __device__ __forceinline__ void strip_step(Strip<INNER, GRAD>& s, const FusedArgs& a, int r, int x, int xc, bool at_l,
                                            bool at_r, bool lane_stores, int y0, int y1, v2f xpm, float hx_2,
                                            float hy_2)
@@ -123,7 +134,16 @@ __device__ __forceinline__ void strip_step(Strip<INNER, GRAD>& s, const FusedArg
     if (!EDGE) at_l = at_r = false;
 
     // ---- commit the prefetched row r (its slot still holds row r-3: sweep 1 needs that row's dv) ----------
-    const float dv_row3 = s.duvw[s0].y;
+    constexpr bool cont = CONT;
+    const float dv_row3 = cont ? s.start_cur.y : s.duvw[s0].y;  // start_cur still is row r-3 here
+    if (cont) {
+        s.start_cur = s.n_start;  // row r-2
+        const int rs = min(max(r - 1, 0), h - 1);
+        const unsigned row_bytes = static_cast<unsigned>(rs) * static_cast<unsigned>(a.pitch) * 4u;
+        const unsigned plane_bytes = static_cast<unsigned>(h) * static_cast<unsigned>(a.pitch) * 4u;
+        s.n_start = v2f{plane_load(plane_rsrc(a.start_du, plane_bytes), static_cast<unsigned>(xc) * 4u, row_bytes),
+                        plane_load(plane_rsrc(a.start_dv, plane_bytes), static_cast<unsigned>(xc) * 4u, row_bytes)};
+    }
     s.f0w[s0] = s.n_f0;
     s.f1w[s0] = s.n_f1;
     s.uvw[s0] = s.n_uv;
@@ -246,7 +266,7 @@ __device__ __forceinline__ void strip_step(Strip<INNER, GRAD>& s, const FusedArg
         }
         c.den = c.ksi * J11_22 + sumH;  // update_denominator for u and v
         // (u + du, v + dv) of row r-2 enters sweep 1's window
-        s.UV[0][s2] = s.uvw[s2] + s.duvw[s2];
+        s.UV[0][s2] = s.uvw[s2] + (cont ? s.start_cur : s.duvw[s2]);
     }
     // stage P's outputs of this step are what stage W consumes in the next one
     s.p_fx = fx;
@@ -282,17 +302,17 @@ __device__ __forceinline__ void strip_step(Strip<INNER, GRAD>& s, const FusedArg
     }
 }
 
-template <int INNER, int GRAD, bool EDGE, bool POW2, size_t... Js>
+template <int INNER, int GRAD, bool EDGE, bool POW2, bool CONT, size_t... Js>
 __device__ __forceinline__ void strip_steps(Strip<INNER, GRAD>& s, const FusedArgs& a, int r_base, int x, int xc,
                                             bool at_l, bool at_r, bool lane_stores, int y0, int y1, v2f xpm,
                                             float hx_2, float hy_2, std::index_sequence<Js...>)
 {
-    (strip_step<INNER, GRAD, EDGE, POW2, static_cast<int>(Js)>(s, a, r_base + static_cast<int>(Js), x, xc, at_l, at_r,
+    (strip_step<INNER, GRAD, EDGE, POW2, CONT, static_cast<int>(Js)>(s, a, r_base + static_cast<int>(Js), x, xc, at_l, at_r,
                                                                lane_stores, y0, y1, xpm, hx_2, hy_2),
      ...);
 }
 
-template <int INNER, int GRAD, bool POW2>
+template <int INNER, int GRAD, bool POW2, bool CONT>
 __global__ __launch_bounds__(256) void fused_outer_kernel(FusedArgs a)
 {
     using S = Strip<INNER, GRAD>;
@@ -335,6 +355,11 @@ __global__ __launch_bounds__(256) void fused_outer_kernel(FusedArgs a)
         s.n_f1 = a.f1[o];
         s.n_uv = v2f{a.u[o], a.v[o]};
         s.n_duv = a.zero_increment ? v2f{0.f, 0.f} : v2f{a.du[o], a.dv[o]};
+        s.start_cur = s.n_start = v2f{0.f, 0.f};
+        if (CONT) {  // the first step commits row r_first - 2 of the starting increment
+            const size_t os = static_cast<size_t>(min(max(r_first - 2, 0), a.h - 1)) * a.pitch + xc;
+            s.n_start = v2f{a.start_du[os], a.start_dv[os]};
+        }
     }
     // the last stored row y1-1 leaves the last sweep at input row (y1-1) + 2 + INNER
     const int r_last = y1 - 1 + 2 + INNER;
@@ -343,26 +368,33 @@ __global__ __launch_bounds__(256) void fused_outer_kernel(FusedArgs a)
     const bool edge = x_first <= 0 || x_first + 63 >= a.w - 1 || y0 <= S::kHalo + 1 || y1 + S::kHalo + 1 >= a.h;
     if (__builtin_amdgcn_readfirstlane(edge)) {
         for (int r = r_first; r <= r_last; r += S::kRing)
-            strip_steps<INNER, GRAD, true, POW2>(s, a, r, x, xc, at_l, at_r, lane_stores, y0, y1, xpm, hx_2, hy_2,
+            strip_steps<INNER, GRAD, true, POW2, CONT>(s, a, r, x, xc, at_l, at_r, lane_stores, y0, y1, xpm, hx_2, hy_2,
                                            std::make_index_sequence<S::kRing>{});
     } else {
         for (int r = r_first; r <= r_last; r += S::kRing)
-            strip_steps<INNER, GRAD, false, POW2>(s, a, r, x, xc, at_l, at_r, lane_stores, y0, y1, xpm, hx_2, hy_2,
+            strip_steps<INNER, GRAD, false, POW2, CONT>(s, a, r, x, xc, at_l, at_r, lane_stores, y0, y1, xpm, hx_2, hy_2,
                                             std::make_index_sequence<S::kRing>{});
+    }
+}
+
+template <int GRAD, bool POW2, bool CONT>
+int launch_for_inner_cont(int inner, dim3 grid, hipStream_t stream, const FusedArgs& a)
+{
+    switch (inner) {
+        case 1: fused_outer_kernel<1, GRAD, POW2, CONT><<<grid, 256, 0, stream>>>(a); return 0;
+        case 2: fused_outer_kernel<2, GRAD, POW2, CONT><<<grid, 256, 0, stream>>>(a); return 0;
+        case 3: fused_outer_kernel<3, GRAD, POW2, CONT><<<grid, 256, 0, stream>>>(a); return 0;
+        case 4: fused_outer_kernel<4, GRAD, POW2, CONT><<<grid, 256, 0, stream>>>(a); return 0;
+        case 5: fused_outer_kernel<5, GRAD, POW2, CONT><<<grid, 256, 0, stream>>>(a); return 0;
+        default: return 1;
     }
 }
 
 template <int GRAD, bool POW2>
 int launch_for_inner(int inner, dim3 grid, hipStream_t stream, const FusedArgs& a)
 {
-    switch (inner) {
-        case 1: fused_outer_kernel<1, GRAD, POW2><<<grid, 256, 0, stream>>>(a); return 0;
-        case 2: fused_outer_kernel<2, GRAD, POW2><<<grid, 256, 0, stream>>>(a); return 0;
-        case 3: fused_outer_kernel<3, GRAD, POW2><<<grid, 256, 0, stream>>>(a); return 0;
-        case 4: fused_outer_kernel<4, GRAD, POW2><<<grid, 256, 0, stream>>>(a); return 0;
-        case 5: fused_outer_kernel<5, GRAD, POW2><<<grid, 256, 0, stream>>>(a); return 0;
-        default: return 1;
-    }
+    return a.continue_sweeps ? launch_for_inner_cont<GRAD, POW2, true>(inner, grid, stream, a)
+                             : launch_for_inner_cont<GRAD, POW2, false>(inner, grid, stream, a);
 }
 
 // true when x is a normal power of two whose reciprocal (and 1/(2x), 1/(4x)) is exactly representable
@@ -412,11 +444,13 @@ int fused_rows_per_strip(const flow2d_context* ctx, size_t w, size_t h, size_t i
 int launch_fused_outer(flow2d_context* ctx, int constancy, const float* f0, const float* f1, const float* u,
                        const float* v, const float* du, const float* dv, size_t w, size_t h, size_t pitch_bytes,
                        float hx, float hy, float alpha, float e_smooth, float e_data, size_t inner, float* out_du,
-                       float* out_dv, int rows_per_strip, bool zero_increment)
+                       float* out_dv, int rows_per_strip, bool zero_increment, const float* start_du,
+                       const float* start_dv)
 {
     if (!fused_supports(inner)) return FLOW2D_ERR_UNSUPPORTED;
     FusedArgs a{f0, f1, u, v, du, dv, out_du, out_dv, (int)w, (int)h, (int)(pitch_bytes / 4), rows_per_strip,
-                zero_increment ? 1 : 0, hx, hy, alpha, e_smooth, e_data};
+                zero_increment ? 1 : 0, start_du, start_dv, (start_du && start_dv) ? 1 : 0, hx, hy, alpha, e_smooth,
+                e_data};
     const int valid = 64 - 2 * ((int)inner + 1);
     const unsigned strips_x = div_up(w, valid);
     const dim3 grid(div_up(strips_x, 4), div_up(h, rows_per_strip));

@@ -2,6 +2,7 @@
 // Replaces the launch loop of CudaOperationSolve2D::Execute
 // (src/cuda_operations/2d/cuda_operation_solve_2d.cpp:229-300) without its per-sweep host
 // synchronisation (:291): everything is queued on the context's stream.
+#include <algorithm>
 #include <cstdlib>
 #include <utility>
 
@@ -26,7 +27,8 @@ int fused_rows_per_strip(const flow2d_context* ctx, size_t w, size_t h, size_t i
 int launch_fused_outer(flow2d_context* ctx, int constancy, const float* f0, const float* f1, const float* u,
                        const float* v, const float* du, const float* dv, size_t w, size_t h, size_t pitch_bytes,
                        float hx, float hy, float alpha, float e_smooth, float e_data, size_t inner, float* out_du,
-                       float* out_dv, int rows_per_strip, bool zero_increment);
+                       float* out_dv, int rows_per_strip, bool zero_increment, const float* start_du,
+                       const float* start_dv);
 }  // namespace flow2d
 
 namespace {
@@ -86,13 +88,12 @@ int flow2d_solve_level(flow2d_context* ctx, const float* frame_0, const float* f
         if (flow2d::small_level_supports(p->width, p->height) && p->height <= 32)
             algorithm = FLOW2D_SOLVER_SINGLE_WORKGROUP;
         else
-            algorithm = (big && flow2d::fused_supports(p->inner_iterations_count)) ? FLOW2D_SOLVER_FUSED
-                                                                                   : FLOW2D_SOLVER_PER_SWEEP;
+            algorithm = big ? FLOW2D_SOLVER_FUSED : FLOW2D_SOLVER_PER_SWEEP;
     }
     if (algorithm == FLOW2D_SOLVER_SINGLE_WORKGROUP && !flow2d::small_level_supports(p->width, p->height))
         return FLOW2D_ERR_UNSUPPORTED;
-    if (algorithm == FLOW2D_SOLVER_FUSED && !flow2d::fused_supports(p->inner_iterations_count))
-        return FLOW2D_ERR_UNSUPPORTED;
+    if (algorithm == FLOW2D_SOLVER_FUSED && p->inner_iterations_count == 0 && p->outer_iterations_count != 0)
+        return FLOW2D_ERR_UNSUPPORTED;  // nothing to fuse: an outer iteration without sweeps leaves du, dv as they are
 
     flow2d_timing_slot* slot = nullptr;
     if (ctx->timing) {
@@ -130,21 +131,45 @@ int flow2d_solve_level(flow2d_context* ctx, const float* frame_0, const float* f
         ++launches;
     }
     static const int rows_env = std::getenv("FLOW2D_FUSED_ROWS") ? std::atoi(std::getenv("FLOW2D_FUSED_ROWS")) : 0;
+    // Fused path: one launch per outer iteration does phi/ksi and up to 5 sweeps (solve_fused.hip); phi and ksi
+    // are not materialised, so their planes serve as a third (du, dv) pair.  More than 5 sweeps per outer
+    // iteration are split into equal chunks: every chunk rebuilds the coefficients from the outer iteration's
+    // starting pair (same arithmetic, same values) and continues the sweeps from the previous chunk's result.
+    float* pair_u[3] = {flow_du, temp_du, phi};
+    float* pair_v[3] = {flow_dv, temp_dv, ksi};
+    int source = 0;  // pair holding du, dv at the start of the outer iteration
+    const size_t inner = p->inner_iterations_count;
+    const size_t chunks = algorithm == FLOW2D_SOLVER_FUSED ? std::max<size_t>(1, (inner + 4) / 5) : 0;
     for (size_t i = 0; algorithm == FLOW2D_SOLVER_FUSED && i < p->outer_iterations_count; ++i) {
-        // one launch per outer iteration: phi/ksi and all inner sweeps in one pass (solve_fused.hip);
-        // phi and ksi are not materialised in this mode.
-        const int rows = rows_env > 0 ? rows_env
-                                      : flow2d::fused_rows_per_strip(ctx, p->width, p->height, p->inner_iterations_count);
-        if (per_launch) FLOW2D_HIP_TRY(mark(ctx, slot));
-        int st = flow2d::launch_fused_outer(ctx, p->data_constancy, frame_0, frame_1, flow_u, flow_v, du, dv, p->width,
-                                            p->height, p->pitch_bytes, p->hx, p->hy, p->equation_alpha,
-                                            p->equation_smoothness, p->equation_data, p->inner_iterations_count, tdu,
-                                            tdv, rows, i == 0);
-        if (st != FLOW2D_OK) return st;
-        if (per_launch) FLOW2D_HIP_TRY(mark(ctx, slot));
+        int in = source;
+        for (size_t c = 0; c < chunks; ++c) {
+            const size_t sweeps = inner / chunks + (c < inner % chunks ? 1 : 0);
+            int out = 0;
+            while (out == source || out == in) ++out;
+            const int rows = rows_env > 0 ? rows_env : flow2d::fused_rows_per_strip(ctx, p->width, p->height, sweeps);
+            if (per_launch) FLOW2D_HIP_TRY(mark(ctx, slot));
+            int st = flow2d::launch_fused_outer(ctx, p->data_constancy, frame_0, frame_1, flow_u, flow_v, pair_u[source],
+                                                pair_v[source], p->width, p->height, p->pitch_bytes, p->hx, p->hy,
+                                                p->equation_alpha, p->equation_smoothness, p->equation_data, sweeps,
+                                                pair_u[out], pair_v[out], rows, i == 0, c == 0 ? nullptr : pair_u[in],
+                                                c == 0 ? nullptr : pair_v[in]);
+            if (st != FLOW2D_OK) return st;
+            if (per_launch) FLOW2D_HIP_TRY(mark(ctx, slot));
+            in = out;
+            ++launches;
+        }
+        source = in;
+    }
+    if (algorithm == FLOW2D_SOLVER_FUSED && source == 2) {  // the caller only knows two pairs: hand the result over
+        FLOW2D_HIP_TRY(hipMemcpy2DAsync(flow_du, p->pitch_bytes, phi, p->pitch_bytes, p->width * sizeof(float), p->height,
+                                        hipMemcpyDeviceToDevice, ctx->stream));
+        FLOW2D_HIP_TRY(hipMemcpy2DAsync(flow_dv, p->pitch_bytes, ksi, p->pitch_bytes, p->width * sizeof(float), p->height,
+                                        hipMemcpyDeviceToDevice, ctx->stream));
+        source = 0;
+    }
+    if (algorithm == FLOW2D_SOLVER_FUSED && source == 1) {
         std::swap(du, tdu);
         std::swap(dv, tdv);
-        ++launches;
     }
     for (size_t i = 0; algorithm == FLOW2D_SOLVER_PER_SWEEP && i < p->outer_iterations_count; ++i) {
         int st = flow2d::launch_phi_ksi(ctx, frame_0, frame_1, flow_u, flow_v, du, dv, p->width, p->height,
@@ -183,7 +208,8 @@ int flow2d_solve_level(flow2d_context* ctx, const float* frame_0, const float* f
         slot->rec.elapsed_ms = -1.f;
         slot->rec.kernel_ms = -1.f;
         double per_px = 40.0;  // one Jacobi sweep
-        if (algorithm == FLOW2D_SOLVER_FUSED) per_px = 32.0 + 40.0 * p->inner_iterations_count;
+        if (algorithm == FLOW2D_SOLVER_FUSED)  // an outer iteration's bytes, spread over its launches
+            per_px = (32.0 + 40.0 * p->inner_iterations_count) / static_cast<double>(std::max<size_t>(1, chunks));
         if (algorithm == FLOW2D_SOLVER_SINGLE_WORKGROUP)
             per_px = p->outer_iterations_count * (32.0 + 40.0 * p->inner_iterations_count);
         slot->rec.algorithmic_bytes_per_launch = per_px * static_cast<double>(p->width) * static_cast<double>(p->height);

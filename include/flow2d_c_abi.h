@@ -202,7 +202,8 @@ FLOW2D_API int flow2d_solve_2d_sor(flow2d_context* ctx, const float* frame_0, co
 typedef enum flow2d_solver_algorithm {
     FLOW2D_SOLVER_AUTO = 0,      /* library picks the fastest bit-exact path for the level size */
     FLOW2D_SOLVER_PER_SWEEP = 1, /* one launch per reference kernel launch (K6, K7/K9) */
-    FLOW2D_SOLVER_FUSED = 2,     /* one launch per outer iteration: phi/ksi + all inner sweeps fused (inner <= 5) */
+    FLOW2D_SOLVER_FUSED = 2,     /* phi/ksi + the inner sweeps of an outer iteration fused into ceil(inner / 5)
+                                  * launches (one for inner <= 5); needs inner >= 1 */
     FLOW2D_SOLVER_SINGLE_WORKGROUP = 3 /* the whole level (all outer x inner iterations) in one launch on one
                                           CU; levels up to 64 x 64 pixels */
 } flow2d_solver_algorithm;
@@ -243,7 +244,7 @@ typedef struct flow2d_timing_record {
     int kernel_launches;    /* launches of the dominant solver kernel inside the bracket */
     float elapsed_ms;       /* event time of the whole solve call */
     float kernel_ms;        /* mode 2: sum of the dominant kernel's launch durations; -1 otherwise */
-    double algorithmic_bytes_per_launch; /* W*H*40 per sweep launch, W*H*(32+40*inner) per fused launch */
+    double algorithmic_bytes_per_launch; /* W*H*40 per sweep launch, W*H*(32+40*inner)/ceil(inner/5) per fused launch */
 } flow2d_timing_record;
 
 FLOW2D_API int flow2d_timing_enable(flow2d_context* ctx, int mode);

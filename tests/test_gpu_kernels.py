@@ -155,6 +155,24 @@ def test_solve_level(ctx, oracle, w, h, cw, ch, outer, inner, constancy, algorit
     assert (rdu is tdu) == (launches % 2 == 1)
 
 
+@pytest.mark.parametrize("algorithm", [2, 0])
+@pytest.mark.parametrize("constancy", [0, 1, 2])
+@pytest.mark.parametrize("outer,inner", [(1, 6), (2, 7), (3, 8), (1, 10), (4, 11), (1, 16)])
+@pytest.mark.parametrize("w,h,cw,ch", [(100, 70, 128, 80), (640, 520, 640, 520)])
+def test_solve_level_fused_more_than_five_sweeps(ctx, oracle, w, h, cw, ch, outer, inner, constancy, algorithm):
+    """More sweeps per outer iteration than one fused launch holds: the launches of one outer iteration share
+    their coefficients' source and hand the increment on; the result can end in any of the three plane pairs."""
+    f0, f1, u, v, _, _ = level_fields(oracle, w, h, 17)
+    hx, hy = np.float32(cw / w), np.float32(ch / h)
+    d = [up(ctx, a, cw, ch) for a in (f0, f1, u, v)]
+    du, dv, phi, ksi, tdu, tdv = (ctx.plane(cw, ch).fill_bytes(0x7f) for _ in range(6))
+    rdu, rdv = ctx.solve_level(*d, du, dv, phi, ksi, tdu, tdv, w, h, hx, hy, 3.5, 0.001, 0.001, outer, inner,
+                               constancy, algorithm)
+    odu, odv, _, _ = oracle.solve_level(f0, f1, u, v, w, h, hx, hy, 3.5, 0.001, 0.001, outer, inner, constancy)
+    assert np.array_equal(rdu.download(w, h), odu)
+    assert np.array_equal(rdv.download(w, h), odv)
+
+
 @pytest.mark.parametrize("constancy", [0, 1, 2])  # 2 = gradient term over true neighbours (not in the reference)
 @pytest.mark.parametrize("outer,inner", [(2, 3), (3, 5), (1, 7), (2, 0), (0, 3)])
 @pytest.mark.parametrize("w,h", [(5, 4), (16, 8), (64, 16), (33, 17), (64, 32), (40, 33), (64, 64), (52, 61), (2, 2)])
@@ -180,17 +198,17 @@ def test_solve_level_single_workgroup_rejects_large_levels(ctx, flow2d, oracle):
     assert e.value.status == 5
 
 
-def test_solve_level_fused_rejects_long_inner_loops(ctx, flow2d, oracle):
-    """inner > 5 is outside the fused kernel's register budget: FUSED refuses, AUTO falls back to per-sweep."""
+def test_solve_level_fused_without_sweeps(ctx, flow2d, oracle):
+    """FUSED has nothing to fuse when an outer iteration holds no sweep: refused; AUTO runs the per-sweep form."""
     w, h = 64, 48
     f0, f1, u, v, _, _ = level_fields(oracle, w, h, 8)
     d = [up(ctx, a, w, h) for a in (f0, f1, u, v)]
     du, dv, phi, ksi, tdu, tdv = (ctx.plane(w, h) for _ in range(6))
     with pytest.raises(flow2d.Flow2DError) as e:
-        ctx.solve_level(*d, du, dv, phi, ksi, tdu, tdv, w, h, 1.0, 1.0, 3.5, 0.001, 0.001, 1, 7, 0, 2)
+        ctx.solve_level(*d, du, dv, phi, ksi, tdu, tdv, w, h, 1.0, 1.0, 3.5, 0.001, 0.001, 2, 0, 0, 2)
     assert e.value.status == 5
-    rdu, rdv = ctx.solve_level(*d, du, dv, phi, ksi, tdu, tdv, w, h, 1.0, 1.0, 3.5, 0.001, 0.001, 1, 7, 0, 0)
-    odu, odv, _, _ = oracle.solve_level(f0, f1, u, v, w, h, 1.0, 1.0, 3.5, 0.001, 0.001, 1, 7, 0)
+    rdu, rdv = ctx.solve_level(*d, du, dv, phi, ksi, tdu, tdv, w, h, 1.0, 1.0, 3.5, 0.001, 0.001, 2, 0, 0, 0)
+    odu, odv, _, _ = oracle.solve_level(f0, f1, u, v, w, h, 1.0, 1.0, 3.5, 0.001, 0.001, 2, 0, 0)
     assert np.array_equal(rdu.download(w, h), odu) and np.array_equal(rdv.download(w, h), odv)
 
 
