@@ -85,6 +85,8 @@ def test_small_pair_against_golden(flow2d, make_flow, constancy, name):
     (64, 48, 3, 0.7, 1, 1, 7, 0.45, 0),      # median 7
     (96, 64, 3, 0.6, 2, 3, 1, 0.45, 1),      # median width 1 = copy
     (80, 60, 2, 0.5, 2, 2, 6, 0.45, 0),      # even width -> 5
+    (640, 528, 3, 0.5, 2, 7, 5, 1.5, 1),     # 7 sweeps per outer iteration: two fused launches at the finest level
+    (1024, 600, 2, 0.5, 1, 10, 5, 1.5, 0),   # 10 sweeps: 5 + 5
 ])
 def test_synthetic_pairs_parity(flow2d, oracle, make_flow, w, h, levels, scale, outer, inner, median, sigma,
                                 constancy):
