@@ -39,8 +39,8 @@ def main():
     }}
     px = float(size) * size
     table = {
-        "fused_outer_kernel<5, false, true>": ("cfg3_4096_grey/algorithm2", px * (32 + 40 * 5)),
-        "fused_outer_kernel<5, true, true>": ("cfg3_4096_gradient/algorithm2", px * (32 + 40 * 5)),
+        "fused_outer_kernel<5, 0, true, false>": ("cfg3_4096_grey/algorithm2", px * (32 + 40 * 5)),
+        "fused_outer_kernel<5, 1, true, false>": ("cfg3_4096_gradient/algorithm2", px * (32 + 40 * 5)),
         "sweep_grey_kernel": ("cfg3_4096_grey/algorithm1", px * 40),
         "sweep_grad_kernel": ("cfg3_4096_gradient/algorithm1", px * 40),
         "phi_ksi_kernel": ("phi_ksi_4096", px * 32),
