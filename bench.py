@@ -173,8 +173,11 @@ def main():
         f = flow2d.OpticalFlow(w, h, cfg["constancy"], ctx=c)
         lanes.append({"ctx": c, "flow": f, "pairs": []})
     ctx, flow = lanes[0]["ctx"], lanes[0]["flow"]
-    params = flow.params(cfg["levels"], cfg["scale"], cfg["outer"], cfg["inner"], cfg["alpha"], 0.001, 0.001,
-                         cfg["median"], cfg["sigma"], args.algorithm)
+    # rank 0's parameter block on every rank (RCCL broadcast), then the same solve everywhere
+    block = batch.broadcast_params([cfg["levels"], cfg["scale"], cfg["outer"], cfg["inner"], cfg["alpha"], 0.001,
+                                    0.001, cfg["median"], cfg["sigma"], args.algorithm])
+    params = flow.params(int(block[0]), block[1], int(block[2]), int(block[3]), block[4], block[5], block[6],
+                         int(block[7]), block[8], int(block[9]))
 
     # this rank's pairs, resident in HBM before the timed region
     total_pairs = cfg["pairs_per_rank"] * world

@@ -1,6 +1,7 @@
 """Sharding of independent image pairs over the GPUs of one node: one process per GPU,
 pair k -> rank k mod world, no data-path collective.  torch.distributed is used only for the start/stop
-barrier, the max-over-ranks of the elapsed time and (optionally) gathering per-pair result digests.
+barrier, the broadcast of rank 0's parameter block, the max-over-ranks of the elapsed time and (optionally)
+gathering per-pair result digests or flow fields.
 Backend "nccl" is RCCL on ROCm; "gloo" is what the CPU tests use."""
 import os
 
@@ -41,6 +42,35 @@ def _collective_device(device):
     if device is not None:
         return device
     return torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else "cpu"
+
+
+def broadcast_params(values, device=None):
+    """Rank 0's parameter block (a flat sequence of numbers, e.g. levels, scale, outer, inner, alpha, ...) on every
+    rank: all ranks of a batch solve with the same parameters whatever their own command line said."""
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        return [float(x) for x in values]
+    t = torch.tensor([float(x) for x in values], dtype=torch.float64, device=_collective_device(device))
+    dist.broadcast(t, src=0)
+    return t.tolist()
+
+
+def gather_fields(local, total_pairs, height, width, device=None):
+    """local: {global_pair_index: (u, v)} float32 arrays of this rank's pairs.  Returns on every rank a float32
+    array [total_pairs, 2, height, width] with all flow fields (the owners are disjoint, so summing gathers)."""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    initialised = dist.is_available() and dist.is_initialized()
+    out = torch.zeros((total_pairs, 2, height, width), dtype=torch.float32,
+                      device=_collective_device(device) if initialised else "cpu")
+    for k, (u, v) in local.items():
+        out[k, 0] = torch.from_numpy(np.ascontiguousarray(u)).to(out.device)
+        out[k, 1] = torch.from_numpy(np.ascontiguousarray(v)).to(out.device)
+    if initialised:
+        dist.all_reduce(out, op=dist.ReduceOp.SUM)
+    return out.cpu().numpy()
 
 
 def max_over_ranks(value, device=None):

@@ -1,5 +1,5 @@
 """world_size-2 CPU test (gloo) of the multi-GPU plumbing bench.py uses: pair sharding without a data-path
-collective, barrier, max-over-ranks timing and the digest gather.  The per-pair work is stood in for by
+collective, parameter broadcast, barrier, max-over-ranks timing and the digest / flow-field gathers.  The per-pair work is stood in for by
 the CPU oracle on a tiny pair (this test checks the sharding logic, not the HIP path)."""
 import os
 import subprocess
@@ -19,20 +19,25 @@ WORKER = textwrap.dedent("""
     rank, local_rank, world = batch.init(backend="gloo")
     total = 5
     mine = batch.pairs_of_rank(total, rank, world)
-    digests = {}
+    digests, fields = {}, {}
+    # rank 0's parameter block wins: rank 1 starts from a different (wrong) one
+    levels, scale, outer, inner, alpha = batch.broadcast_params([3, 0.5, 2, 2, 35.0] if rank == 0 else [9, 0.9, 7, 7, 1.0])
     batch.barrier()
     t0 = time.perf_counter()
     for k in mine:
         f0, f1 = O.synthetic_pair(48, 32, 2.0 * np.cos(k), 2.0 * np.sin(k))
-        u, v, _ = O.compute_flow(f0, f1, 3, 0.5, 2, 2, 35.0, 0.001, 0.001, 5, 1.5)
+        u, v, _ = O.compute_flow(f0, f1, int(levels), scale, int(outer), int(inner), alpha, 0.001, 0.001, 5, 1.5)
         digests[k] = float(u.sum(dtype=np.float64) + 2.0 * v.sum(dtype=np.float64))
+        fields[k] = (u, v)
     time.sleep(0.05 * (rank + 1))
     batch.barrier()
     elapsed = time.perf_counter() - t0
     slowest = batch.max_over_ranks(elapsed)
     allp = batch.gather_digests(digests, total)
+    allf = batch.gather_fields(fields, total, 32, 48)
+    field_digests = [float(allf[k, 0].sum(dtype=np.float64) + 2.0 * allf[k, 1].sum(dtype=np.float64)) for k in range(total)]
     print(json.dumps({"rank": rank, "world": world, "mine": mine, "elapsed": elapsed, "slowest": slowest,
-                      "digests": allp}))
+                      "digests": allp, "field_digests": field_digests, "params": [levels, scale, outer, inner, alpha]}))
     batch.shutdown()
 """) % (ROOT, ROOT)
 
@@ -56,6 +61,8 @@ def test_two_rank_sharding_with_gloo(tmp_path):
     assert sorted(outs[0]["mine"] + outs[1]["mine"]) == list(range(5))      # every pair exactly once
     assert outs[0]["slowest"] == outs[1]["slowest"] >= max(o["elapsed"] for o in outs) - 1e-9
     assert outs[0]["digests"] == outs[1]["digests"] and all(d != 0.0 for d in outs[0]["digests"])
+    assert outs[0]["params"] == outs[1]["params"] == [3.0, 0.5, 2.0, 2.0, 35.0]     # rank 0's block everywhere
+    assert outs[0]["field_digests"] == outs[1]["field_digests"] == outs[0]["digests"]  # gathered fields are the fields
     # single-process reference: the digests do not depend on how the pairs were sharded
     sys.path.insert(0, ROOT)
     import numpy as np
