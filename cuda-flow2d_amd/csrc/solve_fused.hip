@@ -20,7 +20,9 @@
 //  - Every pixel goes through exactly the expressions of solve_2d.cu (solver_math.hpp), in the same
 //    order, without FMA contraction: results are bit-identical to the per-sweep kernels and the oracle.
 //
-// Bound: fp32 VALU issue (about 480 instructions per pixel and outer iteration at inner = 5), not HBM.
+// Bound: fp32 VALU issue, not HBM: 368 VALU instructions per wave and row step at inner = 5 (interior strips), a
+// third of them the twelve correctly rounded divisions; measured breakdown and the per-instruction issue rates
+// are in DESIGN.md section 3.1.
 #include <cmath>
 #include <utility>
 
