@@ -219,6 +219,28 @@ def test_graph_replay_matches_eager(flow2d, oracle, ctx):
         flow.close()
 
 
+def test_graph_replay_with_chunked_fused_solver(flow2d, oracle, ctx):
+    """7 sweeps per outer iteration at a fused-kernel level: two launches per outer iteration and, with one outer
+    iteration, the hand-over copy out of the third plane pair -- all inside a recorded graph."""
+    w, h = 640, 528
+    flow = flow2d.OpticalFlow(w, h, 0, ctx=ctx)
+    try:
+        p = flow.params(2, 0.5, 1, 7, 35.0, 0.001, 0.001, 5, 1.5)
+        f0, f1 = oracle.synthetic_pair(w, h, 1.0, 0.5, seed=6, noise=True)
+        planes = [ctx.plane(w, h, f0), ctx.plane(w, h, f1), ctx.plane(w, h), ctx.plane(w, h)]
+        ptrs = [pl.ptr for pl in planes]
+        ou, ov, _ = oracle.compute_flow(f0, f1, 2, 0.5, 1, 7, 35.0, 0.001, 0.001, 5, 1.5)
+        flow.use_graph(True)
+        for _ in range(3):
+            planes[2].fill_bytes(0x55)
+            planes[3].fill_bytes(0x55)
+            flow.compute_flow_device(*ptrs, p)
+            ctx.synchronize()
+            assert np.array_equal(planes[2].download(), ou) and np.array_equal(planes[3].download(), ov)
+    finally:
+        flow.close()
+
+
 @pytest.mark.parametrize("constancy", [0, 1, 2])
 def test_opt_in_sor_pyramid(flow2d, oracle, make_flow, constancy):
     """The opt-in red-black SOR mode end to end (bag key solver_sor_omega) against its oracle restatement.
