@@ -182,6 +182,42 @@ def test_cli_rub_settings_file(flow2d, oracle, tmp_path):
     assert subprocess.call([flow2d.CLI_PATH, "a", "b", "c"], stdout=subprocess.DEVNULL) == 0  # usage
 
 
+def test_config3_full_size_parity(flow2d, oracle, make_flow):
+    """Config 3 as benchmarked (4096^2, Gradient, 8 levels, 10 x 5 sweeps, median 5, sigma 1.5): every pixel of the
+    flow bit-identical to the oracle (OpenMP on the box's cores, some tens of seconds)."""
+    w = h = 4096
+    f0, f1 = oracle.synthetic_pair(w, h, 2.0, 1.0, seed=3)
+    flow = make_flow(w, h, 1)
+    u, v, _ = flow.compute_flow(f0, f1, flow.params(8, 0.5, 10, 5, 35.0, 0.001, 0.001, 5, 1.5))
+    ou, ov, _ = oracle.compute_flow(f0, f1, 8, 0.5, 10, 5, 35.0, 0.001, 0.001, 5, 1.5, 1)
+    assert np.array_equal(u, ou) and np.array_equal(v, ov)
+
+
+def test_config4_frame_size_parity(flow2d, oracle, make_flow):
+    """One pair of config 4's shape (1920 x 1080, Grey, 8 levels: odd level sizes down to 15 x 9)."""
+    w, h = 1920, 1080
+    f0, f1 = oracle.synthetic_pair(w, h, 2.0 * np.cos(3.0), 2.0 * np.sin(3.0), seed=3)
+    flow = make_flow(w, h)
+    u, v, _ = flow.compute_flow(f0, f1, flow.params(8, 0.5, 10, 5, 35.0, 0.001, 0.001, 5, 1.5))
+    ou, ov, _ = oracle.compute_flow(f0, f1, 8, 0.5, 10, 5, 35.0, 0.001, 0.001, 5, 1.5)
+    assert np.array_equal(u, ou) and np.array_equal(v, ov)
+
+
+def test_config5_size_properties(flow2d, oracle, make_flow):
+    """Config 5's size (8192^2, all 12 levels) is beyond a unit-test budget for the CPU oracle, so it is checked
+    through size-independent properties: the fused path (AUTO) and the per-launch path (one launch per reference
+    launch, itself oracle-checked at every smaller size) agree bit for bit, runs are reproducible, outputs finite."""
+    w = h = 8192
+    f0, f1 = oracle.synthetic_pair(w, h, 12.0, -7.0, seed=5)
+    flow = make_flow(w, h)
+    u, v, _ = flow.compute_flow(f0, f1, flow.params(12, 0.5, 2, 5, 35.0, 0.001, 0.001, 5, 1.5))
+    u1, v1, _ = flow.compute_flow(f0, f1, flow.params(12, 0.5, 2, 5, 35.0, 0.001, 0.001, 5, 1.5, flow2d.SOLVER_PER_SWEEP))
+    assert np.array_equal(u, u1) and np.array_equal(v, v1)
+    u2, v2, _ = flow.compute_flow(f0, f1, flow.params(12, 0.5, 2, 5, 35.0, 0.001, 0.001, 5, 1.5))
+    assert np.array_equal(u, u2) and np.array_equal(v, v2)
+    assert np.isfinite(u).all() and np.isfinite(v).all()
+
+
 def test_graph_replay_matches_eager(flow2d, oracle, ctx):
     """A recorded pyramid replayed on new frame contents gives the same bits as eager launches / the oracle."""
     w, h = 160, 96
