@@ -238,6 +238,10 @@ class Context:
     def record(self, ev):
         _check(hip_lib().flow2d_event_record(self.handle, ev), "flow2d_event_record")
 
+    def wait_event(self, ev):
+        """Host wait until everything recorded before `ev` on this context's stream has finished."""
+        _check(hip_lib().flow2d_event_synchronize(self.handle, ev), "flow2d_event_synchronize")
+
     def elapsed_ms(self, start, stop):
         _check(hip_lib().flow2d_event_synchronize(self.handle, stop), "flow2d_event_synchronize")
         ms = C.c_float()
