@@ -23,6 +23,7 @@
 // Bound: fp32 VALU issue, not HBM: 368 VALU instructions per wave and row step at inner = 5 (interior strips), a
 // third of them the twelve correctly rounded divisions; measured breakdown and the per-instruction issue rates
 // are in DESIGN.md section 3.1.
+#include <algorithm>
 #include <cmath>
 #include <utility>
 
@@ -123,7 +124,11 @@ struct Strip {
 // POW2: 2h and 4h are powers of two, so dividing by them is an exact multiply by the reciprocal.
 // CONT: the launch continues the sweeps of an outer iteration (FusedArgs::continue_sweeps); a template value so
 // that the ordinary launch carries none of it.
-template <int INNER, int GRAD, bool EDGE, bool POW2, bool CONT, int J>
+// T: index of the step in the strip's start-up (0 = the strip's first input row), or -1 in the steady state.  A
+// stored row y needs sweep k on rows y-(INNER-k) .. y+(INNER-k) only, so during the first steps of a strip the later
+// stages would work on rows nothing depends on: stage P is first needed at step 2, stage W at step 3, sweep k at
+// step 3 + 2k.  The start-up steps are peeled off the row loop and compiled without those stages.
+template <int INNER, int GRAD, bool EDGE, bool POW2, bool CONT, int J, int T = -1>
 __device__ __forceinline__ void strip_step(Strip<INNER, GRAD>& s, const FusedArgs& a, int r, int x, int xc, bool at_l,
                                            bool at_r, bool lane_stores, int y0, int y1, v2f xpm, float hx_2,
                                            float hy_2)
@@ -164,10 +169,13 @@ __device__ __forceinline__ void strip_step(Strip<INNER, GRAD>& s, const FusedArg
                                          plane_load(plane_rsrc(a.dv, plane_bytes), col_bytes, row_bytes)};
     }
 
+    constexpr bool run_P = T < 0 || T >= 2, run_W = T < 0 || T >= 3;
+    if (T >= 0) __builtin_amdgcn_sched_barrier(0);  // keep the straight-line start-up from being interleaved across steps
+
     // ---- stage P, row rp = r-1: phi, brightness derivatives, ksi (solve_2d.cu:138-197) -------------------
     const int rp = r - 1;
-    float fx, fy, ft, ksi;
-    {
+    float fx = 0.f, fy = 0.f, ft = 0.f, ksi = 0.f;
+    if (run_P) {
         const bool top = EDGE && (rp == 0), bot = EDGE && (rp == h - 1);
         // cross-lane reads happen with every lane active; the border substitution is a select afterwards
         const v2f uv_l0 = from_left2(s.uvw[s1]), uv_r0 = from_right2(s.uvw[s1]);
@@ -208,7 +216,7 @@ __device__ __forceinline__ void strip_step(Strip<INNER, GRAD>& s, const FusedArg
     // ---- stage W, row rw = r-2: face weights and the motion tensor -> coefficient ring --------------------
     // phi ring: slot s1 holds row r-1 (just written), s2 row r-2, s0 row r-3
     const int rw = r - 2;
-    {
+    if (run_W) {
         constexpr int cw = (J + 2 * kRing - 2) % kRing;
         Coef& c = s.C[cw];
         const bool top = EDGE && (rw == 0), bot = EDGE && (rw == h - 1);
@@ -280,6 +288,7 @@ __device__ __forceinline__ void strip_step(Strip<INNER, GRAD>& s, const FusedArg
     float dv_in = dv_row3;  // dv^0 of row r-3
 #pragma unroll
     for (int k = 1; k <= INNER; ++k) {
+        if (T >= 0 && T < 3 + 2 * k) continue;  // start-up: this sweep's row feeds nothing yet
         const int rk = r - 2 - k;
         // window slots of rows rk-1, rk, rk+1 (rk = r-2-k  ->  slot (J - 2 - k) mod 3)
         const int sc = (J + 3 * 8 - 2 - k) % 3, su = (sc + 2) % 3, sd = (sc + 1) % 3;
@@ -314,8 +323,19 @@ __device__ __forceinline__ void strip_steps(Strip<INNER, GRAD>& s, const FusedAr
      ...);
 }
 
+template <int INNER, int GRAD, bool EDGE, bool POW2, bool CONT, size_t... Ts>
+__device__ __forceinline__ void strip_startup(Strip<INNER, GRAD>& s, const FusedArgs& a, int r_first, int x, int xc,
+                                              bool at_l, bool at_r, bool lane_stores, int y0, int y1, v2f xpm,
+                                              float hx_2, float hy_2, std::index_sequence<Ts...>)
+{
+    constexpr int kRing = Strip<INNER, GRAD>::kRing;
+    (strip_step<INNER, GRAD, EDGE, POW2, CONT, static_cast<int>(Ts) % kRing, static_cast<int>(Ts)>(
+         s, a, r_first + static_cast<int>(Ts), x, xc, at_l, at_r, lane_stores, y0, y1, xpm, hx_2, hy_2),
+     ...);
+}
+
 template <int INNER, int GRAD, bool POW2, bool CONT>
-__global__ __launch_bounds__(256) void fused_outer_kernel(FusedArgs a)
+__global__ __launch_bounds__(256, 2) void fused_outer_kernel(FusedArgs a)
 {
     using S = Strip<INNER, GRAD>;
     const int lane = threadIdx.x & 63;
@@ -368,12 +388,18 @@ __global__ __launch_bounds__(256) void fused_outer_kernel(FusedArgs a)
     // does any row or column this wave touches sit on an image border?  (a superset test is fine)
     const int x_first = strip_x * S::kValid - S::kHalo;
     const bool edge = x_first <= 0 || x_first + 63 >= a.w - 1 || y0 <= S::kHalo + 1 || y1 + S::kHalo + 1 >= a.h;
+    // start-up steps (a whole number of ring turns, so the row loop starts at ring position 0), then the row loop
+    constexpr int kPeel = ((3 + 2 * INNER) / S::kRing) * S::kRing;
     if (__builtin_amdgcn_readfirstlane(edge)) {
-        for (int r = r_first; r <= r_last; r += S::kRing)
+        strip_startup<INNER, GRAD, true, POW2, CONT>(s, a, r_first, x, xc, at_l, at_r, lane_stores, y0, y1, xpm, hx_2, hy_2,
+                                                     std::make_index_sequence<kPeel>{});
+        for (int r = r_first + kPeel; r <= r_last; r += S::kRing)
             strip_steps<INNER, GRAD, true, POW2, CONT>(s, a, r, x, xc, at_l, at_r, lane_stores, y0, y1, xpm, hx_2, hy_2,
                                            std::make_index_sequence<S::kRing>{});
     } else {
-        for (int r = r_first; r <= r_last; r += S::kRing)
+        strip_startup<INNER, GRAD, false, POW2, CONT>(s, a, r_first, x, xc, at_l, at_r, lane_stores, y0, y1, xpm, hx_2,
+                                                      hy_2, std::make_index_sequence<kPeel>{});
+        for (int r = r_first + kPeel; r <= r_last; r += S::kRing)
             strip_steps<INNER, GRAD, false, POW2, CONT>(s, a, r, x, xc, at_l, at_r, lane_stores, y0, y1, xpm, hx_2, hy_2,
                                             std::make_index_sequence<S::kRing>{});
     }
@@ -414,9 +440,12 @@ bool fused_supports(size_t inner) { return inner >= 1 && inner <= 5; }
 
 // Rows per strip.  A wave spends (rows + 2*inner + 3) row steps on `rows` stored rows, so tall strips
 // waste less; but the launch should fill the chip in whole co-resident rounds (two 256-thread
-// workgroups per CU at ~190 VGPRs).  Cost model in row steps: a full round of 2 workgroups per CU
+// workgroups per CU at ~200 VGPRs).  Cost model in row steps: a full round of 2 workgroups per CU
 // costs 2 * steps (VALU-issue bound), a last round with at most one workgroup per CU 1.3 * steps
-// (a lone wave per SIMD cannot saturate the VALU).  Pick the strip height with the smallest estimate.
+// (a lone wave per SIMD cannot saturate the VALU).  The peeled start-up steps run without the stages whose
+// rows nothing depends on yet (strip_step), which is worth about six whole steps at inner = 5; the estimate
+// below weighs the stages by their instruction counts (stage P 102, stage W 20, a sweep 46, the rest 16).
+// Pick the strip height with the smallest estimate.
 int fused_rows_per_strip(const flow2d_context* ctx, size_t w, size_t h, size_t inner)
 {
     const int valid = 64 - 2 * ((int)inner + 1);
@@ -424,13 +453,17 @@ int fused_rows_per_strip(const flow2d_context* ctx, size_t w, size_t h, size_t i
     const long cus = ctx->num_cus > 0 ? ctx->num_cus : 256;
     const long cap = cus * 2;
     const int ring = (((int)inner + 1 + 2) / 3) * 3;
+    const int peel = ((3 + 2 * (int)inner) / ring) * ring;
+    double saved = 2 * 102.0 + 3 * 20.0;
+    for (int k = 1; k <= (int)inner; ++k) saved += 46.0 * std::min(3 + 2 * k, peel);
+    const double saved_steps = saved / (138.0 + 46.0 * (double)inner);
     double best = 1e300;
     int best_rows = 4;
     for (long ny = 1; ny <= (long)((h + 3) / 4); ++ny) {
         const long rows = (long)((h + ny - 1) / ny);
         if (rows < 4) break;
         if ((long)((h + rows - 1) / rows) != ny) continue;  // same ny reachable with fewer rows: skip duplicates
-        const long steps = ((rows + 2 * (long)inner + 3 + ring - 1) / ring) * ring;
+        const double steps = (double)(((rows + 2 * (long)inner + 3 + ring - 1) / ring) * ring) - saved_steps;
         const long blocks = blocks_x * ny;
         const long full = blocks / cap, rem = blocks % cap;
         const double cost = full * 2.0 * steps + (rem == 0 ? 0.0 : (rem <= cus ? 1.3 * steps : 2.0 * steps));
