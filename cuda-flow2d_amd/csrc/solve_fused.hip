@@ -323,6 +323,19 @@ __device__ __forceinline__ void strip_steps(Strip<INNER, GRAD>& s, const FusedAr
      ...);
 }
 
+// the last, partial turn of the ring: the steps up to r_last only (wave-uniform guards)
+template <int INNER, int GRAD, bool EDGE, bool POW2, bool CONT, size_t... Js>
+__device__ __forceinline__ void strip_tail(Strip<INNER, GRAD>& s, const FusedArgs& a, int r_base, int r_last, int x, int xc,
+                                           bool at_l, bool at_r, bool lane_stores, int y0, int y1, v2f xpm, float hx_2,
+                                           float hy_2, std::index_sequence<Js...>)
+{
+    ((r_base + static_cast<int>(Js) <= r_last
+          ? strip_step<INNER, GRAD, EDGE, POW2, CONT, static_cast<int>(Js)>(s, a, r_base + static_cast<int>(Js), x, xc, at_l,
+                                                                          at_r, lane_stores, y0, y1, xpm, hx_2, hy_2)
+          : (void)0),
+     ...);
+}
+
 template <int INNER, int GRAD, bool EDGE, bool POW2, bool CONT, size_t... Ts>
 __device__ __forceinline__ void strip_startup(Strip<INNER, GRAD>& s, const FusedArgs& a, int r_first, int x, int xc,
                                               bool at_l, bool at_r, bool lane_stores, int y0, int y1, v2f xpm,
@@ -393,15 +406,21 @@ __global__ __launch_bounds__(256, 2) void fused_outer_kernel(FusedArgs a)
     if (__builtin_amdgcn_readfirstlane(edge)) {
         strip_startup<INNER, GRAD, true, POW2, CONT>(s, a, r_first, x, xc, at_l, at_r, lane_stores, y0, y1, xpm, hx_2, hy_2,
                                                      std::make_index_sequence<kPeel>{});
-        for (int r = r_first + kPeel; r <= r_last; r += S::kRing)
+        int r = r_first + kPeel;
+        for (; r + S::kRing - 1 <= r_last; r += S::kRing)
             strip_steps<INNER, GRAD, true, POW2, CONT>(s, a, r, x, xc, at_l, at_r, lane_stores, y0, y1, xpm, hx_2, hy_2,
                                            std::make_index_sequence<S::kRing>{});
+        strip_tail<INNER, GRAD, true, POW2, CONT>(s, a, r, r_last, x, xc, at_l, at_r, lane_stores, y0, y1, xpm, hx_2, hy_2,
+                                                  std::make_index_sequence<S::kRing - 1>{});
     } else {
         strip_startup<INNER, GRAD, false, POW2, CONT>(s, a, r_first, x, xc, at_l, at_r, lane_stores, y0, y1, xpm, hx_2,
                                                       hy_2, std::make_index_sequence<kPeel>{});
-        for (int r = r_first + kPeel; r <= r_last; r += S::kRing)
+        int r = r_first + kPeel;
+        for (; r + S::kRing - 1 <= r_last; r += S::kRing)
             strip_steps<INNER, GRAD, false, POW2, CONT>(s, a, r, x, xc, at_l, at_r, lane_stores, y0, y1, xpm, hx_2, hy_2,
                                             std::make_index_sequence<S::kRing>{});
+        strip_tail<INNER, GRAD, false, POW2, CONT>(s, a, r, r_last, x, xc, at_l, at_r, lane_stores, y0, y1, xpm, hx_2, hy_2,
+                                                   std::make_index_sequence<S::kRing - 1>{});
     }
 }
 
@@ -463,7 +482,7 @@ int fused_rows_per_strip(const flow2d_context* ctx, size_t w, size_t h, size_t i
         const long rows = (long)((h + ny - 1) / ny);
         if (rows < 4) break;
         if ((long)((h + rows - 1) / rows) != ny) continue;  // same ny reachable with fewer rows: skip duplicates
-        const double steps = (double)(((rows + 2 * (long)inner + 3 + ring - 1) / ring) * ring) - saved_steps;
+        const double steps = (double)(rows + 2 * (long)inner + 3) - saved_steps;  // the last ring turn is partial
         const long blocks = blocks_x * ny;
         const long full = blocks / cap, rem = blocks % cap;
         const double cost = full * 2.0 * steps + (rem == 0 ? 0.0 : (rem <= cus ? 1.3 * steps : 2.0 * steps));
