@@ -376,6 +376,8 @@ def host_lib():
         L.flow2d_host_max_warp_level.argtypes = [vp, sz, sz, f]
         L.flow2d_host_compute_flow.argtypes = [vp, fp, fp, fp, fp, C.POINTER(HostParams), fp]
         L.flow2d_host_compute_flow_device.argtypes = [vp, vp, vp, vp, vp, C.POINTER(HostParams), i]
+        L.flow2d_host_compute_flow_sequence_device.argtypes = [vp, C.POINTER(vp), sz, C.POINTER(vp), C.POINTER(vp),
+                                                               C.POINTER(HostParams)]
         L.flow2d_host_level_timings.restype = sz
         L.flow2d_host_level_timings.argtypes = [vp, fp, sz]
         L.flow2d_host_reset_timings.argtypes = [vp]
@@ -447,6 +449,19 @@ class OpticalFlow:
                                                         int(timing_mode))
         if rc:
             raise Flow2DError(rc, "OpticalFlow2D::ComputeFlowDevice")
+
+    def compute_flow_sequence_device(self, dev_frames, dev_us, dev_vs, params):
+        """Flows of an image sequence: flow k goes from dev_frames[k] to dev_frames[k + 1] into (dev_us[k], dev_vs[k]).
+        Every frame's blurred plane and pyramid levels are computed once.  Queued, not synchronised."""
+        n = len(dev_frames)
+        if n < 2 or len(dev_us) != n - 1 or len(dev_vs) != n - 1:
+            raise ValueError("a sequence of n frames takes n - 1 flow plane pairs")
+        frames = (C.c_void_p * n)(*dev_frames)
+        us = (C.c_void_p * (n - 1))(*dev_us)
+        vs = (C.c_void_p * (n - 1))(*dev_vs)
+        rc = host_lib().flow2d_host_compute_flow_sequence_device(self.handle, frames, n, us, vs, C.byref(params))
+        if rc:
+            raise Flow2DError(rc, "OpticalFlow2D::ComputeFlowSequenceDevice")
 
     def level_timings(self):
         """[(width, height, solve_ms, kernel_ms, kernel_launches, algorithmic_bytes_per_launch)] per level."""

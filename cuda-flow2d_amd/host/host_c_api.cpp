@@ -120,6 +120,26 @@ HOST_API int flow2d_host_compute_flow_device(flow2d_host_flow* h, void* dev_fram
     return h->flow.ComputeFlowDevice(dp(dev_frame_0), dp(dev_frame_1), dp(dev_flow_u), dp(dev_flow_v), bag) ? 0 : 2;
 }
 
+// OpticalFlow2D::ComputeFlowSequenceDevice: frame_count device frames, frame_count - 1 flow plane pairs.
+HOST_API int flow2d_host_compute_flow_sequence_device(flow2d_host_flow* h, void* const* dev_frames, size_t frame_count,
+                                                      void* const* dev_flows_u, void* const* dev_flows_v,
+                                                      const flow2d_host_params* params)
+{
+    if (!h || !params || !dev_frames || !dev_flows_u || !dev_flows_v || frame_count < 2) return 1;
+    flow2d_host_params p = *params;
+    OperationParameters bag;
+    FillBag(bag, p);
+    h->flow.timing_mode = 0;
+    auto dp = [](void* q) { return static_cast<DevicePtr>(reinterpret_cast<uintptr_t>(q)); };
+    std::vector<DevicePtr> frames(frame_count), us(frame_count - 1), vs(frame_count - 1);
+    for (size_t k = 0; k < frame_count; ++k) frames[k] = dp(dev_frames[k]);
+    for (size_t k = 0; k + 1 < frame_count; ++k) {
+        us[k] = dp(dev_flows_u[k]);
+        vs[k] = dp(dev_flows_v[k]);
+    }
+    return h->flow.ComputeFlowSequenceDevice(frames.data(), frame_count, us.data(), vs.data(), bag) ? 0 : 2;
+}
+
 // Per-level solve records of the last run (needs timing_mode >= 1 and a synchronised context).
 // Writes up to `capacity` records of 6 floats (width, height, solve_ms, kernel_ms, kernel_launches,
 // algorithmic bytes per launch) and returns the number of levels.

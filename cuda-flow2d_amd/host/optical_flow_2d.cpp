@@ -118,6 +118,7 @@ void OpticalFlow2D::Destroy()
     if (context_) {
         if (!all_planes_.empty()) flow2d_synchronize(context_);
         DropGraphs();
+        FreeSequenceCache();
         if (free_planes_.size() != all_planes_.size())
             std::printf("Warning. Not all device memory allocations were freed.\n");
         for (DevicePtr p : all_planes_) flow2d_plane_free(context_, AsPlane(p));
@@ -135,6 +136,95 @@ DevicePtr OpticalFlow2D::Acquire()
 }
 
 void OpticalFlow2D::Release(DevicePtr p) { free_planes_.push_back(p); }
+
+void OpticalFlow2D::FreeSequenceCache()
+{
+    for (FramePyramid& pyramid : sequence_cache_) {
+        if (context_) {
+            if (pyramid.blurred) flow2d_plane_free(context_, AsPlane(pyramid.blurred));
+            for (DevicePtr p : pyramid.levels)
+                if (p) flow2d_plane_free(context_, AsPlane(p));
+        }
+        pyramid = FramePyramid();
+    }
+}
+
+// The plane of `pyramid` that holds pyramid level `level` (>= 1): container width, `rows` rows, same pitch as the
+// 12 containers.  Allocated on first use and whenever a later call needs more rows.  0 on failure.
+DevicePtr OpticalFlow2D::SequenceLevelPlane(FramePyramid& pyramid, size_t level, size_t rows)
+{
+    if (pyramid.levels.size() <= level) {
+        pyramid.levels.resize(level + 1, 0);
+        pyramid.level_rows.resize(level + 1, 0);
+    }
+    if (pyramid.levels[level] && pyramid.level_rows[level] >= rows) return pyramid.levels[level];
+    if (pyramid.levels[level]) {
+        flow2d_synchronize(context_);  // the old plane may still be read by queued work
+        flow2d_plane_free(context_, AsPlane(pyramid.levels[level]));
+        pyramid.levels[level] = 0;
+    }
+    void* plane = nullptr;
+    size_t pitch = 0;
+    if (CheckFlow2DError(flow2d_plane_alloc(context_, dev_container_size_.width, rows, &plane, &pitch), "flow2d_plane_alloc"))
+        return 0;
+    if (pitch != dev_container_size_.pitch) {
+        flow2d_plane_free(context_, static_cast<float*>(plane));
+        std::printf("Error: '%s': sequence cache pitch %zu differs from the container pitch %zu.\n", GetName(), pitch,
+                    dev_container_size_.pitch);
+        return 0;
+    }
+    pyramid.levels[level] = static_cast<DevicePtr>(reinterpret_cast<uintptr_t>(plane));
+    pyramid.level_rows[level] = rows;
+    return pyramid.levels[level];
+}
+
+bool OpticalFlow2D::ComputeFlowSequenceDevice(const DevicePtr* dev_frames, size_t frame_count, const DevicePtr* dev_flows_u,
+                                              const DevicePtr* dev_flows_v, OperationParameters& params)
+{
+    if (!IsInitialized() || !dev_frames || !dev_flows_u || !dev_flows_v || frame_count < 2) return false;
+    for (size_t k = 0; k < frame_count; ++k)
+        if (!dev_frames[k] || (k + 1 < frame_count && (!dev_flows_u[k] || !dev_flows_v[k]))) return false;
+    float gaussian_sigma = 0.f;
+    params.Read<float>("gaussian_sigma", gaussian_sigma);
+    for (FramePyramid& pyramid : sequence_cache_) {
+        pyramid.valid = false;
+        if (gaussian_sigma > 0.f && !pyramid.blurred) {  // a plane for the blurred frame
+            void* plane = nullptr;
+            size_t pitch = 0;
+            if (CheckFlow2DError(flow2d_plane_alloc(context_, dev_container_size_.width, dev_container_size_.height,
+                                                    &plane, &pitch),
+                                 "flow2d_plane_alloc") ||
+                pitch != dev_container_size_.pitch)
+                return false;
+            pyramid.blurred = static_cast<DevicePtr>(reinterpret_cast<uintptr_t>(plane));
+        }
+    }
+    bool ok = true;
+    for (size_t k = 0; ok && k + 1 < frame_count; ++k) {
+        FramePyramid& first = sequence_cache_[k % 2];          // frame k: built as the second frame of pair k-1
+        FramePyramid& second = sequence_cache_[(k + 1) % 2];   // frame k+1: built by this pair
+        second.valid = false;
+        sequence_frames_[0] = &first;
+        sequence_frames_[1] = &second;
+        dev_frame_0_ = Acquire();  // unused by a sequence pair, kept for the pool's bookkeeping
+        dev_frame_1_ = Acquire();
+        dev_flow_u_ = Acquire();
+        dev_flow_v_ = Acquire();
+        caller_frame_0_ = dev_frames[k];
+        caller_frame_1_ = dev_frames[k + 1];
+        caller_flow_u_ = dev_flows_u[k];
+        caller_flow_v_ = dev_flows_v[k];
+        ok = RunPyramid(params);
+        caller_frame_0_ = caller_frame_1_ = caller_flow_u_ = caller_flow_v_ = 0;
+        sequence_frames_[0] = sequence_frames_[1] = nullptr;
+        Release(dev_frame_0_);
+        Release(dev_frame_1_);
+        Release(dev_flow_u_);
+        Release(dev_flow_v_);
+        if (ok) first.valid = second.valid = true;
+    }
+    return ok;
+}
 
 void OpticalFlow2D::ResetLevelTimings()
 {
@@ -352,7 +442,31 @@ bool OpticalFlow2D::RunPyramid(OperationParameters& params)
     DevicePtr frame_0_res = Acquire(), frame_1_res = Acquire(), flow_du = Acquire(), flow_dv = Acquire();
     OperationParameters op;
 
-    if (gaussian_sigma > 0.0 && caller_frame_0_) {  // frames still in the caller's planes: blur them into ours
+    const bool sequence = sequence_frames_[0] != nullptr;
+    if (sequence) {  // a frame's level 0 is blurred once (or is the caller's own plane) and then only read
+        DevicePtr callers[2] = {caller_frame_0_, caller_frame_1_};
+        DevicePtr* level0[2] = {&frame_0, &frame_1};
+        DevicePtr temp = Acquire();
+        for (int i = 0; i < 2; ++i) {
+            FramePyramid& pyramid = *sequence_frames_[i];
+            if (gaussian_sigma > 0.0) {
+                pyramid.level0 = pyramid.blurred;
+                if (!pyramid.valid) {
+                    op.Clear();
+                    op.PushValuePtr("dev_input", &callers[i]);
+                    op.PushValuePtr("dev_output", &pyramid.level0);
+                    op.PushValuePtr("dev_temp", &temp);
+                    op.PushValuePtr("data_size", &original_size);
+                    op.PushValuePtr("gaussian_sigma", &gaussian_sigma);
+                    cuop_convolution_.Execute(op);
+                }
+            } else {
+                pyramid.level0 = callers[i];
+            }
+            *level0[i] = pyramid.level0;
+        }
+        Release(temp);
+    } else if (gaussian_sigma > 0.0 && caller_frame_0_) {  // frames still in the caller's planes: blur them into ours
         DevicePtr temp = Acquire();
         DevicePtr sources[2] = {caller_frame_0_, caller_frame_1_};
         DevicePtr* targets[2] = {&frame_0, &frame_1};
@@ -392,7 +506,33 @@ bool OpticalFlow2D::RunPyramid(OperationParameters& params)
         if (!silent) std::printf("Solve level %2d (%4zu x%4zu) \n", level, current_size.width, current_size.height);
 
         // frames: level 0 uses the (blurred) full-resolution planes, others are resampled from them
-        if (level == 0) {
+        DevicePtr sequence_level[2] = {frame_0, frame_1};  // sequence only: this level's read-only frame planes
+        if (sequence) {
+            DevicePtr temp = level > 0 ? Acquire() : 0;
+            for (int i = 0; i < 2 && level > 0; ++i) {
+                FramePyramid& pyramid = *sequence_frames_[i];
+                DevicePtr plane = SequenceLevelPlane(pyramid, static_cast<size_t>(level), current_size.height);
+                if (!plane) {
+                    Release(temp);
+                    Release(frame_0_res);
+                    Release(frame_1_res);
+                    Release(flow_du);
+                    Release(flow_dv);
+                    return false;
+                }
+                if (!pyramid.valid) {
+                    op.Clear();
+                    op.PushValuePtr("dev_input", i == 0 ? &frame_0 : &frame_1);
+                    op.PushValuePtr("dev_output", &plane);
+                    op.PushValuePtr("dev_temp", &temp);
+                    op.PushValuePtr("data_size", &original_size);
+                    op.PushValuePtr("resample_size", &current_size);
+                    cuop_resample_.Execute(op);
+                }
+                sequence_level[i] = plane;
+            }
+            if (temp) Release(temp);
+        } else if (level == 0) {
             std::swap(frame_0, frame_0_res);
             std::swap(frame_1, frame_1_res);
         } else {
@@ -431,7 +571,20 @@ bool OpticalFlow2D::RunPyramid(OperationParameters& params)
             Release(temp);
         }
 
-        {  // backward registration of frame 1 by the current flow; the warped frame replaces it
+        DevicePtr solve_frame_0 = frame_0_res;  // what the solver reads as frame 0 of this level
+        if (sequence) {  // the level planes are kept for the next pair: warp into the pool plane, read the rest
+            op.Clear();
+            op.PushValuePtr("dev_frame_0", &sequence_level[0]);
+            op.PushValuePtr("dev_frame_1", &sequence_level[1]);
+            op.PushValuePtr("dev_flow_u", &flow_u);
+            op.PushValuePtr("dev_flow_v", &flow_v);
+            op.PushValuePtr("dev_output", &frame_1_res);
+            op.PushValuePtr("data_size", &current_size);
+            op.PushValuePtr("hx", &hx);
+            op.PushValuePtr("hy", &hy);
+            cuop_register_.Execute(op);
+            solve_frame_0 = sequence_level[0];
+        } else {  // backward registration of frame 1 by the current flow; the warped frame replaces it
             DevicePtr temp = Acquire();
             op.Clear();
             op.PushValuePtr("dev_frame_0", &frame_0_res);
@@ -450,7 +603,7 @@ bool OpticalFlow2D::RunPyramid(OperationParameters& params)
         {  // lagged-diffusivity fixed point: the hot loop
             DevicePtr phi = Acquire(), ksi = Acquire(), temp_du = Acquire(), temp_dv = Acquire();
             op.Clear();
-            op.PushValuePtr("dev_frame_0", &frame_0_res);
+            op.PushValuePtr("dev_frame_0", &solve_frame_0);
             op.PushValuePtr("dev_frame_1", &frame_1_res);
             op.PushValuePtr("dev_flow_u", &flow_u);
             op.PushValuePtr("dev_flow_v", &flow_v);
@@ -511,8 +664,10 @@ bool OpticalFlow2D::RunPyramid(OperationParameters& params)
     }
 
     // hand the roles back: the caller reads the flow from dev_flow_u_/v_ and releases all four
-    dev_frame_0_ = frame_0;
-    dev_frame_1_ = frame_1;
+    if (!sequence) {  // (a sequence pair's frame planes belong to the sequence cache or to the caller)
+        dev_frame_0_ = frame_0;
+        dev_frame_1_ = frame_1;
+    }
     dev_flow_u_ = flow_u;
     dev_flow_v_ = flow_v;
     Release(frame_0_res);

@@ -74,6 +74,13 @@ public:
     bool ComputeFlowDevice(DevicePtr dev_frame_0, DevicePtr dev_frame_1, DevicePtr dev_flow_u, DevicePtr dev_flow_v,
                            OperationParameters& params);
 
+    // Flows of an image sequence: flow k is the flow from frames[k] to frames[k + 1] (frame_count - 1 flows), each
+    // bit-identical to ComputeFlowDevice on that pair.  Every frame's pre-blurred plane and pyramid levels are
+    // computed once and serve first as the second, then as the first frame of consecutive pairs.
+    // Frames are only read; queued on the context's stream, launched eagerly (no graph).
+    bool ComputeFlowSequenceDevice(const DevicePtr* dev_frames, size_t frame_count, const DevicePtr* dev_flows_u,
+                                   const DevicePtr* dev_flows_v, OperationParameters& params);
+
     // When set, ComputeFlowDevice records the whole pyramid of a pair into a HIP graph the first time it
     // sees a (buffers, parameters) combination and replays it afterwards: one host call instead of
     // several hundred launches.  Ignored while timing_mode != 0 (events are not captured).
@@ -108,6 +115,19 @@ private:
     // ComputeFlowDevice only: the caller's planes.  With a pre-blur the frames are read once (by the blur), so
     // they are read in place instead of copied; the last level's median writes the caller's flow planes.
     DevicePtr caller_frame_0_ = 0, caller_frame_1_ = 0, caller_flow_u_ = 0, caller_flow_v_ = 0;
+    // ComputeFlowSequenceDevice only: a frame's blurred full-resolution plane (level 0; the caller's own plane when
+    // there is no pre-blur) and its resampled levels, kept from one pair to the next.
+    struct FramePyramid {
+        DevicePtr blurred = 0;             // owned: the pre-blurred frame (allocated on first use)
+        DevicePtr level0 = 0;              // what level 0 reads: `blurred`, or the caller's plane without a pre-blur
+        std::vector<DevicePtr> levels;     // [l] for l >= 1, container width x level height
+        std::vector<size_t> level_rows;
+        bool valid = false;
+    };
+    FramePyramid sequence_cache_[2];
+    FramePyramid* sequence_frames_[2] = {nullptr, nullptr};  // non-null inside a sequence pair: frame 0 / frame 1
+    DevicePtr SequenceLevelPlane(FramePyramid& pyramid, size_t level, size_t rows);
+    void FreeSequenceCache();
     flow2d_context* context_ = nullptr;
     float last_total_ms_ = 0.f;
     // recorded pyramids, keyed by the caller buffers and parameters they were recorded for

@@ -218,6 +218,42 @@ def test_config5_size_properties(flow2d, oracle, make_flow):
     assert np.isfinite(u).all() and np.isfinite(v).all()
 
 
+@pytest.mark.parametrize("w,h,levels,outer,inner,sigma,constancy", [
+    (200, 120, 4, 2, 3, 1.5, 0),     # pre-blur: every frame blurred and resampled once
+    (200, 120, 4, 2, 3, 0.0, 1),     # no pre-blur: the callers' planes are level 0 themselves
+    (640, 528, 3, 1, 5, 1.5, 1),     # a fused-kernel level
+])
+def test_sequence_matches_pairwise(flow2d, oracle, ctx, w, h, levels, outer, inner, sigma, constancy):
+    """ComputeFlowSequenceDevice: flow k of the sequence is bit-identical to the pair (k, k+1) computed on its
+    own (and the first one to the oracle); frames are left untouched; a second call reuses the cache planes."""
+    flow = flow2d.OpticalFlow(w, h, constancy, ctx=ctx)
+    try:
+        p = flow.params(levels, 0.5, outer, inner, 35.0, 0.001, 0.001, 5, sigma)
+        shifts = [(0.0, 0.0), (1.5, -0.75), (2.5, 0.5), (4.0, 1.0), (3.0, 2.5)]
+        frames = [oracle.synthetic_pair(w, h, dx, dy, seed=7 + k, noise=True)[1] for k, (dx, dy) in enumerate(shifts)]
+        planes = [ctx.plane(w, h, f) for f in frames]
+        n = len(frames)
+        us, vs = [ctx.plane(w, h) for _ in range(n - 1)], [ctx.plane(w, h) for _ in range(n - 1)]
+        pu, pv = ctx.plane(w, h), ctx.plane(w, h)
+        for rep in range(2):
+            for pl in us + vs:
+                pl.fill_bytes(0x33)
+            flow.compute_flow_sequence_device([pl.ptr for pl in planes], [pl.ptr for pl in us], [pl.ptr for pl in vs], p)
+            ctx.synchronize()
+            for k in range(n - 1):
+                flow.compute_flow_device(planes[k].ptr, planes[k + 1].ptr, pu.ptr, pv.ptr, p)
+                ctx.synchronize()
+                assert np.array_equal(us[k].download(), pu.download()), "u of pair %d" % k
+                assert np.array_equal(vs[k].download(), pv.download()), "v of pair %d" % k
+        ou, ov, _ = oracle.compute_flow(frames[0], frames[1], levels, 0.5, outer, inner, 35.0, 0.001, 0.001, 5, sigma,
+                                        constancy)
+        assert np.array_equal(us[0].download(), ou) and np.array_equal(vs[0].download(), ov)
+        for pl, f in zip(planes, frames):
+            assert np.array_equal(pl.download(), f)
+    finally:
+        flow.close()
+
+
 def test_graph_replay_matches_eager(flow2d, oracle, ctx):
     """A recorded pyramid replayed on new frame contents gives the same bits as eager launches / the oracle."""
     w, h = 160, 96
