@@ -80,11 +80,12 @@ int flow2d_solve_level(flow2d_context* ctx, const float* frame_0, const float* f
     if (sor && p->algorithm != FLOW2D_SOLVER_AUTO && p->algorithm != FLOW2D_SOLVER_PER_SWEEP) return FLOW2D_ERR_UNSUPPORTED;
     int algorithm = sor ? FLOW2D_SOLVER_PER_SWEEP : p->algorithm;
     if (algorithm == FLOW2D_SOLVER_AUTO) {
-        // Below ~512^2 both forms are launch/latency bound and the per-sweep kernels are marginally
-        // quicker (measured on MI355X, profiles/r01_*); above, the fused kernel wins by 1.7-2.9x.
         // Up to 64 x 32 the whole level runs in one launch on one CU (solve_small.hip; measured 0.06-0.10 ms
         // against 0.16-0.19 ms for 60 per-sweep launches; at 64 x 64 four pixels per thread spill and lose).
-        const bool big = p->width * p->height >= 512 * 512 && p->inner_iterations_count >= 2;
+        // Everything else goes through the fused kernel: since its strip start-up is peeled it also wins on the
+        // launch-bound levels (10 launches of ~15 us instead of 60 of ~4 us: 0.15 against 0.21 ms at 64^2 .. 256^2),
+        // and above 512^2 it wins by 1.7-2.9x.  A single sweep per outer iteration leaves nothing to fuse.
+        const bool big = p->inner_iterations_count >= 2;
         if (flow2d::small_level_supports(p->width, p->height) && p->height <= 32)
             algorithm = FLOW2D_SOLVER_SINGLE_WORKGROUP;
         else

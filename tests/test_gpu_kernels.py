@@ -150,7 +150,7 @@ def test_solve_level(ctx, oracle, w, h, cw, ch, outer, inner, constancy, algorit
     # which pair holds the result: per-sweep = the reference's swap parity (cuda_operation_solve_2d.cpp:288-289),
     # fused = one swap per outer iteration; either way the library reports it
     single = algorithm == 0 and w <= 64 and h <= 32
-    fused = algorithm == 2 or (algorithm == 0 and not single and w * h >= 512 * 512 and inner >= 2)
+    fused = algorithm == 2 or (algorithm == 0 and not single and inner >= 2)
     launches = 0 if single else (outer if fused else outer * inner)
     assert (rdu is tdu) == (launches % 2 == 1)
 
