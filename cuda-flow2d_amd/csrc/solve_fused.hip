@@ -477,10 +477,10 @@ int fused_rows_per_strip(const flow2d_context* ctx, size_t w, size_t h, size_t i
     for (int k = 1; k <= (int)inner; ++k) saved += 46.0 * std::min(3 + 2 * k, peel);
     const double saved_steps = saved / (138.0 + 46.0 * (double)inner);
     double best = 1e300;
-    int best_rows = 4;
-    for (long ny = 1; ny <= (long)((h + 3) / 4); ++ny) {
+    int best_rows = 1;
+    for (long ny = 1; ny <= (long)h; ++ny) {
         const long rows = (long)((h + ny - 1) / ny);
-        if (rows < 4) break;
+        if (rows < 1) break;
         if ((long)((h + rows - 1) / rows) != ny) continue;  // same ny reachable with fewer rows: skip duplicates
         const double steps = (double)(rows + 2 * (long)inner + 3) - saved_steps;  // the last ring turn is partial
         const long blocks = blocks_x * ny;
