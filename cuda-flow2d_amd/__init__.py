@@ -107,6 +107,10 @@ def hip_lib():
         L.flow2d_registration_2d.argtypes = [vp, vp, vp, vp, vp, sz, sz, sz, f, f, vp]
         L.flow2d_resample_x.argtypes = [vp, vp, vp, sz, sz, sz, sz]
         L.flow2d_resample_y.argtypes = [vp, vp, vp, sz, sz, sz, sz]
+        L.flow2d_add_2d_pair.argtypes = [vp, vp, vp, vp, vp, sz, sz, sz]
+        L.flow2d_median_2d_pair.argtypes = [vp, vp, vp, sz, sz, sz, sz, vp, vp]
+        L.flow2d_resample_x_pair.argtypes = [vp, vp, vp, vp, vp, sz, sz, sz, sz]
+        L.flow2d_resample_y_pair.argtypes = [vp, vp, vp, vp, vp, sz, sz, sz, sz]
         L.flow2d_compute_phi_ksi.argtypes = [vp] * 7 + [sz, sz, sz, f, f, f, f, vp, vp]
         L.flow2d_solve_2d.argtypes = [vp] * 9 + [sz, sz, sz, f, f, f, vp, vp]
         L.flow2d_solve_2d_grad.argtypes = [vp] * 9 + [sz, sz, sz, f, f, f, vp, vp]
@@ -283,6 +287,23 @@ class Context:
     def resample_y(self, src, dst, out_w, out_h, in_h):
         _check(hip_lib().flow2d_resample_y(self.handle, src.ptr, dst.ptr, out_w, out_h, in_h, src.pitch),
                "flow2d_resample_y")
+
+    # two planes of the same geometry per launch
+    def add_pair(self, op0_a, op1_a, op0_b, op1_b, w, h):
+        _check(hip_lib().flow2d_add_2d_pair(self.handle, op0_a.ptr, op1_a.ptr, op0_b.ptr, op1_b.ptr, w, h, op0_a.pitch),
+               "flow2d_add_2d_pair")
+
+    def median_pair(self, src_a, src_b, w, h, window, dst_a, dst_b):
+        _check(hip_lib().flow2d_median_2d_pair(self.handle, src_a.ptr, src_b.ptr, w, h, src_a.pitch, window, dst_a.ptr,
+                                               dst_b.ptr), "flow2d_median_2d_pair")
+
+    def resample_x_pair(self, src_a, dst_a, src_b, dst_b, out_w, out_h, in_w):
+        _check(hip_lib().flow2d_resample_x_pair(self.handle, src_a.ptr, dst_a.ptr, src_b.ptr, dst_b.ptr, out_w, out_h,
+                                                in_w, src_a.pitch), "flow2d_resample_x_pair")
+
+    def resample_y_pair(self, src_a, dst_a, src_b, dst_b, out_w, out_h, in_h):
+        _check(hip_lib().flow2d_resample_y_pair(self.handle, src_a.ptr, dst_a.ptr, src_b.ptr, dst_b.ptr, out_w, out_h,
+                                                in_h, src_a.pitch), "flow2d_resample_y_pair")
 
     def compute_phi_ksi(self, f0, f1, u, v, du, dv, w, h, hx, hy, e_smooth, e_data, phi, ksi):
         _check(hip_lib().flow2d_compute_phi_ksi(self.handle, f0.ptr, f1.ptr, u.ptr, v.ptr, du.ptr, dv.ptr, w, h,

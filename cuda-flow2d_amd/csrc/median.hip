@@ -83,10 +83,14 @@ __device__ __forceinline__ void run_network(float (&v)[N], std::index_sequence<I
         ...);
 }
 
+// (grid.z = 2 filters a second, independent plane in the same launch: the flow's u and v)
 template <int R>
-__global__ __launch_bounds__(256) void median_kernel(const float* __restrict__ in, int w, int h, int pitch,
-                                                     float* __restrict__ out)
+__global__ __launch_bounds__(256) void median_kernel(const float* __restrict__ in_a, const float* __restrict__ in_b, int w,
+                                                     int h, int pitch, float* __restrict__ out_a,
+                                                     float* __restrict__ out_b)
 {
+    const float* __restrict__ in = blockIdx.z ? in_b : in_a;
+    float* __restrict__ out = blockIdx.z ? out_b : out_a;
     constexpr int R2 = R / 2;
     constexpr int N = R * R;
     const int x = blockIdx.x * kBlockX + threadIdx.x;
@@ -246,9 +250,13 @@ __device__ __forceinline__ void median5_strip(const float* __restrict__ in, floa
     }
 }
 
-__global__ __launch_bounds__(256) void median5_stream_kernel(const float* __restrict__ in, int w, int h, int pitch,
-                                                             int rows_per_strip, float* __restrict__ out)
+__global__ __launch_bounds__(256) void median5_stream_kernel(const float* __restrict__ in_a,
+                                                             const float* __restrict__ in_b, int w, int h, int pitch,
+                                                             int rows_per_strip, float* __restrict__ out_a,
+                                                             float* __restrict__ out_b)
 {
+    const float* __restrict__ in = blockIdx.z ? in_b : in_a;
+    float* __restrict__ out = blockIdx.z ? out_b : out_a;
     const int lane = threadIdx.x & 63;
     const int strip = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int x_first = strip * kStreamValid - 2;
@@ -278,31 +286,50 @@ int median5_rows_per_strip(const flow2d_context* ctx, size_t w, size_t h)
 
 }  // namespace
 
-extern "C" int flow2d_median_2d(flow2d_context* ctx, const float* input, size_t width, size_t height,
-                                size_t pitch_bytes, size_t window, float* output)
+static int launch_median(flow2d_context* ctx, const float* input, const float* input_b, size_t width, size_t height,
+                         size_t pitch_bytes, size_t window, float* output, float* output_b)
 {
     FLOW2D_ENTER(ctx);
     if (!flow2d::plane_args_ok(input, width, height, pitch_bytes) ||
         !flow2d::plane_args_ok(output, width, height, pitch_bytes) || input == output)
         return FLOW2D_ERR_INVALID_ARGUMENT;
+    const bool pair = input_b || output_b;
+    if (pair && (!flow2d::plane_args_ok(input_b, width, height, pitch_bytes) ||
+                 !flow2d::plane_args_ok(output_b, width, height, pitch_bytes) || input_b == output_b ||
+                 output_b == output || output_b == input || output == input_b))
+        return FLOW2D_ERR_INVALID_ARGUMENT;
     if (window != 3 && window != 5 && window != 7) return FLOW2D_ERR_UNSUPPORTED;
     // the mirror rule needs every reflected index inside the image
     if (width <= window / 2 || height <= window / 2) return FLOW2D_ERR_UNSUPPORTED;
-    const dim3 grid(flow2d::div_up(width, kBlockX), flow2d::div_up(height, kBlockY));
+    const unsigned z = pair ? 2 : 1;
+    const dim3 grid(flow2d::div_up(width, kBlockX), flow2d::div_up(height, kBlockY), z);
     const dim3 block(kBlockX, kBlockY);
     const int w = (int)width, h = (int)height, pitch = (int)(pitch_bytes / 4);
     if (window == 5 && width >= 8 && height >= 8) {  // mirrored rows/columns up to 3 beyond the border stay inside
         const int rows = median5_rows_per_strip(ctx, width, height);
-        const dim3 sgrid(flow2d::div_up(flow2d::div_up(width, kStreamValid), 4), flow2d::div_up(height, rows));
-        median5_stream_kernel<<<sgrid, 256, 0, ctx->stream>>>(input, w, h, pitch, rows, output);
+        const dim3 sgrid(flow2d::div_up(flow2d::div_up(width, kStreamValid), 4), flow2d::div_up(height, rows), z);
+        median5_stream_kernel<<<sgrid, 256, 0, ctx->stream>>>(input, input_b, w, h, pitch, rows, output, output_b);
         FLOW2D_CHECK_LAUNCH();
         return FLOW2D_OK;
     }
     switch (window) {
-        case 3: median_kernel<3><<<grid, block, 0, ctx->stream>>>(input, w, h, pitch, output); break;
-        case 5: median_kernel<5><<<grid, block, 0, ctx->stream>>>(input, w, h, pitch, output); break;
-        default: median_kernel<7><<<grid, block, 0, ctx->stream>>>(input, w, h, pitch, output); break;
+        case 3: median_kernel<3><<<grid, block, 0, ctx->stream>>>(input, input_b, w, h, pitch, output, output_b); break;
+        case 5: median_kernel<5><<<grid, block, 0, ctx->stream>>>(input, input_b, w, h, pitch, output, output_b); break;
+        default: median_kernel<7><<<grid, block, 0, ctx->stream>>>(input, input_b, w, h, pitch, output, output_b); break;
     }
     FLOW2D_CHECK_LAUNCH();
     return FLOW2D_OK;
+}
+
+extern "C" int flow2d_median_2d(flow2d_context* ctx, const float* input, size_t width, size_t height,
+                                size_t pitch_bytes, size_t window, float* output)
+{
+    return launch_median(ctx, input, nullptr, width, height, pitch_bytes, window, output, nullptr);
+}
+
+extern "C" int flow2d_median_2d_pair(flow2d_context* ctx, const float* input_a, const float* input_b, size_t width,
+                                     size_t height, size_t pitch_bytes, size_t window, float* output_a, float* output_b)
+{
+    if (!input_b || !output_b) return FLOW2D_ERR_INVALID_ARGUMENT;
+    return launch_median(ctx, input_a, input_b, width, height, pitch_bytes, window, output_a, output_b);
 }

@@ -19,9 +19,14 @@ inline dim3 grid_for(size_t w, size_t h) { return dim3(flow2d::div_up(w, kBlockX
 
 // ---- add_2d: src/kernels/add_2d.cu:33-46 --------------------------------------------------------
 // float4 body (four pixels per lane, 1 KiB per wave-instruction) + scalar tail.
-__global__ __launch_bounds__(256) void add_2d_kernel(float* __restrict__ op0, const float* __restrict__ op1, int w,
+// Two independent planes per launch (grid.z = 2 picks the second set): u += du and v += dv, the two frames of a
+// level, ... come in pairs, and on the small levels a launch costs more than its work.
+__global__ __launch_bounds__(256) void add_2d_kernel(float* __restrict__ op0_a, const float* __restrict__ op1_a,
+                                                     float* __restrict__ op0_b, const float* __restrict__ op1_b, int w,
                                                      int h, int pitch)
 {
+    float* __restrict__ op0 = blockIdx.z ? op0_b : op0_a;
+    const float* __restrict__ op1 = blockIdx.z ? op1_b : op1_a;
     const int x4 = (blockIdx.x * kBlockX + threadIdx.x) * 4;
     const int y = blockIdx.y * kBlockY + threadIdx.y;
     if (y >= h || x4 >= w) return;
@@ -220,9 +225,12 @@ void launch_gauss_stream(flow2d_context* ctx, float* dst, const float* src, size
 
 // ---- area-weighted resampling: src/kernels/resample_2d.cu:34-75 (x), :77-118 (y) ----------------
 template <bool kAlongX>
-__global__ __launch_bounds__(256) void resample_kernel(const float* __restrict__ in, float* __restrict__ out,
+__global__ __launch_bounds__(256) void resample_kernel(const float* __restrict__ in_a, float* __restrict__ out_a,
+                                                       const float* __restrict__ in_b, float* __restrict__ out_b,
                                                        int out_w, int out_h, int in_n, int pitch)
 {
+    const float* __restrict__ in = blockIdx.z ? in_b : in_a;
+    float* __restrict__ out = blockIdx.z ? out_b : out_a;
     const int x = blockIdx.x * kBlockX + threadIdx.x;
     const int y = blockIdx.y * kBlockY + threadIdx.y;
     if (x >= out_w || y >= out_h) return;
@@ -256,9 +264,12 @@ __global__ __launch_bounds__(256) void resample_kernel(const float* __restrict__
 constexpr int kResampleChunk = 2048;                                   // floats of input per wave and pass
 constexpr int kResampleLdsPerWave = kResampleChunk + kResampleChunk / 32;  // one pad word per 32: conflict-free strides
 
-__global__ __launch_bounds__(256) void resample_x_lds_kernel(const float* __restrict__ in, float* __restrict__ out,
+__global__ __launch_bounds__(256) void resample_x_lds_kernel(const float* __restrict__ in_a, float* __restrict__ out_a,
+                                                             const float* __restrict__ in_b, float* __restrict__ out_b,
                                                              int out_w, int out_h, int in_w, int pitch)
 {
+    const float* __restrict__ in = blockIdx.z ? in_b : in_a;
+    float* __restrict__ out = blockIdx.z ? out_b : out_a;
     __shared__ float lds[4][kResampleLdsPerWave];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int x = blockIdx.x * 64 + lane;
@@ -339,23 +350,38 @@ __global__ __launch_bounds__(256) void registration_kernel(const float* __restri
 
 extern "C" {
 
-int flow2d_add_2d(flow2d_context* ctx, float* operand_0, const float* operand_1, size_t width, size_t height,
-                  size_t pitch_bytes)
+static int launch_add(flow2d_context* ctx, float* operand_0, const float* operand_1, float* operand_0_b,
+                      const float* operand_1_b, size_t width, size_t height, size_t pitch_bytes)
 {
     FLOW2D_ENTER(ctx);
     if (!flow2d::plane_args_ok(operand_0, width, height, pitch_bytes) ||
         !flow2d::plane_args_ok(operand_1, width, height, pitch_bytes))
         return FLOW2D_ERR_INVALID_ARGUMENT;
-    dim3 grid(flow2d::div_up(width, kBlockX * 4), flow2d::div_up(height, kBlockY));
-    add_2d_kernel<<<grid, dim3(kBlockX, kBlockY), 0, ctx->stream>>>(operand_0, operand_1, (int)width, (int)height,
-                                                                   (int)(pitch_bytes / 4));
+    const bool pair = operand_0_b || operand_1_b;
+    if (pair && (!flow2d::plane_args_ok(operand_0_b, width, height, pitch_bytes) ||
+                 !flow2d::plane_args_ok(operand_1_b, width, height, pitch_bytes) || operand_0_b == operand_0 ||
+                 operand_0_b == operand_1 || operand_0 == operand_1_b))
+        return FLOW2D_ERR_INVALID_ARGUMENT;
+    dim3 grid(flow2d::div_up(width, kBlockX * 4), flow2d::div_up(height, kBlockY), pair ? 2 : 1);
+    add_2d_kernel<<<grid, dim3(kBlockX, kBlockY), 0, ctx->stream>>>(operand_0, operand_1, operand_0_b, operand_1_b,
+                                                                   (int)width, (int)height, (int)(pitch_bytes / 4));
     FLOW2D_CHECK_LAUNCH();
     return FLOW2D_OK;
 }
 
-// CudaOperationConvolution2D::ComputeGaussianKernel(sigma, precision = 3, pixel_size = 1.0),
-// src/cuda_operations/2d/cuda_operation_convolution_2d.cpp:83-112: taps evaluated in double,
-// stored as float, normalised by a float running sum.
+int flow2d_add_2d(flow2d_context* ctx, float* operand_0, const float* operand_1, size_t width, size_t height,
+                  size_t pitch_bytes)
+{
+    return launch_add(ctx, operand_0, operand_1, nullptr, nullptr, width, height, pitch_bytes);
+}
+
+int flow2d_add_2d_pair(flow2d_context* ctx, float* operand_0_a, const float* operand_1_a, float* operand_0_b,
+                       const float* operand_1_b, size_t width, size_t height, size_t pitch_bytes)
+{
+    if (!operand_0_b || !operand_1_b) return FLOW2D_ERR_INVALID_ARGUMENT;
+    return launch_add(ctx, operand_0_a, operand_1_a, operand_0_b, operand_1_b, width, height, pitch_bytes);
+}
+
 int flow2d_gaussian_kernel(float sigma, float* taps, int* out_radius)
 {
     if (!taps || !out_radius || !(sigma > 0.f)) return FLOW2D_ERR_INVALID_ARGUMENT;
@@ -437,8 +463,8 @@ int flow2d_gaussian_blur(flow2d_context* ctx, float* dst, const float* src, size
     return FLOW2D_OK;
 }
 
-static int launch_resample(flow2d_context* ctx, bool along_x, const float* input, float* output, size_t out_width,
-                           size_t out_height, size_t in_extent, size_t pitch_bytes)
+static int launch_resample(flow2d_context* ctx, bool along_x, const float* input, float* output, const float* input_b,
+                           float* output_b, size_t out_width, size_t out_height, size_t in_extent, size_t pitch_bytes)
 {
     FLOW2D_ENTER(ctx);
     const size_t in_w = along_x ? in_extent : out_width;
@@ -446,16 +472,26 @@ static int launch_resample(flow2d_context* ctx, bool along_x, const float* input
     if (!flow2d::plane_args_ok(input, in_w, in_h, pitch_bytes) ||
         !flow2d::plane_args_ok(output, out_width, out_height, pitch_bytes) || input == output)
         return FLOW2D_ERR_INVALID_ARGUMENT;
+    const bool pair = input_b || output_b;
+    if (pair && (!flow2d::plane_args_ok(input_b, in_w, in_h, pitch_bytes) ||
+                 !flow2d::plane_args_ok(output_b, out_width, out_height, pitch_bytes) || input_b == output_b ||
+                 output_b == output || output_b == input || output == input_b))
+        return FLOW2D_ERR_INVALID_ARGUMENT;
+    const unsigned z = pair ? 2 : 1;
     if (along_x && in_extent >= 2 * out_width)  // strong down-sampling: coalesced staging through LDS
-        resample_x_lds_kernel<<<dim3(flow2d::div_up(out_width, 64), flow2d::div_up(out_height, 4)), 256, 0,
-                                ctx->stream>>>(input, output, (int)out_width, (int)out_height, (int)in_extent,
-                                               (int)(pitch_bytes / 4));
-    else if (along_x)
-        resample_kernel<true><<<grid_for(out_width, out_height), dim3(kBlockX, kBlockY), 0, ctx->stream>>>(
-            input, output, (int)out_width, (int)out_height, (int)in_extent, (int)(pitch_bytes / 4));
-    else
-        resample_kernel<false><<<grid_for(out_width, out_height), dim3(kBlockX, kBlockY), 0, ctx->stream>>>(
-            input, output, (int)out_width, (int)out_height, (int)in_extent, (int)(pitch_bytes / 4));
+        resample_x_lds_kernel<<<dim3(flow2d::div_up(out_width, 64), flow2d::div_up(out_height, 4), z), 256, 0,
+                                ctx->stream>>>(input, output, input_b, output_b, (int)out_width, (int)out_height,
+                                               (int)in_extent, (int)(pitch_bytes / 4));
+    else {
+        dim3 grid = grid_for(out_width, out_height);
+        grid.z = z;
+        if (along_x)
+            resample_kernel<true><<<grid, dim3(kBlockX, kBlockY), 0, ctx->stream>>>(
+                input, output, input_b, output_b, (int)out_width, (int)out_height, (int)in_extent, (int)(pitch_bytes / 4));
+        else
+            resample_kernel<false><<<grid, dim3(kBlockX, kBlockY), 0, ctx->stream>>>(
+                input, output, input_b, output_b, (int)out_width, (int)out_height, (int)in_extent, (int)(pitch_bytes / 4));
+    }
     FLOW2D_CHECK_LAUNCH();
     return FLOW2D_OK;
 }
@@ -463,13 +499,28 @@ static int launch_resample(flow2d_context* ctx, bool along_x, const float* input
 int flow2d_resample_x(flow2d_context* ctx, const float* input, float* output, size_t out_width, size_t out_height,
                       size_t in_width, size_t pitch_bytes)
 {
-    return launch_resample(ctx, true, input, output, out_width, out_height, in_width, pitch_bytes);
+    return launch_resample(ctx, true, input, output, nullptr, nullptr, out_width, out_height, in_width, pitch_bytes);
+}
+
+int flow2d_resample_x_pair(flow2d_context* ctx, const float* input_a, float* output_a, const float* input_b,
+                           float* output_b, size_t out_width, size_t out_height, size_t in_width, size_t pitch_bytes)
+{
+    if (!input_b || !output_b) return FLOW2D_ERR_INVALID_ARGUMENT;
+    return launch_resample(ctx, true, input_a, output_a, input_b, output_b, out_width, out_height, in_width, pitch_bytes);
 }
 
 int flow2d_resample_y(flow2d_context* ctx, const float* input, float* output, size_t out_width, size_t out_height,
                       size_t in_height, size_t pitch_bytes)
 {
-    return launch_resample(ctx, false, input, output, out_width, out_height, in_height, pitch_bytes);
+    return launch_resample(ctx, false, input, output, nullptr, nullptr, out_width, out_height, in_height, pitch_bytes);
+}
+
+int flow2d_resample_y_pair(flow2d_context* ctx, const float* input_a, float* output_a, const float* input_b,
+                           float* output_b, size_t out_width, size_t out_height, size_t in_height, size_t pitch_bytes)
+{
+    if (!input_b || !output_b) return FLOW2D_ERR_INVALID_ARGUMENT;
+    return launch_resample(ctx, false, input_a, output_a, input_b, output_b, out_width, out_height, in_height,
+                           pitch_bytes);
 }
 
 int flow2d_registration_2d(flow2d_context* ctx, const float* frame_0, const float* frame_1, const float* flow_u,

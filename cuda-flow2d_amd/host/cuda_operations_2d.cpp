@@ -14,6 +14,14 @@ void CudaOperationAdd2D::Execute(OperationParameters& params)
     FLOW2D_PARAM_OR_RETURN(params, DevicePtr, operand_0, "operand_0");
     FLOW2D_PARAM_OR_RETURN(params, DevicePtr, operand_1, "operand_1");
     FLOW2D_PARAM_OR_RETURN(params, DataSize3, data_size, "data_size");
+    // optional second plane set (not in the reference's bag): both additions in one launch
+    DevicePtr operand_0_b = 0, operand_1_b = 0;
+    if (params.Read<DevicePtr>("operand_0_b", operand_0_b) && params.Read<DevicePtr>("operand_1_b", operand_1_b)) {
+        Failed(flow2d_add_2d_pair(context_, AsPlane(operand_0), AsPlane(operand_1), AsPlane(operand_0_b),
+                                  AsPlane(operand_1_b), data_size.width, data_size.height, dev_container_size_.pitch),
+               "flow2d_add_2d_pair");
+        return;
+    }
     Failed(flow2d_add_2d(context_, AsPlane(operand_0), AsPlane(operand_1), data_size.width, data_size.height,
                          dev_container_size_.pitch),
            "flow2d_add_2d");
@@ -87,17 +95,33 @@ void CudaOperationMedian2D::Execute(OperationParameters& params)
         std::printf("Operation '%s': Error. Input buffer cannot serve as output buffer.", GetName());
         return;
     }
+    DevicePtr dev_input_b = 0, dev_output_b = 0;  // optional second plane (not in the reference's bag)
+    const bool pair = params.Read<DevicePtr>("dev_input_b", dev_input_b) &&
+                      params.Read<DevicePtr>("dev_output_b", dev_output_b);
+    if (pair && dev_input_b == dev_output_b) {
+        std::printf("Operation '%s': Error. Input buffer cannot serve as output buffer.", GetName());
+        return;
+    }
     if (radius == 1) {  // no filtering: copy the whole container (cuda_operation_median_2d.cpp:100-104)
         Failed(flow2d_copy_d2d(context_, AsPlane(dev_output), AsPlane(dev_input),
                                dev_container_size_.pitch * dev_container_size_.height),
                "flow2d_copy_d2d");
+        if (pair)
+            Failed(flow2d_copy_d2d(context_, AsPlane(dev_output_b), AsPlane(dev_input_b),
+                                   dev_container_size_.pitch * dev_container_size_.height),
+                   "flow2d_copy_d2d");
         return;
     }
     if (radius % 2 == 0) {
         std::printf("Warning. Median raduis is even (%zu), decresaing by 1...\n", radius);
         radius -= 1;
     }
-    if (radius >= 3 && radius <= 7) {
+    if (radius >= 3 && radius <= 7 && pair) {
+        Failed(flow2d_median_2d_pair(context_, AsPlane(dev_input), AsPlane(dev_input_b), data_size.width,
+                                     data_size.height, dev_container_size_.pitch, radius, AsPlane(dev_output),
+                                     AsPlane(dev_output_b)),
+               "flow2d_median_2d_pair");
+    } else if (radius >= 3 && radius <= 7) {
         Failed(flow2d_median_2d(context_, AsPlane(dev_input), data_size.width, data_size.height,
                                 dev_container_size_.pitch, radius, AsPlane(dev_output)),
                "flow2d_median_2d");
@@ -144,6 +168,21 @@ void CudaOperationResample2D::Execute(OperationParameters& params)
     FLOW2D_PARAM_OR_RETURN(params, DataSize3, resample_size, "resample_size");
     if (dev_input == dev_output) {
         std::printf("Operation '%s': Error. Input buffer cannot serve as output buffer.", GetName());
+        return;
+    }
+    // optional second plane set (not in the reference's bag): two planes of the same geometry per launch
+    DevicePtr dev_input_b = 0, dev_output_b = 0, dev_temp_b = 0;
+    if (params.Read<DevicePtr>("dev_input_b", dev_input_b) && params.Read<DevicePtr>("dev_output_b", dev_output_b) &&
+        params.Read<DevicePtr>("dev_temp_b", dev_temp_b)) {
+        if (Failed(flow2d_resample_x_pair(context_, AsPlane(dev_input), AsPlane(dev_temp), AsPlane(dev_input_b),
+                                          AsPlane(dev_temp_b), resample_size.width, data_size.height, data_size.width,
+                                          dev_container_size_.pitch),
+                   "flow2d_resample_x_pair"))
+            return;
+        Failed(flow2d_resample_y_pair(context_, AsPlane(dev_temp), AsPlane(dev_output), AsPlane(dev_temp_b),
+                                      AsPlane(dev_output_b), resample_size.width, resample_size.height,
+                                      data_size.height, dev_container_size_.pitch),
+               "flow2d_resample_y_pair");
         return;
     }
     // x pass into temp at (new width x old height), then y pass (cuda_operation_resample_2d.cpp:99-105)

@@ -535,18 +535,19 @@ bool OpticalFlow2D::RunPyramid(OperationParameters& params)
         } else if (level == 0) {
             std::swap(frame_0, frame_0_res);
             std::swap(frame_1, frame_1_res);
-        } else {
-            DevicePtr temp = Acquire();
-            DevicePtr* io[2][2] = {{&frame_0, &frame_0_res}, {&frame_1, &frame_1_res}};
-            for (auto& pair : io) {
-                op.Clear();
-                op.PushValuePtr("dev_input", pair[0]);
-                op.PushValuePtr("dev_output", pair[1]);
-                op.PushValuePtr("dev_temp", &temp);
-                op.PushValuePtr("data_size", &original_size);
-                op.PushValuePtr("resample_size", &current_size);
-                cuop_resample_.Execute(op);
-            }
+        } else {  // both frames of the level in one resample call (two planes per launch)
+            DevicePtr temp = Acquire(), temp_b = Acquire();
+            op.Clear();
+            op.PushValuePtr("dev_input", &frame_0);
+            op.PushValuePtr("dev_output", &frame_0_res);
+            op.PushValuePtr("dev_temp", &temp);
+            op.PushValuePtr("dev_input_b", &frame_1);
+            op.PushValuePtr("dev_output_b", &frame_1_res);
+            op.PushValuePtr("dev_temp_b", &temp_b);
+            op.PushValuePtr("data_size", &original_size);
+            op.PushValuePtr("resample_size", &current_size);
+            cuop_resample_.Execute(op);
+            Release(temp_b);
             Release(temp);
         }
 
@@ -555,19 +556,21 @@ bool OpticalFlow2D::RunPyramid(OperationParameters& params)
             const size_t row_bytes = dev_container_size_.width * sizeof(float);
             flow2d_memset_2d(context_, AsPlane(flow_u), dev_container_size_.pitch, 0, row_bytes, dev_container_size_.height);
             flow2d_memset_2d(context_, AsPlane(flow_v), dev_container_size_.pitch, 0, row_bytes, dev_container_size_.height);
-        } else {
-            DevicePtr temp = Acquire();
-            DevicePtr* io[2][2] = {{&flow_u, &flow_du}, {&flow_v, &flow_dv}};
-            for (auto& pair : io) {
-                op.Clear();
-                op.PushValuePtr("dev_input", pair[0]);
-                op.PushValuePtr("dev_output", pair[1]);
-                op.PushValuePtr("dev_temp", &temp);
-                op.PushValuePtr("data_size", &prev_size);
-                op.PushValuePtr("resample_size", &current_size);
-                cuop_resample_.Execute(op);
-                std::swap(*pair[0], *pair[1]);
-            }
+        } else {  // u and v of the previous level in one resample call
+            DevicePtr temp = Acquire(), temp_b = Acquire();
+            op.Clear();
+            op.PushValuePtr("dev_input", &flow_u);
+            op.PushValuePtr("dev_output", &flow_du);
+            op.PushValuePtr("dev_temp", &temp);
+            op.PushValuePtr("dev_input_b", &flow_v);
+            op.PushValuePtr("dev_output_b", &flow_dv);
+            op.PushValuePtr("dev_temp_b", &temp_b);
+            op.PushValuePtr("data_size", &prev_size);
+            op.PushValuePtr("resample_size", &current_size);
+            cuop_resample_.Execute(op);
+            std::swap(flow_u, flow_du);
+            std::swap(flow_v, flow_dv);
+            Release(temp_b);
             Release(temp);
         }
 
@@ -632,33 +635,35 @@ bool OpticalFlow2D::RunPyramid(OperationParameters& params)
             Release(temp_dv);
         }
 
-        {  // u += du, v += dv
-            DevicePtr* io[2][2] = {{&flow_u, &flow_du}, {&flow_v, &flow_dv}};
-            for (auto& pair : io) {
-                op.Clear();
-                op.PushValuePtr("operand_0", pair[0]);
-                op.PushValuePtr("operand_1", pair[1]);
-                op.PushValuePtr("data_size", &current_size);
-                cuop_add_.Execute(op);
-            }
+        {  // u += du, v += dv (one launch)
+            op.Clear();
+            op.PushValuePtr("operand_0", &flow_u);
+            op.PushValuePtr("operand_1", &flow_du);
+            op.PushValuePtr("operand_0_b", &flow_v);
+            op.PushValuePtr("operand_1_b", &flow_dv);
+            op.PushValuePtr("data_size", &current_size);
+            cuop_add_.Execute(op);
         }
         prev_size = current_size;
 
-        {  // median of u and v after every level, the finest included
-            DevicePtr temp = Acquire();
-            DevicePtr* fields[2] = {&flow_u, &flow_v};
-            DevicePtr caller_out[2] = {caller_flow_u_, caller_flow_v_};
-            for (int i = 0; i < 2; ++i) {
-                // the last median of a ComputeFlowDevice run delivers the result into the caller's plane
-                const bool deliver = level == 0 && caller_out[i] != 0;
-                op.Clear();
-                op.PushValuePtr("dev_input", fields[i]);
-                op.PushValuePtr("dev_output", deliver ? &caller_out[i] : &temp);
-                op.PushValuePtr("data_size", &current_size);
-                op.PushValuePtr("radius", &median_radius);
-                cuop_median_.Execute(op);
-                if (!deliver) std::swap(*fields[i], temp);
+        {  // median of u and v after every level, the finest included (one launch for both)
+            DevicePtr temp = Acquire(), temp_b = Acquire();
+            // the last median of a ComputeFlowDevice run delivers the result into the caller's planes
+            const bool deliver = level == 0 && caller_flow_u_ != 0 && caller_flow_v_ != 0;
+            DevicePtr out_u = deliver ? caller_flow_u_ : temp, out_v = deliver ? caller_flow_v_ : temp_b;
+            op.Clear();
+            op.PushValuePtr("dev_input", &flow_u);
+            op.PushValuePtr("dev_output", &out_u);
+            op.PushValuePtr("dev_input_b", &flow_v);
+            op.PushValuePtr("dev_output_b", &out_v);
+            op.PushValuePtr("data_size", &current_size);
+            op.PushValuePtr("radius", &median_radius);
+            cuop_median_.Execute(op);
+            if (!deliver) {
+                std::swap(flow_u, temp);
+                std::swap(flow_v, temp_b);
             }
+            Release(temp_b);
             Release(temp);
         }
     }

@@ -154,6 +154,24 @@ FLOW2D_API int flow2d_resample_x(flow2d_context* ctx, const float* input, float*
 FLOW2D_API int flow2d_resample_y(flow2d_context* ctx, const float* input, float* output, size_t out_width,
                                  size_t out_height, size_t in_height, size_t pitch_bytes);
 
+/* Two-plane forms of the three launchers the pyramid calls once for u and once for v (or once per frame) with
+ * identical geometry: one launch does what two calls of the single-plane entry do, plane set `a` and plane set
+ * `b` independently and with the same results (the second set rides in grid.z).  They replace the back-to-back
+ * launch pairs of optical_flow_2d.cpp:284-303 (frames), :320-345 (flow resample), :480-500 (add), :505-530 (median);
+ * on the coarse levels a launch costs more than its work.  The four output planes must be distinct. */
+FLOW2D_API int flow2d_add_2d_pair(flow2d_context* ctx, float* operand_0_a, const float* operand_1_a,
+                                  float* operand_0_b, const float* operand_1_b, size_t width, size_t height,
+                                  size_t pitch_bytes);
+FLOW2D_API int flow2d_median_2d_pair(flow2d_context* ctx, const float* input_a, const float* input_b, size_t width,
+                                     size_t height, size_t pitch_bytes, size_t window, float* output_a,
+                                     float* output_b);
+FLOW2D_API int flow2d_resample_x_pair(flow2d_context* ctx, const float* input_a, float* output_a,
+                                      const float* input_b, float* output_b, size_t out_width, size_t out_height,
+                                      size_t in_width, size_t pitch_bytes);
+FLOW2D_API int flow2d_resample_y_pair(flow2d_context* ctx, const float* input_a, float* output_a,
+                                      const float* input_b, float* output_b, size_t out_width, size_t out_height,
+                                      size_t in_height, size_t pitch_bytes);
+
 /* compute_phi_ksi (src/kernels/solve_2d.cu:43-198). */
 FLOW2D_API int flow2d_compute_phi_ksi(flow2d_context* ctx, const float* frame_0, const float* frame_1,
                                       const float* flow_u, const float* flow_v, const float* flow_du,

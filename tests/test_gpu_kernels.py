@@ -122,6 +122,29 @@ def test_median5_streaming_strips(ctx, oracle, w, h, cw, ch):
     assert np.array_equal(dst.download(w, h), oracle.median(u, w, h, 5))
 
 
+@pytest.mark.parametrize("w,h,cw,ch", [(100, 70, 128, 80), (257, 33, 300, 40), (16, 8, 16, 8), (700, 133, 704, 140)])
+def test_two_plane_launches(ctx, flow2d, oracle, w, h, cw, ch):
+    """add / median / resample on two planes per launch: each plane gets what the single-plane entry gives."""
+    a, b, c, d, *_ = level_fields(oracle, w, h, 21)
+    pa, pb, pc, pd = (up(ctx, x, cw, ch, 3.0) for x in (a, b, c, d))
+    ctx.add_pair(pa, pb, pc, pd, w, h)
+    assert np.array_equal(pa.download(w, h), oracle.add(a, b, w, h)) and np.array_equal(pc.download(w, h), oracle.add(c, d, w, h))
+    for window in (3, 5, 7):
+        sa, sb, da, db = up(ctx, a, cw, ch), up(ctx, c, cw, ch), ctx.plane(cw, ch), ctx.plane(cw, ch)
+        ctx.median_pair(sa, sb, w, h, window, da, db)
+        assert np.array_equal(da.download(w, h), oracle.median(a, w, h, window))
+        assert np.array_equal(db.download(w, h), oracle.median(c, w, h, window))
+    for ow, oh in ((w // 2, h // 2), (max(2, w // 9), max(2, h // 5)), (min(cw, w + 20), min(ch, h + 7))):
+        sa, sb = up(ctx, a, cw, ch), up(ctx, c, cw, ch)
+        ta, tb, da, db = (ctx.plane(cw, ch) for _ in range(4))
+        ctx.resample_x_pair(sa, ta, sb, tb, ow, h, w)
+        ctx.resample_y_pair(ta, da, tb, db, ow, oh, h)
+        assert np.array_equal(da.download(ow, oh), oracle.resample(in_container(a, cw, ch), w, h, ow, oh)[:oh, :ow])
+        assert np.array_equal(db.download(ow, oh), oracle.resample(in_container(c, cw, ch), w, h, ow, oh)[:oh, :ow])
+    with pytest.raises(flow2d.Flow2DError):
+        ctx.median_pair(pa, pb, w, h, 5, pc, pc)  # the two outputs must differ
+
+
 def test_median_rejects_bad_window(ctx, flow2d, oracle):
     src, dst = ctx.plane(32, 32), ctx.plane(32, 32)
     for bad in (0, 1, 2, 4, 9):
