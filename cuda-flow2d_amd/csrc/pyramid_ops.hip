@@ -246,7 +246,22 @@ __global__ __launch_bounds__(256) void resample_kernel(const float* __restrict__
     const float* base = kAlongX ? in + static_cast<size_t>(y) * pitch : in + x;
     const size_t stride = kAlongX ? 1 : pitch;
     float value = 0.f;
-    for (int j = 0; j < cells; ++j) {
+    // the cells are summed in order (parity), but their loads do not depend on the sum: eight at a time in flight
+    // (a coarse level sums up to 128 cells per output with only a few thousand outputs to hide the latency)
+    int j = 0;
+    for (; j + 8 <= cells; j += 8) {
+        float v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = base[static_cast<size_t>(left_i + j + k) * stride];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            float frac = 1.f;
+            if (j + k == 0) frac = static_cast<float>(left_i + 1) - left_f;
+            if (j + k == cells - 1) frac = right_f - static_cast<float>(left_i + j + k);
+            value += v[k] * frac;
+        }
+    }
+    for (; j < cells; ++j) {
         float frac = 1.f;
         if (j == 0) frac = static_cast<float>(left_i + 1) - left_f;
         if (j == cells - 1) frac = right_f - static_cast<float>(left_i + j);

@@ -40,6 +40,8 @@ def main():
         ("resample x to 1/2", lambda: ctx.resample_x(a, tmp, n // 2, n, n), 1.5),
         ("resample y to 1/2 (half width)", lambda: ctx.resample_y(tmp, out, n // 2, n // 2, n), 0.75),
         ("resample x to 1/16", lambda: ctx.resample_x(a, tmp, n // 16, n, n), 1 + 1 / 16),
+        ("resample y to 1/128 at width n/128 (coarsest level)", lambda: ctx.resample_y(a, out, n // 128, n // 128, n), 1 / 128),
+        ("resample y to 1/32 at width n/32", lambda: ctx.resample_y(a, out, n // 32, n // 32, n), 1 / 32),
         ("resample x to 0.9", lambda: ctx.resample_x(a, tmp, int(n * 0.9), n, n), 1.9),
     ]
     for name, fn, planes in rows:
