@@ -221,6 +221,35 @@ def test_solve_level_single_workgroup_rejects_large_levels(ctx, flow2d, oracle):
     assert e.value.status == 5
 
 
+@pytest.mark.parametrize("algorithm", [1, 2, 0])
+@pytest.mark.parametrize("case", ["zero frames", "constant frames", "alpha 0", "epsilon 0", "huge values"])
+def test_solve_level_degenerate_inputs(ctx, oracle, case, algorithm):
+    """Flat images, vanishing regularisation or robustifier, overflowing intermediates: zeros, infinities and NaNs
+    come out where the oracle's IEEE arithmetic puts them."""
+    w, h, cw, ch = 150, 90, 160, 96
+    f0, f1, u, v, _, _ = level_fields(oracle, w, h, 23)
+    alpha, eps = 3.5, 0.001
+    if case == "zero frames":
+        f0, f1 = np.zeros_like(f0), np.zeros_like(f1)
+    elif case == "constant frames":
+        f0, f1 = np.full_like(f0, 17.0), np.full_like(f1, 17.0)
+    elif case == "alpha 0":
+        alpha = 0.0
+    elif case == "epsilon 0":
+        eps = 0.0
+        u, v = np.zeros_like(u), np.zeros_like(v)   # zero gradients: phi = 1 / (2 sqrt(0)) = inf
+    else:
+        f0, f1 = f0 * np.float32(1e18), f1 * np.float32(1e18)
+    hx, hy = np.float32(cw / w), np.float32(ch / h)
+    d = [up(ctx, a, cw, ch) for a in (f0, f1, u, v)]
+    du, dv, phi, ksi, tdu, tdv = (ctx.plane(cw, ch).fill_bytes(0x7f) for _ in range(6))
+    rdu, rdv = ctx.solve_level(*d, du, dv, phi, ksi, tdu, tdv, w, h, hx, hy, alpha, eps, eps, 2, 3, 0, algorithm)
+    odu, odv, _, _ = oracle.solve_level(f0, f1, u, v, w, h, hx, hy, alpha, eps, eps, 2, 3, 0)
+    with np.errstate(invalid="ignore"):
+        assert np.array_equal(rdu.download(w, h), odu, equal_nan=True)
+        assert np.array_equal(rdv.download(w, h), odv, equal_nan=True)
+
+
 def test_solve_level_fused_without_sweeps(ctx, flow2d, oracle):
     """FUSED has nothing to fuse when an outer iteration holds no sweep: refused; AUTO runs the per-sweep form."""
     w, h = 64, 48
