@@ -203,3 +203,18 @@ def test_cli_exit_codes_without_device(flow2d, tmp_path):
         pytest.skip("a GPU is visible; the no-device exit path cannot be exercised")
     rc = subprocess.call([flow2d.CLI_PATH, "nope.xml"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     assert rc == 1
+
+
+def test_committed_bench_line_has_the_contract_fields():
+    """The bench line committed with the rocprof summary carries every field the bench contract names."""
+    import json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    line = json.loads(open(os.path.join(root, "profiles", "r01_final_bench_line_under_rocprof.json")).read())
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in line, key
+    assert line["config"]["workload"] == "cfg3_4096_gradient" and line["scaling"] == "weak" and line["dtype"] == "f32"
+    roof = line["roofline"]
+    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert key in roof, key
+    assert roof["bound"] == "hbm" and roof["peak"] == 8000.0 and abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-3
