@@ -126,7 +126,7 @@ def load_traffic(workload, algorithm):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default=DEFAULT_WORKLOAD, choices=sorted(WORKLOADS))
     ap.add_argument("--algorithm", type=int, default=0, help="flow2d_solver_algorithm: 0 auto, 1 per-sweep, 2 fused")
