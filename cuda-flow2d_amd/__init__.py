@@ -20,9 +20,9 @@ HIP_LIB_PATH = os.path.join(_HERE, "csrc", "libflow2d_hip.so")
 HOST_LIB_PATH = os.path.join(_HERE, "host", "libflow2d_host.so")
 CLI_PATH = os.path.join(_HERE, "host", "flow2d")
 
-GREY, GRADIENT, GRADIENT_UNTILED = 0, 1, 2  # flow2d_constancy; 2 = true-neighbour gradient term (not in the reference)
-HOST_LOG_DERIVATIVES = "LogDerivatives"  # the reference's third DataConstancy; the host layer refuses it
-_HOST_CONSTANCY = {GREY: 0, GRADIENT: 1, GRADIENT_UNTILED: 3, HOST_LOG_DERIVATIVES: 2}  # enum class DataConstancy
+# flow2d_constancy; 2 = true-neighbour gradient term (not in the reference), 3 = the reference's LogDerivatives
+GREY, GRADIENT, GRADIENT_UNTILED, LOG_DERIVATIVES = 0, 1, 2, 3
+_HOST_CONSTANCY = {GREY: 0, GRADIENT: 1, GRADIENT_UNTILED: 3, LOG_DERIVATIVES: 2}  # enum class DataConstancy
 SOLVER_AUTO, SOLVER_PER_SWEEP, SOLVER_FUSED, SOLVER_SINGLE_WORKGROUP = 0, 1, 2, 3
 
 STATUS = {0: "ok", 1: "invalid argument", 2: "no usable HIP device", 3: "HIP runtime error",
@@ -115,6 +115,7 @@ def hip_lib():
         L.flow2d_solve_2d.argtypes = [vp] * 9 + [sz, sz, sz, f, f, f, vp, vp]
         L.flow2d_solve_2d_grad.argtypes = [vp] * 9 + [sz, sz, sz, f, f, f, vp, vp]
         L.flow2d_solve_2d_grad_untiled.argtypes = [vp] * 9 + [sz, sz, sz, f, f, f, vp, vp]
+        L.flow2d_solve_2d_log.argtypes = [vp] * 9 + [sz, sz, sz, f, f, f, vp, vp]
         L.flow2d_solve_2d_sor.argtypes = [vp] * 9 + [sz, sz, sz, f, f, f, f, i]
         L.flow2d_solve_level.argtypes = [vp] * 11 + [C.POINTER(SolveParams), C.POINTER(i)]
         L.flow2d_timing_enable.argtypes = [vp, i]
@@ -312,7 +313,8 @@ class Context:
 
     def solve_sweep(self, f0, f1, u, v, du, dv, phi, ksi, w, h, hx, hy, alpha, tdu, tdv, constancy=GREY):
         fn = {GREY: hip_lib().flow2d_solve_2d, GRADIENT: hip_lib().flow2d_solve_2d_grad,
-              GRADIENT_UNTILED: hip_lib().flow2d_solve_2d_grad_untiled}[constancy]
+              GRADIENT_UNTILED: hip_lib().flow2d_solve_2d_grad_untiled,
+              LOG_DERIVATIVES: hip_lib().flow2d_solve_2d_log}[constancy]
         _check(fn(self.handle, f0.ptr, f1.ptr, u.ptr, v.ptr, du.ptr, dv.ptr, phi.ptr, ksi.ptr, w, h, f0.pitch, hx, hy,
                   alpha, tdu.ptr, tdv.ptr), "flow2d_solve_2d*")
 
@@ -406,6 +408,9 @@ def host_lib():
         L.flow2d_host_missing_key_leaves_outputs.argtypes = [vp, C.c_char_p]
         L.flow2d_host_read_raw.argtypes = [C.c_char_p, sz, sz, i, fp]
         L.flow2d_host_write_outputs.argtypes = [fp, fp, sz, sz, C.c_char_p, C.c_char_p, f]
+        L.flow2d_host_write_raw.argtypes = [fp, sz, sz, i, C.c_char_p]
+        L.flow2d_host_max_warp_level_static.restype = sz
+        L.flow2d_host_max_warp_level_static.argtypes = [sz, sz, f]
         L.flow2d_host_convert_to_rgb.argtypes = [f, f, C.POINTER(i)]
         L.flow2d_host_load_settings.argtypes = [C.c_char_p, C.POINTER(HostSettings)]
         L.flow2d_host_operator_create.restype = vp
@@ -514,6 +519,16 @@ def read_raw(path, width, height, u8):
     out = np.empty((height, width), np.float32)
     rc = host_lib().flow2d_host_read_raw(path.encode(), width, height, int(u8), _fptr(out))
     return out if rc == 0 else None
+
+
+def write_raw(image, path, u8):
+    a = np.ascontiguousarray(image, np.float32)
+    return host_lib().flow2d_host_write_raw(_fptr(a), a.shape[1], a.shape[0], int(u8), path.encode()) == 0
+
+
+def max_warp_level(width, height, scale):
+    """OpticalFlowBase2D::GetMaxWarpLevel of the host layer (no device needed)."""
+    return host_lib().flow2d_host_max_warp_level_static(width, height, scale)
 
 
 def write_outputs(u, v, ppm_path, amp_path, flow_max_scale=10.0):

@@ -2,7 +2,11 @@
 // Restates src/kernels/median_2d.cu:87-299 of the reference: window [x-r/2, x+r/2]^2 with
 // reflect-without-repeat borders, output = element r*r/2 of the ascending window.  The reference
 // sorts the window with a per-thread insertion sort; selection is order-free, so any exact
-// selection network gives the same value (ties only differ in the sign of zero).
+// selection network gives the same value -- except where the order of the reference's sort shows:
+// a window holding a NaN (`temp < window[j]` is false for it, so NaNs never move and cut the window into
+// separately sorted runs) or zeros of both signs (-0 < +0 is false either way: they keep their gather order).
+// Windows holding a NaN or a -0 are therefore recomputed by exact_median(), which evaluates what that
+// insertion sort leaves at position r*r/2 (median_2d.cu:52-63,281-296); everything else takes the networks.
 //
 // Generic kernel (any r): the window lives in registers and goes through a Batcher odd-even merge network
 // whose comparator list is generated at compile time; comparators that cannot influence the median are
@@ -83,6 +87,48 @@ __device__ __forceinline__ void run_network(float (&v)[N], std::index_sequence<I
         ...);
 }
 
+// v_cmp_class mask: signalling NaN, quiet NaN, negative zero
+constexpr int kSpecialClass = 0x1 | 0x2 | 0x20;
+__device__ __forceinline__ bool is_special(float v) { return __builtin_amdgcn_classf(v, kSpecialClass); }
+
+// What the reference's insertion sort (median_2d.cu:52-63) leaves at index r*r/2 of the window gathered in its
+// order (descending offsets, :281-287), for ANY contents.  With `temp < window[j]` as the only comparison
+//  * a NaN is never moved and never passed: the NaNs stay at their gather positions and the values between two
+//    of them are sorted among themselves;
+//  * equal values (and -0 / +0, which compare equal) keep their gather order (the sort is stable).
+// So the result is the NaN sitting at r*r/2, or the element of stable rank r*r/2 - a in the run [a, b) of gather
+// positions between the nearest NaNs on either side.  O(n^2) loads (L1 hits); only rare windows come here.
+template <int R>
+__device__ __noinline__ float exact_median(const float* __restrict__ in, int x, int y, int w, int h, int pitch)
+{
+    constexpr int N = R * R, R2 = R / 2, M = N / 2;
+    auto at = [&](int k) {
+        const int iy = k / R, ix = k - iy * R;
+        return in[static_cast<size_t>(mirror_index(y - iy + R2, h)) * pitch + mirror_index(x - ix + R2, w)];
+    };
+    const float vm = at(M);
+    if (vm != vm) return vm;
+    int a = 0, b = N;
+    for (int k = 0; k < N; ++k) {
+        const float v = at(k);
+        if (v != v) {
+            if (k < M) a = k + 1;
+            else if (b == N) b = k;
+        }
+    }
+    const int target = M - a;
+    for (int i = a; i < b; ++i) {
+        const float vi = at(i);
+        int rank = 0;
+        for (int j = a; j < b; ++j) {
+            const float vj = at(j);
+            rank += (vj < vi || (vj == vi && j < i)) ? 1 : 0;
+        }
+        if (rank == target) return vi;
+    }
+    return vm;  // not reached: the ranks of a run are a permutation of 0 .. b-a-1
+}
+
 // (grid.z = 2 filters a second, independent plane in the same launch: the flow's u and v)
 template <int R>
 __global__ __launch_bounds__(256) void median_kernel(const float* __restrict__ in_a, const float* __restrict__ in_b, int w,
@@ -100,14 +146,20 @@ __global__ __launch_bounds__(256) void median_kernel(const float* __restrict__ i
 #pragma unroll
     for (int i = 0; i < R; ++i) xs[i] = mirror_index(x + i - R2, w);
     float v[N];
+    bool special = false;
 #pragma unroll
     for (int j = 0; j < R; ++j) {
         const float* row = in + static_cast<size_t>(mirror_index(y + j - R2, h)) * pitch;
 #pragma unroll
-        for (int i = 0; i < R; ++i) v[j * R + i] = row[xs[i]];
+        for (int i = 0; i < R; ++i) {
+            v[j * R + i] = row[xs[i]];
+            special |= is_special(v[j * R + i]);
+        }
     }
     run_network<N>(v, std::make_index_sequence<network_size<N>()>{});
-    out[static_cast<size_t>(y) * pitch + x] = v[N / 2];
+    float result = v[N / 2];
+    if (special) result = exact_median<R>(in, x, y, w, h, pitch);
+    out[static_cast<size_t>(y) * pitch + x] = result;
 }
 
 // ---- r = 5, streaming -----------------------------------------------------------------------------------------
@@ -161,17 +213,23 @@ struct RowLoad {
     float v[EDGE ? 5 : 1];
 };
 
+// `special` collects whether any value this lane loaded is a NaN or a -0 (one v_cmp_class per load; the strip is
+// re-checked per pixel only when some lane of the wave saw one)
 template <bool EDGE>
 __device__ __forceinline__ RowLoad<EDGE> load_row(const float* __restrict__ in, int row, int h, int pitch, int xc,
-                                                  const int (&xm)[5])
+                                                  const int (&xm)[5], bool& special)
 {
     const float* line = in + static_cast<size_t>(min(max(mirror_index(row, h), 0), h - 1)) * pitch;
     RowLoad<EDGE> r;
     if (EDGE) {
 #pragma unroll
-        for (int i = 0; i < 5; ++i) r.v[i] = line[xm[i]];
+        for (int i = 0; i < 5; ++i) {
+            r.v[i] = line[xm[i]];
+            special |= is_special(r.v[i]);
+        }
     } else {
         r.v[0] = line[xc];
+        special |= is_special(r.v[0]);
     }
     return r;
 }
@@ -200,13 +258,13 @@ __device__ __forceinline__ void sorted_tuple(const RowLoad<EDGE>& r, float (&t)[
 template <bool EDGE, int I>
 __device__ __forceinline__ void median5_step(float (&ring)[6][5], RowLoad<EDGE> (&next)[2], const float* __restrict__ in,
                                              float* __restrict__ out, int ya, int y1, int h, int pitch, int x, int xc,
-                                             const int (&xm)[5], bool lane_stores)
+                                             const int (&xm)[5], bool lane_stores, bool& special)
 {
     // rows ya+2 and ya+3 were requested one step ago; request the two after them before working
     sorted_tuple<EDGE>(next[0], ring[(2 * I + 4) % 6]);
     sorted_tuple<EDGE>(next[1], ring[(2 * I + 5) % 6]);
-    next[0] = load_row<EDGE>(in, ya + 4, h, pitch, xc, xm);
-    next[1] = load_row<EDGE>(in, ya + 5, h, pitch, xc, xm);
+    next[0] = load_row<EDGE>(in, ya + 4, h, pitch, xc, xm, special);
+    next[1] = load_row<EDGE>(in, ya + 5, h, pitch, xc, xm, special);
     float v[kMedianPairWires];
 #pragma unroll
     for (int g = 0; g < 6; ++g)
@@ -230,23 +288,37 @@ __device__ __forceinline__ void median5_strip(const float* __restrict__ in, floa
 #pragma unroll
     for (int i = 0; i < 5; ++i) xm[i] = min(max(mirror_index(x + i - 2, w), 0), w - 1);
     float ring[6][5];
+    bool special = false;
     // rows y0-2 .. y0+1 fill slots 0..3; rows y0+2, y0+3 are the first pair in flight
     {
         RowLoad<EDGE> first[4];
 #pragma unroll
-        for (int g = 0; g < 4; ++g) first[g] = load_row<EDGE>(in, y0 - 2 + g, h, pitch, xc, xm);
+        for (int g = 0; g < 4; ++g) first[g] = load_row<EDGE>(in, y0 - 2 + g, h, pitch, xc, xm, special);
 #pragma unroll
         for (int g = 0; g < 4; ++g) sorted_tuple<EDGE>(first[g], ring[g]);
 #pragma unroll
         for (int e = 0; e < 5; ++e) ring[4][e] = ring[5][e] = 0.f;
     }
-    RowLoad<EDGE> next[2] = {load_row<EDGE>(in, y0 + 2, h, pitch, xc, xm), load_row<EDGE>(in, y0 + 3, h, pitch, xc, xm)};
+    RowLoad<EDGE> next[2] = {load_row<EDGE>(in, y0 + 2, h, pitch, xc, xm, special),
+                             load_row<EDGE>(in, y0 + 3, h, pitch, xc, xm, special)};
     for (int ya = y0; ya < y1; ya += 6) {
-        median5_step<EDGE, 0>(ring, next, in, out, ya, y1, h, pitch, x, xc, xm, lane_stores);
+        median5_step<EDGE, 0>(ring, next, in, out, ya, y1, h, pitch, x, xc, xm, lane_stores, special);
         if (ya + 2 >= y1) break;
-        median5_step<EDGE, 1>(ring, next, in, out, ya + 2, y1, h, pitch, x, xc, xm, lane_stores);
+        median5_step<EDGE, 1>(ring, next, in, out, ya + 2, y1, h, pitch, x, xc, xm, lane_stores, special);
         if (ya + 4 >= y1) break;
-        median5_step<EDGE, 2>(ring, next, in, out, ya + 4, y1, h, pitch, x, xc, xm, lane_stores);
+        median5_step<EDGE, 2>(ring, next, in, out, ya + 4, y1, h, pitch, x, xc, xm, lane_stores, special);
+    }
+    // Some lane of this wave loaded a NaN or a -0: every window of the strip is a subset of what the wave loaded,
+    // so look at each stored pixel's window again and redo those that hold one the way the reference's sort would.
+    if (__builtin_amdgcn_ballot_w64(special) != 0 && lane_stores) {
+        for (int y = y0; y < y1; ++y) {
+            bool hit = false;
+            for (int j = -2; j <= 2; ++j) {
+                const float* line = in + static_cast<size_t>(mirror_index(y + j, h)) * pitch;
+                for (int i = -2; i <= 2; ++i) hit |= is_special(line[mirror_index(x + i, w)]);
+            }
+            if (hit) out[static_cast<size_t>(y) * pitch + x] = exact_median<5>(in, x, y, w, h, pitch);
+        }
     }
 }
 

@@ -1,7 +1,8 @@
 // Per-sweep solver kernels of the flow2d hot path for gfx950: the robust weights (phi, ksi) and
-// one Jacobi sweep of the 2-field Euler-Lagrange system, brightness and gradient constancy.
+// one Jacobi sweep of the 2-field Euler-Lagrange system: brightness, gradient and log-derivative constancy.
 // One launch here corresponds to one launch of the reference
-// (compute_phi_ksi / solve_2d / solve_2d_grad, src/kernels/solve_2d.cu:43-198, 200-377, 683-952).
+// (compute_phi_ksi / solve_2d / solve_2d_log / solve_2d_grad, src/kernels/solve_2d.cu:43-198, 200-377, 391-669,
+// 683-952).
 //
 // Mapping: one wave = 64 consecutive pixels of one image row, so each of the 8 input planes is
 // read as contiguous 256-byte row segments; the x+-1 / y+-1 neighbours of a wave come from the same
@@ -183,6 +184,73 @@ __global__ __launch_bounds__(512) void sweep_grad_kernel(const float* __restrict
     jacobi_update(u, v, du, dv, phi, ksi, n, x, y, w, h, hx, hy, alpha, J11, J22, J12, J13, J23, tdu, tdv);
 }
 
+// ---- solve_2d_log: src/kernels/solve_2d.cu:391-669 (DataConstancy::LogDerivatives) ---------------------
+// solve_2d_grad on log(I + 1.0f) -- with one more tile effect: the halo offsets of this kernel are
+// `global_x - 1 + 1` etc. (= 0, :448,462,476,490), so the halo of EVERY plane (frames, u, v, du, dv, phi, ksi)
+// holds the 16x8 block's own edge pixel.  Inside a block a neighbour is the true one; a block that sticks out of
+// the image has its out-of-range threads load the reflected pixel (:434-435), which the last in-range pixel reads.
+__device__ __forceinline__ Neighbourhood neighbourhood_log(int x, int y, int w, int h, int pitch)
+{
+    const int xl = (x % kGradTileX == 0) ? x : x - 1;
+    const int xr = (x % kGradTileX == kGradTileX - 1) ? x : mirror_index(x + 1, w);
+    const int yu = (y % kGradTileY == 0) ? y : y - 1;
+    const int yd = (y % kGradTileY == kGradTileY - 1) ? y : mirror_index(y + 1, h);
+    const size_t rc = static_cast<size_t>(y) * pitch;
+    Neighbourhood n;
+    n.c = rc + x;
+    n.l = rc + xl;
+    n.r = rc + xr;
+    n.u = static_cast<size_t>(yu) * pitch + x;
+    n.d = static_cast<size_t>(yd) * pitch + x;
+    return n;
+}
+
+__global__ __launch_bounds__(512) void sweep_log_kernel(const float* __restrict__ f0, const float* __restrict__ f1,
+                                                        const float* __restrict__ u, const float* __restrict__ v,
+                                                        const float* __restrict__ du, const float* __restrict__ dv,
+                                                        const float* __restrict__ phi, const float* __restrict__ ksi,
+                                                        int w, int h, int pitch, float hx, float hy, float alpha,
+                                                        float* __restrict__ tdu, float* __restrict__ tdv)
+{
+    __shared__ float s_fx[kGradTileY][kBlockX];
+    __shared__ float s_fy[kGradTileY][kBlockX];
+    __shared__ float s_ft[kGradTileY][kBlockX];
+
+    const int tx = threadIdx.x, ty = threadIdx.y;
+    const int x = blockIdx.x * kBlockX + tx;
+    const int y = blockIdx.y * kGradTileY + ty;
+    const bool inside = x < w && y < h;
+    Neighbourhood n{};
+    if (inside) {
+        n = neighbourhood_log(x, y, w, h, pitch);
+        using flow2d_math::log1p_frame;
+        s_fx[ty][tx] = flow2d_math::diff4(log1p_frame(f0[n.r]), log1p_frame(f0[n.l]), log1p_frame(f1[n.r]),
+                                          log1p_frame(f1[n.l]), 4.f * hx);   // :519-522
+        s_fy[ty][tx] = flow2d_math::diff4(log1p_frame(f0[n.d]), log1p_frame(f0[n.u]), log1p_frame(f1[n.d]),
+                                          log1p_frame(f1[n.u]), 4.f * hy);   // :523-526
+        s_ft[ty][tx] = log1p_frame(f1[n.c]) - log1p_frame(f0[n.c]);          // :534-535
+    }
+    __syncthreads();
+    if (!inside) return;
+
+    // fx, fy, ft: own value replicated at the block edge (:542-565); unwritten slot at the image edge -> own value
+    const int xa = (tx % kGradTileX == 0) ? tx : tx - 1;
+    const int xb = (tx % kGradTileX == kGradTileX - 1 || x == w - 1) ? tx : tx + 1;
+    const int ya = (ty == 0) ? ty : ty - 1;
+    const int yb = (ty == kGradTileY - 1 || y == h - 1) ? ty : ty + 1;
+    const float hx_1 = 1.0 / (2.0 * hx);  // :584-585
+    const float hy_1 = 1.0 / (2.0 * hy);
+    const float fxx = (s_fx[ty][xb] - s_fx[ty][xa]) * hx_1;
+    const float fxy = (s_fx[yb][tx] - s_fx[ya][tx]) * hy_1;
+    const float fyy = (s_fy[yb][tx] - s_fy[ya][tx]) * hy_1;
+    const float fxt = (s_ft[ty][xb] - s_ft[ty][xa]) * hx_1;
+    const float fyt = (s_ft[yb][tx] - s_ft[ya][tx]) * hy_1;
+    float J11, J22, J12, J13, J23;
+    flow2d_math::gradient_tensor(fxx, fxy, fyy, fxt, fyt, J11, J22, J12, J13, J23);
+    // the smoothness term sees the same block-edge replication through n (:612-633)
+    jacobi_update(u, v, du, dv, phi, ksi, n, x, y, w, h, hx, hy, alpha, J11, J22, J12, J13, J23, tdu, tdv);
+}
+
 // ---- gradient constancy with true neighbours (FLOW2D_CONSTANCY_GRADIENT_UNTILED; not a reference kernel) ------
 // Same motion tensor as solve_2d_grad, but the second derivatives are central differences of fx, fy, ft over the
 // real neighbours x+-1, y+-1 (reflected at the image border like every other neighbour of the solver) instead of
@@ -324,6 +392,10 @@ int launch_sweep(flow2d_context* ctx, int constancy, const float* f0, const floa
         const dim3 grid(div_up(w, kBlockX), div_up(h, kGradTileY));
         sweep_grad_kernel<<<grid, dim3(kBlockX, kGradTileY), 0, ctx->stream>>>(
             f0, f1, u, v, du, dv, phi, ksi, (int)w, (int)h, (int)(pitch_bytes / 4), hx, hy, alpha, tdu, tdv);
+    } else if (constancy == FLOW2D_CONSTANCY_LOG_DERIVATIVES) {
+        const dim3 grid(div_up(w, kBlockX), div_up(h, kGradTileY));
+        sweep_log_kernel<<<grid, dim3(kBlockX, kGradTileY), 0, ctx->stream>>>(
+            f0, f1, u, v, du, dv, phi, ksi, (int)w, (int)h, (int)(pitch_bytes / 4), hx, hy, alpha, tdu, tdv);
     } else if (constancy == FLOW2D_CONSTANCY_GRADIENT_UNTILED) {
         const dim3 grid(div_up(w, kBlockX), div_up(h, kBlockY));
         sweep_grad_untiled_kernel<<<grid, dim3(kBlockX, kBlockY), 0, ctx->stream>>>(
@@ -431,6 +503,15 @@ int flow2d_solve_2d_grad(flow2d_context* ctx, const float* frame_0, const float*
 {
     return sweep_entry(ctx, FLOW2D_CONSTANCY_GRADIENT, frame_0, frame_1, flow_u, flow_v, flow_du, flow_dv, phi, ksi,
                        width, height, pitch_bytes, hx, hy, equation_alpha, temp_du, temp_dv);
+}
+
+int flow2d_solve_2d_log(flow2d_context* ctx, const float* frame_0, const float* frame_1, const float* flow_u,
+                        const float* flow_v, const float* flow_du, const float* flow_dv, const float* phi,
+                        const float* ksi, size_t width, size_t height, size_t pitch_bytes, float hx, float hy,
+                        float equation_alpha, float* temp_du, float* temp_dv)
+{
+    return sweep_entry(ctx, FLOW2D_CONSTANCY_LOG_DERIVATIVES, frame_0, frame_1, flow_u, flow_v, flow_du, flow_dv, phi,
+                       ksi, width, height, pitch_bytes, hx, hy, equation_alpha, temp_du, temp_dv);
 }
 
 int flow2d_solve_2d_grad_untiled(flow2d_context* ctx, const float* frame_0, const float* frame_1, const float* flow_u,

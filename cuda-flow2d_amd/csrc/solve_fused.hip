@@ -94,7 +94,10 @@ __device__ __forceinline__ v2f from_right2(v2f v) { return v2f{from_right(v.x), 
 __device__ __forceinline__ v2f pick2(bool c, v2f a, v2f b) { return v2f{c ? a.x : b.x, c ? a.y : b.y}; }
 
 // GRAD: 0 brightness constancy, 1 gradient constancy with the reference's 16x8 tile rule, 2 gradient constancy with
-// true neighbours (FLOW2D_CONSTANCY_GRADIENT_UNTILED)
+// true neighbours (FLOW2D_CONSTANCY_GRADIENT_UNTILED), 3 solve_2d_log (solve_2d.cu:391-669): as 1 on log(I + 1),
+// and every x/y neighbour of the tensor's first derivatives, of phi in the face weights and of the flow in the sweeps
+// is the pixel's own value at a 16x8 block edge (that kernel's halo offsets are 0, :448,462,476,490).  phi and ksi
+// themselves come from compute_phi_ksi in every mode: brightness tensor, true neighbours.
 template <int INNER, int GRAD>
 struct Strip {
     static constexpr int kHalo = INNER + 1;
@@ -106,6 +109,7 @@ struct Strip {
     v2f uvw[3], duvw[3];
     float phiw[3];
     float fxw[3], fyw[3], ftw[3];  // GRAD only
+    float lf0w[3], lf1w[3];        // GRAD == 3 only: log(frame + 1) rows
     v2f UV[INNER][3];                // UV[k] = (u + du^k, v + dv^k) rows around the row sweep k+1 is working on
     float dvc[INNER];                // dv^k of the row sweep k+1 processes in the current step
     Coef C[kRing];
@@ -155,6 +159,10 @@ __device__ __forceinline__ void strip_step(Strip<INNER, GRAD>& s, const FusedArg
     s.f1w[s0] = s.n_f1;
     s.uvw[s0] = s.n_uv;
     s.duvw[s0] = s.n_duv;
+    if (GRAD == 3) {
+        s.lf0w[s0] = log1p_frame(s.n_f0);
+        s.lf1w[s0] = log1p_frame(s.n_f1);
+    }
     {  // prefetch row r+1 (clamped: rows outside the image are never used by a stored pixel)
         const int rn = min(max(r + 1, 0), h - 1);
         const unsigned row_bytes = static_cast<unsigned>(rn) * static_cast<unsigned>(a.pitch) * 4u;
@@ -206,7 +214,19 @@ __device__ __forceinline__ void strip_step(Strip<INNER, GRAD>& s, const FusedArg
         fy = diff4s<POW2>(f0D, f0U, f1D, f1U, 4.f * a.hy, 1.f / (4.f * a.hy));
         ft = f1c - f0c;
         ksi = ksi_value(fx, fy, ft, s.duvw[s1].x, s.duvw[s1].y, a.e_data);
-        if (GRAD) {
+        if (GRAD == 3) {
+            // first derivatives of log(I + 1) with the block rule of solve_2d_log (:519-535 over the halo of :446-503)
+            const bool x_lo = (x & 15) == 0, x_hi = (x & 15) == 15, y_lo = (rp & 7) == 0, y_hi = (rp & 7) == 7;
+            const float l0c = s.lf0w[s1], l1c = s.lf1w[s1];
+            const float l0l0 = from_left(l0c), l0r0 = from_right(l0c), l1l0 = from_left(l1c), l1r0 = from_right(l1c);
+            const float l0L = x_lo ? l0c : l0l0, l0R = x_hi ? l0c : (at_r ? l0l0 : l0r0);
+            const float l1L = x_lo ? l1c : l1l0, l1R = x_hi ? l1c : (at_r ? l1l0 : l1r0);
+            const float l0U = y_lo ? l0c : s.lf0w[s2], l0D = y_hi ? l0c : (bot ? s.lf0w[s2] : s.lf0w[s0]);
+            const float l1U = y_lo ? l1c : s.lf1w[s2], l1D = y_hi ? l1c : (bot ? s.lf1w[s2] : s.lf1w[s0]);
+            s.fxw[s1] = diff4s<POW2>(l0R, l0L, l1R, l1L, 4.f * a.hx, 1.f / (4.f * a.hx));
+            s.fyw[s1] = diff4s<POW2>(l0D, l0U, l1D, l1U, 4.f * a.hy, 1.f / (4.f * a.hy));
+            s.ftw[s1] = l1c - l0c;
+        } else if (GRAD) {
             s.fxw[s1] = fx;
             s.fyw[s1] = fy;
             s.ftw[s1] = ft;
@@ -222,8 +242,17 @@ __device__ __forceinline__ void strip_step(Strip<INNER, GRAD>& s, const FusedArg
         const bool top = EDGE && (rw == 0), bot = EDGE && (rw == h - 1);
         const float pc = s.phiw[s2];
         const float pl0 = from_left(pc), pr0 = from_right(pc);
-        const v2f p_rl = v2f{at_r ? pl0 : pr0, at_l ? pr0 : pl0};                       // (phi[x+1], phi[x-1])
-        const float pU = top ? s.phiw[s1] : s.phiw[s0], pD = bot ? s.phiw[s0] : s.phiw[s1];
+        v2f p_rl;                                                                        // (phi[x+1], phi[x-1])
+        float pU, pD;
+        if (GRAD == 3) {  // own value at the 16x8 block edge, reflected pixel where the block leaves the image
+            p_rl = v2f{(x & 15) == 15 ? pc : (at_r ? pl0 : pr0), (x & 15) == 0 ? pc : pl0};
+            pU = (rw & 7) == 0 ? pc : s.phiw[s0];
+            pD = (rw & 7) == 7 ? pc : (bot ? s.phiw[s0] : s.phiw[s1]);
+        } else {
+            p_rl = v2f{at_r ? pl0 : pr0, at_l ? pr0 : pl0};
+            pU = top ? s.phiw[s1] : s.phiw[s0];
+            pD = bot ? s.phiw[s0] : s.phiw[s1];
+        }
         const float yp = EDGE ? static_cast<float>(rw < h - 1) * hy_2 : hy_2;
         const float ym = EDGE ? static_cast<float>(rw > 0) * hy_2 : hy_2;
         c.wx = (p_rl + pc) / 2.f * xpm;                                                  // face_phi * (xp, xm)
@@ -246,7 +275,7 @@ __device__ __forceinline__ void strip_step(Strip<INNER, GRAD>& s, const FusedArg
             const float fx_l0 = from_left(fxc), fx_r0 = from_right(fxc);
             const float ft_l0 = from_left(ftc), ft_r0 = from_right(ftc);
             float fx_l, fx_r, ft_l, ft_r, fx_u, fx_d, fy_u, fy_d, ft_u, ft_d;
-            if (GRAD == 1) {  // the reference's tile rule: own value at the 16x8 block edge and at the image edge
+            if (GRAD == 1 || GRAD == 3) {  // the reference's tile rule: own value at the 16x8 block edge and at the image edge
                 const int tx = x & 15, ty = rw & 7;
                 const bool x_lo = (tx == 0), x_hi = (tx == 15) || (x == w - 1);
                 const bool y_lo = (ty == 0), y_hi = (ty == 7) || (rw == h - 1);
@@ -296,8 +325,16 @@ __device__ __forceinline__ void strip_step(Strip<INNER, GRAD>& s, const FusedArg
         const bool top = EDGE && (rk == 0), bot = EDGE && (rk == h - 1);
         const v2f n_c = s.UV[k - 1][sc];
         const v2f n_l0 = from_left2(n_c), n_r0 = from_right2(n_c);
-        const v2f nL = pick2(at_l, n_r0, n_l0), nR = pick2(at_r, n_l0, n_r0);
-        const v2f nU = pick2(top, s.UV[k - 1][sd], s.UV[k - 1][su]), nD = pick2(bot, s.UV[k - 1][su], s.UV[k - 1][sd]);
+        v2f nL, nR, nU, nD;
+        if (GRAD == 3) {  // solve_2d_log: the flow neighbours follow the block rule too (:612-633)
+            nL = pick2((x & 15) == 0, n_c, n_l0);
+            nR = pick2((x & 15) == 15, n_c, pick2(at_r, n_l0, n_r0));
+            nU = pick2((rk & 7) == 0, n_c, s.UV[k - 1][su]);
+            nD = pick2((rk & 7) == 7, n_c, pick2(bot, s.UV[k - 1][su], s.UV[k - 1][sd]));
+        } else {
+            nL = pick2(at_l, n_r0, n_l0), nR = pick2(at_r, n_l0, n_r0);
+            nU = pick2(top, s.UV[k - 1][sd], s.UV[k - 1][su]), nD = pick2(bot, s.UV[k - 1][su], s.UV[k - 1][sd]);
+        }
         const v2f sums = sum_flux2(c.wx, c.wy, nR, nL, nD, nU, c.uvc);  // (sumU, sumV)
         float du_new, dv_new;
         point_update(c.ksi, c.den.x, c.den.y, c.J12, c.J13_23.x, c.J13_23.y, sums.x, sums.y, dv_in, du_new, dv_new);
@@ -370,6 +407,7 @@ __global__ __launch_bounds__(256, 2) void fused_outer_kernel(FusedArgs a)
         s.f0w[i] = s.f1w[i] = s.phiw[i] = 0.f;
         s.uvw[i] = s.duvw[i] = v2f{0.f, 0.f};
         s.fxw[i] = s.fyw[i] = s.ftw[i] = 0.f;
+        s.lf0w[i] = s.lf1w[i] = 0.f;
     }
 #pragma unroll
     for (int k = 0; k < INNER; ++k) {
@@ -516,6 +554,9 @@ int launch_fused_outer(flow2d_context* ctx, int constancy, const float* f0, cons
     else if (constancy == FLOW2D_CONSTANCY_GRADIENT_UNTILED)
         rc = pow2 ? launch_for_inner<2, true>((int)inner, grid, ctx->stream, a)
                   : launch_for_inner<2, false>((int)inner, grid, ctx->stream, a);
+    else if (constancy == FLOW2D_CONSTANCY_LOG_DERIVATIVES)
+        rc = pow2 ? launch_for_inner<3, true>((int)inner, grid, ctx->stream, a)
+                  : launch_for_inner<3, false>((int)inner, grid, ctx->stream, a);
     else
         rc = pow2 ? launch_for_inner<0, true>((int)inner, grid, ctx->stream, a)
                   : launch_for_inner<0, false>((int)inner, grid, ctx->stream, a);

@@ -70,7 +70,7 @@ int flow2d_solve_level(flow2d_context* ctx, const float* frame_0, const float* f
     if (p->width < 2 || p->height < 2 || p->container_height < p->height || !(p->hx > 0.f) || !(p->hy > 0.f))
         return FLOW2D_ERR_INVALID_ARGUMENT;
     if (p->data_constancy != FLOW2D_CONSTANCY_GREY && p->data_constancy != FLOW2D_CONSTANCY_GRADIENT &&
-        p->data_constancy != FLOW2D_CONSTANCY_GRADIENT_UNTILED)
+        p->data_constancy != FLOW2D_CONSTANCY_GRADIENT_UNTILED && p->data_constancy != FLOW2D_CONSTANCY_LOG_DERIVATIVES)
         return FLOW2D_ERR_UNSUPPORTED;
     if (p->algorithm < FLOW2D_SOLVER_AUTO || p->algorithm > FLOW2D_SOLVER_SINGLE_WORKGROUP)
         return FLOW2D_ERR_INVALID_ARGUMENT;
@@ -78,6 +78,7 @@ int flow2d_solve_level(flow2d_context* ctx, const float* frame_0, const float* f
     const bool sor = p->sor_omega != 0.f;
     if (sor && (!(p->sor_omega > 0.f) || !(p->sor_omega < 2.f))) return FLOW2D_ERR_INVALID_ARGUMENT;
     if (sor && p->algorithm != FLOW2D_SOLVER_AUTO && p->algorithm != FLOW2D_SOLVER_PER_SWEEP) return FLOW2D_ERR_UNSUPPORTED;
+    if (sor && p->data_constancy == FLOW2D_CONSTANCY_LOG_DERIVATIVES) return FLOW2D_ERR_UNSUPPORTED;
     int algorithm = sor ? FLOW2D_SOLVER_PER_SWEEP : p->algorithm;
     if (algorithm == FLOW2D_SOLVER_AUTO) {
         // Up to 64 x 32 the whole level runs in one launch on one CU (solve_small.hip; measured 0.06-0.10 ms

@@ -34,6 +34,8 @@ struct SmallArgs {
     int outer, inner;
     float hx, hy, alpha, e_smooth, e_data;
     int untiled;  // gradient constancy only: true neighbours instead of the reference's 16x8 tile rule
+    int log;      // solve_2d_log (solve_2d.cu:391-669): tensor from log(I + 1); x/y neighbours of the frames, of phi in
+                  // the face weights and of the flow in the sweeps are the pixel's own value at a 16x8 block edge
 };
 
 __device__ __forceinline__ int at(int x, int y) { return (y + 1) * kStride + (x + 1); }
@@ -65,6 +67,14 @@ __global__ __launch_bounds__(1024) void small_level_kernel(SmallArgs a)
     const int x = threadIdx.x;       // 0..63
     const int y_base = threadIdx.y * kPx;
     const bool col_ok = x < w;
+
+    // neighbour columns / rows of the face weights and of the sweeps: x-1, x+1, y-1, y+1 (the LDS halo holds the
+    // reflected pixel), except in solve_2d_log mode, where a 16x8 block edge sees the pixel itself
+    const bool logm = GRAD && a.log;
+    const int xl_n = (logm && (x & 15) == 0) ? x : x - 1;
+    const int xr_n = (logm && (x & 15) == 15) ? x : x + 1;
+    auto up_of = [&](int y) { return (logm && (y & 7) == 0) ? y : y - 1; };
+    auto down_of = [&](int y) { return (logm && (y & 7) == 7) ? y : y + 1; };
 
     float uc[kPx], vc[kPx], du[kPx], dv[kPx];
     float fx[kPx], fy[kPx], ft[kPx];          // brightness derivatives (ksi; Grey tensor)
@@ -107,15 +117,49 @@ __global__ __launch_bounds__(1024) void small_level_kernel(SmallArgs a)
         }
     }
     if (GRAD) {
+        // what the tensor differentiates: fx, fy, ft of the frames, or (log mode) of log(frame + 1) with the block rule
+        float gx[kPx], gy[kPx], gt[kPx];
+#pragma unroll
+        for (int j = 0; j < kPx; ++j) {
+            gx[j] = fx[j];
+            gy[j] = fy[j];
+            gt[j] = ft[j];
+        }
+        if (logm) {
+            float r0[kPx], r1[kPx];
+#pragma unroll
+            for (int j = 0; j < kPx; ++j) {
+                r0[j] = ok[j] ? P_uu[at(x, y_base + j)] : 0.f;
+                r1[j] = ok[j] ? P_vv[at(x, y_base + j)] : 0.f;
+            }
+            __syncthreads();  // every brightness read of the raw frames is done
+#pragma unroll
+            for (int j = 0; j < kPx; ++j)
+                if (ok[j]) {
+                    put(P_uu, x, y_base + j, w, h, log1p_frame(r0[j]));
+                    put(P_vv, x, y_base + j, w, h, log1p_frame(r1[j]));
+                }
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < kPx; ++j) {
+                const int y = y_base + j;
+                if (ok[j]) {  // solve_2d.cu:519-535
+                    gx[j] = diff4(P_uu[at(xr_n, y)], P_uu[at(xl_n, y)], P_vv[at(xr_n, y)], P_vv[at(xl_n, y)], 4.f * a.hx);
+                    gy[j] = diff4(P_uu[at(x, down_of(y))], P_uu[at(x, up_of(y))], P_vv[at(x, down_of(y))],
+                                  P_vv[at(x, up_of(y))], 4.f * a.hy);
+                    gt[j] = P_vv[at(x, y)] - P_uu[at(x, y)];
+                }
+            }
+        }
         // second derivatives inside the reference's 16x8 blocks with the block's edge value replicated
         // (solve_2d.cu:816-841,872-884); planes kDU, kDV, kPhi hold fx, fy, ft for this step only
         __syncthreads();
 #pragma unroll
         for (int j = 0; j < kPx; ++j)
             if (ok[j]) {
-                P_du[at(x, y_base + j)] = fx[j];
-                P_dv[at(x, y_base + j)] = fy[j];
-                P_phi[at(x, y_base + j)] = ft[j];
+                P_du[at(x, y_base + j)] = gx[j];
+                P_dv[at(x, y_base + j)] = gy[j];
+                P_phi[at(x, y_base + j)] = gt[j];
             }
         __syncthreads();
         const float hx_1 = 1.0 / (2.0 * a.hx);  // double, rounded to float (solve_2d.cu:868-869)
@@ -192,10 +236,10 @@ __global__ __launch_bounds__(1024) void small_level_kernel(SmallArgs a)
                 const float yp = static_cast<float>(y < h - 1) * hy_2;
                 const float ym = static_cast<float>(y > 0) * hy_2;
                 const float pc = P_phi[at(x, y)];
-                wxp[j] = face_phi(P_phi[at(x + 1, y)], pc) * xp;
-                wxm[j] = face_phi(P_phi[at(x - 1, y)], pc) * xm;
-                wyp[j] = face_phi(P_phi[at(x, y + 1)], pc) * yp;
-                wym[j] = face_phi(P_phi[at(x, y - 1)], pc) * ym;
+                wxp[j] = face_phi(P_phi[at(xr_n, y)], pc) * xp;
+                wxm[j] = face_phi(P_phi[at(xl_n, y)], pc) * xm;
+                wyp[j] = face_phi(P_phi[at(x, down_of(y))], pc) * yp;
+                wym[j] = face_phi(P_phi[at(x, up_of(y))], pc) * ym;
                 const float sumH = sum_weights(wxp[j], wxm[j], wyp[j], wym[j]);
                 float J11, J22, J12, J13, J23;
                 tensor(j, J11, J22, J12, J13, J23);
@@ -216,10 +260,10 @@ __global__ __launch_bounds__(1024) void small_level_kernel(SmallArgs a)
                 const int y = y_base + j;
                 ndu[j] = ndv[j] = 0.f;
                 if (ok[j]) {
-                    const float sumU = sum_flux(wxp[j], wxm[j], wyp[j], wym[j], P_uu[at(x + 1, y)], P_uu[at(x - 1, y)],
-                                                P_uu[at(x, y + 1)], P_uu[at(x, y - 1)], uc[j]);
-                    const float sumV = sum_flux(wxp[j], wxm[j], wyp[j], wym[j], P_vv[at(x + 1, y)], P_vv[at(x - 1, y)],
-                                                P_vv[at(x, y + 1)], P_vv[at(x, y - 1)], vc[j]);
+                    const float sumU = sum_flux(wxp[j], wxm[j], wyp[j], wym[j], P_uu[at(xr_n, y)], P_uu[at(xl_n, y)],
+                                                P_uu[at(x, down_of(y))], P_uu[at(x, up_of(y))], uc[j]);
+                    const float sumV = sum_flux(wxp[j], wxm[j], wyp[j], wym[j], P_vv[at(xr_n, y)], P_vv[at(xl_n, y)],
+                                                P_vv[at(x, down_of(y))], P_vv[at(x, up_of(y))], vc[j]);
                     float J11, J22, J12, J13, J23;
                     tensor(j, J11, J22, J12, J13, J23);
                     point_update(ksi[j], den_u[j], den_v[j], J12, J13, J23, sumU, sumV, dv[j], ndu[j], ndv[j]);
@@ -260,10 +304,11 @@ int launch_small_level(flow2d_context* ctx, int constancy, const float* f0, cons
 {
     if (!small_level_supports(w, h)) return FLOW2D_ERR_UNSUPPORTED;
     SmallArgs a{f0, f1, u, v, out_du, out_dv, (int)w, (int)h, (int)(pitch_bytes / 4), (int)outer, (int)inner,
-                hx, hy, alpha, e_smooth, e_data, 0};
+                hx, hy, alpha, e_smooth, e_data, 0, 0};
     const dim3 block(kMaxSide, 1024 / kMaxSide);
     const bool grad = constancy != FLOW2D_CONSTANCY_GREY;
     a.untiled = constancy == FLOW2D_CONSTANCY_GRADIENT_UNTILED ? 1 : 0;
+    a.log = constancy == FLOW2D_CONSTANCY_LOG_DERIVATIVES ? 1 : 0;
     const int px = h <= 16 ? 1 : (h <= 32 ? 2 : 4);
     if (px == 1)
         grad ? small_level_kernel<true, 1><<<1, block, 0, ctx->stream>>>(a)

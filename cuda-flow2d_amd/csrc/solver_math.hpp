@@ -92,6 +92,11 @@ __device__ __forceinline__ void gradient_tensor(float fxx, float fxy, float fyy,
     J23 = fxy * fxt + fyy * fyt;
 }
 
+// log(I + 1.0f) of a frame value, solve_2d.cu:519-535 (solve_2d_log).  logf is the device library's; the
+// reference's kernel compiled for this GPU calls the same function, so the bits agree with it (a CPU libm's logf
+// may differ in the last place).
+__device__ __forceinline__ float log1p_frame(float value) { return logf(value + 1.0f); }
+
 // ---- two-wide forms: the u and v equations share their weights, so the pair (u, v) goes through
 // v_pk_add_f32 / v_pk_mul_f32 (one VALU issue for both fields).  Component by component these are the
 // scalar expressions above, in the same order; nothing is contracted into an FMA.

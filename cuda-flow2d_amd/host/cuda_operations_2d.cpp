@@ -205,12 +205,6 @@ bool CudaOperationSolve2D::Initialize(const OperationParameters* params)
         initialized_ = false;
         return false;
     }
-    if (constancy == DataConstancy::LogDerivatives) {
-        std::printf("Operation: '%s'. DataConstancy::LogDerivatives is not supported by the MI355X path.\n",
-                    GetName());
-        initialized_ = false;
-        return false;
-    }
     init_constancy_ = constancy;
     return true;
 }
@@ -257,7 +251,9 @@ void CudaOperationSolve2D::Execute(OperationParameters& params)
     p.height = data_size.height;
     p.pitch_bytes = dev_container_size_.pitch;
     p.container_height = dev_container_size_.height;
+    // the kernel is chosen by the constancy given to Initialize (cuda_operation_solve_2d.cpp:65-82)
     p.data_constancy = init_constancy_ == DataConstancy::Gradient          ? FLOW2D_CONSTANCY_GRADIENT
+                       : init_constancy_ == DataConstancy::LogDerivatives  ? FLOW2D_CONSTANCY_LOG_DERIVATIVES
                        : init_constancy_ == DataConstancy::GradientUntiled ? FLOW2D_CONSTANCY_GRADIENT_UNTILED
                                                                            : FLOW2D_CONSTANCY_GREY;
     p.algorithm = algorithm;

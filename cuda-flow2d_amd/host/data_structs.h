@@ -6,7 +6,6 @@
 
 enum class Methods { OpticalFlow, Correlation };
 
-// LogDerivatives is accepted by the type but not implemented by the MI355X path (out of scope).
 // Grey, Gradient, LogDerivatives: the reference's values (src/data_types/data_structs.h:27).  GradientUntiled is an
 // opt-in extra of this implementation (flow2d_c_abi.h, FLOW2D_CONSTANCY_GRADIENT_UNTILED): gradient constancy whose
 // second derivatives use the true neighbours instead of the reference's 16x8 launch tiles.

@@ -54,7 +54,7 @@ HOST_API void flow2d_host_adopt_context(flow2d_context* ctx) { AdoptDeviceContex
 HOST_API flow2d_context* flow2d_host_context(void) { return CurrentDeviceContext(); }
 HOST_API void flow2d_host_shutdown(void) { DestroyDeviceContext(); }
 
-// constancy: 0 Grey, 1 Gradient, 2 LogDerivatives (refused).  Returns nullptr on failure.
+// constancy: enum class DataConstancy (0 Grey, 1 Gradient, 2 LogDerivatives, 3 GradientUntiled).  nullptr on failure.
 HOST_API flow2d_host_flow* flow2d_host_flow_create(size_t width, size_t height, int constancy, int silent)
 {
     flow2d_host_flow* h = new (std::nothrow) flow2d_host_flow();
@@ -82,6 +82,13 @@ HOST_API size_t flow2d_host_flow_pitch(flow2d_host_flow* h) { return h ? h->flow
 HOST_API size_t flow2d_host_max_warp_level(flow2d_host_flow* h, size_t width, size_t height, float scale)
 {
     return h ? h->flow.GetMaxWarpLevel(width, height, scale) : 0;
+}
+
+// GetMaxWarpLevel needs no device (optical_flow_base_2d.cpp:36-59 is pure host arithmetic)
+HOST_API size_t flow2d_host_max_warp_level_static(size_t width, size_t height, float scale)
+{
+    OpticalFlow2D flow;
+    return flow.GetMaxWarpLevel(width, height, scale);
 }
 
 // OpticalFlow2D::ComputeFlow on tight host images (width*height floats each).  0 on success.
@@ -198,6 +205,14 @@ HOST_API int flow2d_host_read_raw(const char* path, size_t width, size_t height,
     if (!ok) return 1;
     std::memcpy(out, d.DataPtr(), width * height * sizeof(float));
     return 0;
+}
+
+// Data2D::WriteRAWToFileU8 / WriteRAWToFileF32 of a tight width x height image.  0 on success.
+HOST_API int flow2d_host_write_raw(const float* data, size_t width, size_t height, int u8, const char* path)
+{
+    Data2D d(width, height);
+    std::memcpy(d.DataPtr(), data, width * height * sizeof(float));
+    return (u8 ? d.WriteRAWToFileU8(path) : d.WriteRAWToFileF32(path)) ? 0 : 1;
 }
 
 HOST_API int flow2d_host_write_outputs(const float* u, const float* v, size_t width, size_t height,

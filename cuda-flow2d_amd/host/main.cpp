@@ -7,7 +7,7 @@
 // exit codes: 1 no device, 2 frame load failed, 3 settings error, 255 cannot write PPM/amp, 0 otherwise.
 // Documented supersets: imageType="8-bit" selects the u8 reader; inputPath is tried as
 // a prefix before the bare file name; argc == 6 no longer dereferences argv[6]; no blocking getchar();
-// options --u8, --gradient, --device N, --verbose, --sor OMEGA (opt-in red-black SOR, no reference parity)
+// options --u8, --gradient, --log-derivatives, --device N, --verbose, --sor OMEGA (opt-in red-black SOR, no reference parity)
 // may precede the positional arguments.
 #include <cstdio>
 #include <cstdlib>
@@ -51,6 +51,7 @@ int main(int argc, char** argv)
         if (!std::strcmp(argv[i], "--u8")) force_u8 = true;
         else if (!std::strcmp(argv[i], "--gradient")) data_constancy = DataConstancy::Gradient;
         else if (!std::strcmp(argv[i], "--gradient-untiled")) data_constancy = DataConstancy::GradientUntiled;
+        else if (!std::strcmp(argv[i], "--log-derivatives")) data_constancy = DataConstancy::LogDerivatives;
         else if (!std::strcmp(argv[i], "--verbose")) verbose = true;
         else if (!std::strcmp(argv[i], "--device") && i + 1 < argc) device = std::atoi(argv[++i]);
         else if (!std::strcmp(argv[i], "--sor") && i + 1 < argc) sor_omega = static_cast<float>(std::atof(argv[++i]));
@@ -119,6 +120,7 @@ int main(int argc, char** argv)
         if (settings.imageType == "8-bit") u8 = true;
         if (settings.dataConstancy == "gradient") data_constancy = DataConstancy::Gradient;
         if (settings.dataConstancy == "gradient-untiled") data_constancy = DataConstancy::GradientUntiled;
+        if (settings.dataConstancy == "log-derivatives") data_constancy = DataConstancy::LogDerivatives;
     } else {
         std::cout << "Usage: " << args[0] << " <settings file>. Otherwise settings.xml in the current directory is used"
                   << std::endl;

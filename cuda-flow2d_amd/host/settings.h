@@ -7,7 +7,7 @@
 // The reference parses with a vendored TinyXML and crashes on a missing element; this reader is a
 // ~100-line attribute scanner for the fixed schema and returns -1 instead.  Supersets:
 // imageType ("8-bit" | "32-bit", default 32-bit as main.cpp:175 reads F32) and an optional
-// /Parameters/Method@dataConstancy ("grey" | "gradient").
+// /Parameters/Method@dataConstancy ("grey" | "gradient" | "log-derivatives" | "gradient-untiled").
 #pragma once
 
 #include <string>

@@ -44,16 +44,18 @@ typedef enum flow2d_status {
     FLOW2D_ERR_UNSUPPORTED = 5       /* e.g. median window not in {3,5,7}, Gaussian longer than 51 taps */
 } flow2d_status;
 
-/* Data term.  GREY and GRADIENT are `enum class DataConstancy` Grey and Gradient of the reference
- * (src/data_types/data_structs.h:27); its LogDerivatives mode is out of scope (the host layer refuses it).
- * GRADIENT_UNTILED is an extra, opt-in mode with no counterpart in the reference: the gradient-constancy
+/* Data term.  GREY, GRADIENT and LOG_DERIVATIVES are `enum class DataConstancy` Grey, Gradient and LogDerivatives
+ * of the reference (src/data_types/data_structs.h:27), which selects solve_2d / solve_2d_grad / solve_2d_log with
+ * them (src/cuda_operations/2d/cuda_operation_solve_2d.cpp:65-82); the numeric values here are the C-ABI's own
+ * (the host layer maps the enum).  GRADIENT_UNTILED is an extra, opt-in mode with no counterpart in the reference: the gradient-constancy
  * tensor of solve_2d_grad with its second derivatives taken over the true neighbours (reflected at the image
  * border) instead of being cut at the reference's 16x8 launch tiles.  Results differ from
  * GRADIENT at tile edges by design. */
 typedef enum flow2d_constancy {
     FLOW2D_CONSTANCY_GREY = 0,
     FLOW2D_CONSTANCY_GRADIENT = 1,
-    FLOW2D_CONSTANCY_GRADIENT_UNTILED = 2
+    FLOW2D_CONSTANCY_GRADIENT_UNTILED = 2,
+    FLOW2D_CONSTANCY_LOG_DERIVATIVES = 3
 } flow2d_constancy;
 
 typedef struct flow2d_context flow2d_context; /* opaque: device ordinal + stream + scratch */
@@ -201,6 +203,15 @@ FLOW2D_API int flow2d_solve_2d_grad(flow2d_context* ctx, const float* frame_0, c
                                     size_t height, size_t pitch_bytes, float hx, float hy, float equation_alpha,
                                     float* temp_du, float* temp_dv);
 
+/* solve_2d_log (src/kernels/solve_2d.cu:391-669): one Jacobi sweep on the logarithmic derivatives
+ * (gradient constancy of log(I + 1)), including that kernel's block rule: every 16x8 block's halo -- of the
+ * frames, u, v, du, dv, phi and ksi alike -- holds the block's own edge pixel (:448,462,476,490). */
+FLOW2D_API int flow2d_solve_2d_log(flow2d_context* ctx, const float* frame_0, const float* frame_1,
+                                   const float* flow_u, const float* flow_v, const float* flow_du,
+                                   const float* flow_dv, const float* phi, const float* ksi, size_t width,
+                                   size_t height, size_t pitch_bytes, float hx, float hy, float equation_alpha,
+                                   float* temp_du, float* temp_dv);
+
 /* Opt-in red-black successive over-relaxation: ONE iteration = the pixels with even (x + y), then the odd
  * ones, relaxed in place on flow_du / flow_dv with factor omega in (0, 2).  NOT a reference kernel: the
  * reference relaxes with Jacobi sweeps, so this mode has no parity with it at equal iteration
@@ -219,7 +230,7 @@ FLOW2D_API int flow2d_solve_2d_sor(flow2d_context* ctx, const float* frame_0, co
  * does (:288-289).  No host synchronisation inside.  `algorithm`: see flow2d_solver_algorithm. */
 typedef enum flow2d_solver_algorithm {
     FLOW2D_SOLVER_AUTO = 0,      /* library picks the fastest bit-exact path for the level size */
-    FLOW2D_SOLVER_PER_SWEEP = 1, /* one launch per reference kernel launch (K6, K7/K9) */
+    FLOW2D_SOLVER_PER_SWEEP = 1, /* one launch per reference kernel launch (K6, K7/K9/K11) */
     FLOW2D_SOLVER_FUSED = 2,     /* phi/ksi + the inner sweeps of an outer iteration fused into ceil(inner / 5)
                                   * launches (one for inner <= 5); needs inner >= 1 */
     FLOW2D_SOLVER_SINGLE_WORKGROUP = 3 /* the whole level (all outer x inner iterations) in one launch on one

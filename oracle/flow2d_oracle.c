@@ -6,15 +6,23 @@
  * bench.py's cpu_baseline leg may call it.  The shipped path (cuda-flow2d_amd/) never links,
  * loads or falls back to anything in oracle/.
  *
- * PARITY STATUS: "parity unpinned" by the reference itself.  The reference ships no tests,
- * golden vectors or fixtures, and its own sources cannot be built in this image (they need
- * nvcc, cuda.h/libcuda and an NVIDIA GPU; building them here would require hand-written
- * stand-ins for the CUDA toolchain, which is not allowed).  What pins this file instead:
- *   (1) an independent numpy restatement (oracle/np_restatement.py) that must agree bit for
- *       bit on every kernel and end to end (tests/test_oracle.py);
- *   (2) the rub1/rub2 anchor statistics recorded in SURVEY.md section 8(c), which the survey
- *       obtained from the reference's own sources (tests/test_oracle.py::test_rub_anchors);
- *   (3) committed golden vectors generated by this oracle (tests/golden/) as regression pins.
+ * PARITY STATUS: pinned against the reference itself, two ways (the reference ships no tests or vectors of its own):
+ *   (1) its device kernels: src/kernels/{add,convolution,median,registration,resample,solve}_2d.cu are compiled
+ *       for gfx950 from where they lie (oracle/Makefile -> oracle/_ref/*.co, no FMA contraction) and run on an
+ *       MI355X through oracle/ref_driver.cpp (symbol names, launch geometry and argument order of the reference's
+ *       operator layer).  Their outputs on seeded inputs -- every kernel, CudaOperationSolve2D::Execute, and whole
+ *       ComputeFlow runs on rub1/rub2 (settings.xml values and main.cpp defaults) and synthetic pairs -- are the
+ *       fixture tests/golden/ref_kernels_golden.npz (tests/golden/make_ref_golden.py); this file reproduces them
+ *       bit for bit (tests/test_oracle.py::test_ref_golden_*), NaN / signed-zero median windows included.
+ *       Two documented exceptions: solve_2d_grad / solve_2d_log where the image edge falls inside a 16x8 block
+ *       (the reference reads unwritten shared memory there; see oracle_solve_2d_grad), and solve_2d_log's logf
+ *       (device library there, libm here: last-place differences).
+ *   (2) its host code: GetMaxWarpLevel, ComputeGaussianKernel (and, for the product's host layer, Data2D IO,
+ *       the colour-wheel writers, Settings, OperationParameters) are compiled from where they lie into
+ *       oracle/_ref/ref_host_probe and run in the build container; outputs in tests/golden/ref_host_golden.npz.
+ *   Besides: an independent numpy restatement (oracle/np_restatement.py) that agrees bit for bit, and the
+ *   anchors SURVEY.md 8(c) recorded.  The reference's host orchestration (optical_flow_2d.cpp, the operator
+ *   classes) needs libcuda and is not built; ref_driver.cpp restates it around the real kernels.
  *
  * Every function follows one reference function; the file:line it restates is cited above it
  * (paths relative to the reference repository root).  Arithmetic is fp32 with the reference's
@@ -352,37 +360,71 @@ static void grad_neighbours(long i, long n, long tile, int tiled, long* lo, long
     }
 }
 
+/* Neighbour indices of the EIGHT BASE PLANES in solve_2d_log (solve_2d.cu:448,462,476,490): the halo offsets
+ * there are `global_x - 1 + 1`, `global_x + 1 - 1`, ... = 0, so every 16x8 block's halo holds the block's own edge
+ * pixel; inside a block the neighbour is the true one, and a block that sticks out of the image has its
+ * out-of-range threads load the reflected pixel (:434-435), which is what the last in-range pixel then reads. */
+static void log_neighbours(long i, long n, long tile, long* lo, long* hi)
+{
+    *lo = (i % tile == 0) ? i : i - 1;
+    *hi = (i % tile == tile - 1) ? i : mirror_index(i + 1, n);
+}
+
+/* mode 0: Gradient over true neighbours (not a reference mode); 1: solve_2d_grad (:683-952);
+ * 2: solve_2d_log (:391-669) -- as 1 on log(I + 1.0f), with the block-edge replication applied to the frames,
+ * u, v, du, dv, phi and ksi as well.  lg0 / lg1, when non-NULL, are precomputed log(I + 1) planes of frame_0 /
+ * frame_1 (same pitch); NULL -> logf from libm, which is within an ulp of, but not bit-identical to, a GPU's. */
 static void solve_2d_grad_any(const float* f0, const float* f1, const float* u, const float* v, const float* du,
                               const float* dv, const float* phi, const float* ksi, size_t w, size_t h, size_t pitch,
-                              float hx, float hy, float alpha, float* tdu, float* tdv, int tiled)
+                              float hx, float hy, float alpha, float* tdu, float* tdv, int mode, const float* lg0,
+                              const float* lg1)
 {
     const float hx_2 = alpha / (hx * hx), hy_2 = alpha / (hy * hy);
     const float hx_1 = (float)(1.0 / (2.0 * (double)hx));
     const float hy_1 = (float)(1.0 / (2.0 * (double)hy));
+    const int tiled = mode != 0, logm = mode == 2;
     float* fxp = (float*)malloc(sizeof(float) * w * h);
     float* fyp = (float*)malloc(sizeof(float) * w * h);
     float* ftp = (float*)malloc(sizeof(float) * w * h);
+    float* l0 = NULL;
+    float* l1 = NULL;
+    if (logm && !(lg0 && lg1)) {
+        l0 = (float*)malloc(sizeof(float) * pitch * h);
+        l1 = (float*)malloc(sizeof(float) * pitch * h);
+#pragma omp parallel for schedule(static)
+        for (long y = 0; y < (long)h; ++y)
+            for (long x = 0; x < (long)w; ++x) {
+                l0[y * pitch + x] = logf(f0[y * pitch + x] + 1.0f);
+                l1[y * pitch + x] = logf(f1[y * pitch + x] + 1.0f);
+            }
+        lg0 = l0;
+        lg1 = l1;
+    }
+    const float* g0 = logm ? lg0 : f0;
+    const float* g1 = logm ? lg1 : f1;
 #pragma omp parallel for schedule(static)
     for (long y = 0; y < (long)h; ++y) {
-        size_t rc = (size_t)y * pitch;
-        size_t ru = (size_t)mirror_index(y - 1, (long)h) * pitch;
-        size_t rd = (size_t)mirror_index(y + 1, (long)h) * pitch;
+        long yu = mirror_index(y - 1, (long)h), yd = mirror_index(y + 1, (long)h);
+        if (logm) log_neighbours(y, (long)h, GRAD_TILE_Y, &yu, &yd);
+        size_t rc = (size_t)y * pitch, ru = (size_t)yu * pitch, rd = (size_t)yd * pitch;
         for (long x = 0; x < (long)w; ++x) {
-            size_t xl = (size_t)mirror_index(x - 1, (long)w), xr = (size_t)mirror_index(x + 1, (long)w);
-            fxp[y * w + x] = (f0[rc + xr] - f0[rc + xl] + f1[rc + xr] - f1[rc + xl]) / (4.f * hx);
-            fyp[y * w + x] = (f0[rd + x] - f0[ru + x] + f1[rd + x] - f1[ru + x]) / (4.f * hy);
-            ftp[y * w + x] = f1[rc + x] - f0[rc + x];
+            long xl = mirror_index(x - 1, (long)w), xr = mirror_index(x + 1, (long)w);
+            if (logm) log_neighbours(x, (long)w, GRAD_TILE_X, &xl, &xr);
+            fxp[y * w + x] = (g0[rc + xr] - g0[rc + xl] + g1[rc + xr] - g1[rc + xl]) / (4.f * hx);
+            fyp[y * w + x] = (g0[rd + x] - g0[ru + x] + g1[rd + x] - g1[ru + x]) / (4.f * hy);
+            ftp[y * w + x] = g1[rc + x] - g0[rc + x];
         }
     }
 #pragma omp parallel for schedule(static)
     for (long y = 0; y < (long)h; ++y) {
-        size_t rc = (size_t)y * pitch;
-        size_t ru = (size_t)mirror_index(y - 1, (long)h) * pitch;
-        size_t rd = (size_t)mirror_index(y + 1, (long)h) * pitch;
+        long yn = mirror_index(y - 1, (long)h), ys = mirror_index(y + 1, (long)h);
+        if (logm) log_neighbours(y, (long)h, GRAD_TILE_Y, &yn, &ys);
+        size_t rc = (size_t)y * pitch, ru = (size_t)yn * pitch, rd = (size_t)ys * pitch;
         long yu, yd;
         grad_neighbours(y, (long)h, GRAD_TILE_Y, tiled, &yu, &yd);
         for (long x = 0; x < (long)w; ++x) {
-            size_t xl = (size_t)mirror_index(x - 1, (long)w), xr = (size_t)mirror_index(x + 1, (long)w);
+            long xl = mirror_index(x - 1, (long)w), xr = mirror_index(x + 1, (long)w);
+            if (logm) log_neighbours(x, (long)w, GRAD_TILE_X, &xl, &xr);
             long xa, xb;
             grad_neighbours(x, (long)w, GRAD_TILE_X, tiled, &xa, &xb);
             float fxx = (fxp[y * w + xb] - fxp[y * w + xa]) * hx_1;
@@ -395,20 +437,22 @@ static void solve_2d_grad_any(const float* f0, const float* f1, const float* u, 
             float J12 = fxx * fxy + fxy * fyy;
             float J13 = fxx * fxt + fxy * fyt;
             float J23 = fxy * fxt + fyy * fyt;
-            jacobi_update(u, v, du, dv, phi, ksi, rc, ru, rd, x, xl, xr, y, (long)w, (long)h, hx_2, hy_2, J11, J22,
-                          J12, J13, J23, tdu, tdv);
+            jacobi_update(u, v, du, dv, phi, ksi, rc, ru, rd, x, (size_t)xl, (size_t)xr, y, (long)w, (long)h, hx_2,
+                          hy_2, J11, J22, J12, J13, J23, tdu, tdv);
         }
     }
     free(fxp);
     free(fyp);
     free(ftp);
+    free(l0);
+    free(l1);
 }
 
 ORACLE_API void oracle_solve_2d_grad(const float* f0, const float* f1, const float* u, const float* v,
                                      const float* du, const float* dv, const float* phi, const float* ksi, size_t w,
                                      size_t h, size_t pitch, float hx, float hy, float alpha, float* tdu, float* tdv)
 {
-    solve_2d_grad_any(f0, f1, u, v, du, dv, phi, ksi, w, h, pitch, hx, hy, alpha, tdu, tdv, 1);
+    solve_2d_grad_any(f0, f1, u, v, du, dv, phi, ksi, w, h, pitch, hx, hy, alpha, tdu, tdv, 1, NULL, NULL);
 }
 
 /* Gradient constancy with true neighbours (constancy 2 of the product; not a reference kernel). */
@@ -417,7 +461,27 @@ ORACLE_API void oracle_solve_2d_grad_untiled(const float* f0, const float* f1, c
                                              size_t w, size_t h, size_t pitch, float hx, float hy, float alpha,
                                              float* tdu, float* tdv)
 {
-    solve_2d_grad_any(f0, f1, u, v, du, dv, phi, ksi, w, h, pitch, hx, hy, alpha, tdu, tdv, 0);
+    solve_2d_grad_any(f0, f1, u, v, du, dv, phi, ksi, w, h, pitch, hx, hy, alpha, tdu, tdv, 0, NULL, NULL);
+}
+
+/* One Jacobi sweep on the logarithmic derivatives.  src/kernels/solve_2d.cu:391-669 (solve_2d_log), selected by
+ * DataConstancy::LogDerivatives (cuda_operation_solve_2d.cpp:75-77).  Like solve_2d_grad its result depends on the
+ * 16x8 launch tiling, and where the image edge falls inside a block the last pixel's fx/fy/ft neighbour is an
+ * unwritten shared-memory slot in the reference (defined here as the pixel's own value). */
+ORACLE_API void oracle_solve_2d_log(const float* f0, const float* f1, const float* u, const float* v,
+                                    const float* du, const float* dv, const float* phi, const float* ksi, size_t w,
+                                    size_t h, size_t pitch, float hx, float hy, float alpha, float* tdu, float* tdv)
+{
+    solve_2d_grad_any(f0, f1, u, v, du, dv, phi, ksi, w, h, pitch, hx, hy, alpha, tdu, tdv, 2, NULL, NULL);
+}
+
+/* The same with log(frame + 1.0f) supplied by the caller (to take the libm out of a comparison). */
+ORACLE_API void oracle_solve_2d_log_planes(const float* lg0, const float* lg1, const float* u, const float* v,
+                                           const float* du, const float* dv, const float* phi, const float* ksi,
+                                           size_t w, size_t h, size_t pitch, float hx, float hy, float alpha,
+                                           float* tdu, float* tdv)
+{
+    solve_2d_grad_any(lg0, lg1, u, v, du, dv, phi, ksi, w, h, pitch, hx, hy, alpha, tdu, tdv, 2, lg0, lg1);
 }
 
 /* ------------------------------------------------------------------------------------------
@@ -585,7 +649,7 @@ ORACLE_API int oracle_median_op(const float* in, size_t w, size_t h, size_t pitc
  * du, dv are zeroed (level width x container height), then outer x [phi/ksi, inner x sweep+swap].
  * The four pointers are swapped in place exactly like the reference (:288-289); on return
  * *du / *dv hold the result.  constancy: 0 = Grey (solve_2d), 1 = Gradient (solve_2d_grad), 2 = Gradient with
- * true neighbours (not a reference mode).
+ * true neighbours (not a reference mode), 3 = LogDerivatives (solve_2d_log).
  * ---------------------------------------------------------------------------------------- */
 ORACLE_API void oracle_solve_level(const float* f0, const float* f1, const float* u, const float* v, float** du,
                                    float** dv, float* phi, float* ksi, float** tdu, float** tdv, size_t w, size_t h,
@@ -603,6 +667,8 @@ ORACLE_API void oracle_solve_level(const float* f0, const float* f1, const float
                 oracle_solve_2d_grad(f0, f1, u, v, *du, *dv, phi, ksi, w, h, pitch, hx, hy, alpha, *tdu, *tdv);
             else if (constancy == 2)
                 oracle_solve_2d_grad_untiled(f0, f1, u, v, *du, *dv, phi, ksi, w, h, pitch, hx, hy, alpha, *tdu, *tdv);
+            else if (constancy == 3)
+                oracle_solve_2d_log(f0, f1, u, v, *du, *dv, phi, ksi, w, h, pitch, hx, hy, alpha, *tdu, *tdv);
             else
                 oracle_solve_2d(f0, f1, u, v, *du, *dv, phi, ksi, w, h, pitch, hx, hy, alpha, *tdu, *tdv);
             float* t = *du; *du = *tdu; *tdu = t;
@@ -633,7 +699,7 @@ typedef struct {
     float equation_data;
     size_t median_radius;
     float gaussian_sigma;
-    int data_constancy; /* 0 Grey, 1 Gradient (reference tile rule), 2 Gradient with true neighbours */
+    int data_constancy; /* 0 Grey, 1 Gradient (reference tile rule), 2 Gradient with true neighbours, 3 Log */
     float sor_omega;    /* 0: Jacobi sweeps (reference).  (0,2): opt-in red-black SOR iterations instead */
 } oracle_flow_params;
 

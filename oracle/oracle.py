@@ -2,8 +2,8 @@
 
 TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and bench.py's
 cpu_baseline leg -- never by the product package.  Parity status: see the header of
-flow2d_oracle.c ("parity unpinned" by the reference; pinned by a second independent
-restatement, the SURVEY anchors and committed goldens).
+flow2d_oracle.c (pinned bit for bit against the reference's own kernels run on an MI355X and
+its own host code run in the build container: tests/golden/ref_*_golden.npz).
 
 Planes are C-contiguous float32 arrays of shape (container_h, pitch); a level occupies the
 top-left w x h corner, like the reference's pitched containers.
@@ -18,7 +18,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, "libflow2d_oracle.so")
 _lib = None
 
-GREY, GRADIENT, GRADIENT_UNTILED = 0, 1, 2  # 2: true neighbours instead of the 16x8 tile rule (not a reference mode)
+GREY, GRADIENT, GRADIENT_UNTILED, LOG_DERIVATIVES = 0, 1, 2, 3  # 2: true neighbours instead of the 16x8 tile rule (not a reference mode)
 
 
 def build(force=False):
@@ -95,6 +95,8 @@ def lib():
         L.oracle_solve_2d.argtypes = [fp] * 8 + [sz, sz, sz, f, f, f, fp, fp]
         L.oracle_solve_2d_grad.argtypes = [fp] * 8 + [sz, sz, sz, f, f, f, fp, fp]
         L.oracle_solve_2d_grad_untiled.argtypes = [fp] * 8 + [sz, sz, sz, f, f, f, fp, fp]
+        L.oracle_solve_2d_log.argtypes = [fp] * 8 + [sz, sz, sz, f, f, f, fp, fp]
+        L.oracle_solve_2d_log_planes.argtypes = [fp] * 8 + [sz, sz, sz, f, f, f, fp, fp]
         L.oracle_solve_2d_sor.argtypes = [fp] * 8 + [sz, sz, sz, f, f, f, f, C.c_int]
         L.oracle_solve_level_sor.argtypes = [fp] * 8 + [sz, sz, sz, sz, f, f, f, f, f, sz, sz, C.c_int, f]
         L.oracle_add_2d.argtypes = [fp, fp, sz, sz, sz]
@@ -208,9 +210,18 @@ def solve_sweep(f0, f1, u, v, du, dv, phi, ksi, w, h, hx, hy, alpha, constancy=G
     tdu = np.zeros_like(f0)
     tdv = np.zeros_like(f0)
     fn = {GREY: lib().oracle_solve_2d, GRADIENT: lib().oracle_solve_2d_grad,
-          GRADIENT_UNTILED: lib().oracle_solve_2d_grad_untiled}[constancy]
+          GRADIENT_UNTILED: lib().oracle_solve_2d_grad_untiled, LOG_DERIVATIVES: lib().oracle_solve_2d_log}[constancy]
     fn(_p(f0), _p(f1), _p(u), _p(v), _p(du), _p(dv), _p(phi), _p(ksi), w, h, _pitch(f0), hx, hy, alpha, _p(tdu),
        _p(tdv))
+    return tdu, tdv
+
+
+def solve_sweep_log_planes(lg0, lg1, u, v, du, dv, phi, ksi, w, h, hx, hy, alpha):
+    """solve_2d_log with log(frame + 1) supplied by the caller (takes the libm out of a comparison)."""
+    tdu = np.zeros_like(lg0)
+    tdv = np.zeros_like(lg0)
+    lib().oracle_solve_2d_log_planes(_p(lg0), _p(lg1), _p(u), _p(v), _p(du), _p(dv), _p(phi), _p(ksi), w, h,
+                                     _pitch(lg0), hx, hy, alpha, _p(tdu), _p(tdv))
     return tdu, tdv
 
 

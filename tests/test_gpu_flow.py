@@ -144,9 +144,6 @@ def test_boundary_error_behaviour(flow2d, make_flow):
     # a missing bag key: print + return, outputs untouched (optical_flow_2d.cpp:160-168)
     for key in ("warp_levels_count", "equation_alpha", "gaussian_sigma"):
         assert flow.missing_key_leaves_outputs(key) == 1
-    # LogDerivatives is refused at Initialize
-    with pytest.raises(flow2d.Flow2DError):
-        flow2d.OpticalFlow(64, 48, flow2d.HOST_LOG_DERIVATIVES)
     # no usable level (scale >= 1) is an input error: outputs keep the poison value of the facade
     f = np.zeros((48, 64), np.float32)
     u, v, _ = flow.compute_flow(f, f, flow.params(3, 1.0, 1, 1, 3.5, 0.001, 0.001, 5, 0.45))

@@ -122,6 +122,32 @@ def test_median5_streaming_strips(ctx, oracle, w, h, cw, ch):
     assert np.array_equal(dst.download(w, h), oracle.median(u, w, h, 5))
 
 
+@pytest.mark.parametrize("window", [3, 5, 7])
+@pytest.mark.parametrize("w,h,cw,ch", [(100, 70, 128, 80), (257, 33, 300, 40), (700, 133, 704, 140), (8, 8, 8, 8), (7, 5, 8, 8)])
+def test_median_nan_and_signed_zero(ctx, oracle, w, h, cw, ch, window):
+    """Windows holding NaNs or zeros of both signs: the one place where the ORDER of the reference's insertion
+    sort (`temp < window[j]`, median_2d.cu:52-63) shows.  The oracle restates that sort (and is held to the
+    reference's own kernel on such inputs by tests/golden/ref_kernels_golden.npz); the HIP kernels detect those
+    windows and evaluate the same rule: identical bits, NaN payloads and zero signs included."""
+    rng = np.random.default_rng(w * 131 + h)
+    _, _, u, *_ = level_fields(oracle, w, h, 26)
+    u[rng.random((h, w)) < 0.15] = 0.0
+    u[rng.random((h, w)) < 0.10] = -0.0
+    u[rng.random((h, w)) < 0.03] = np.nan
+    u[0, 0] = np.nan
+    u[h - 1, w - 1] = -0.0
+    u[h // 2, : min(w, 6)] = np.nan           # a run of NaNs: windows cut into several runs
+    src, dst = up(ctx, u, cw, ch, 99.0), ctx.plane(cw, ch)
+    ctx.median(src, w, h, window, dst)
+    got, want = dst.download(w, h), oracle.median(u, w, h, window)
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    # and a plane without any: untouched by the detection
+    clean = np.abs(np.nan_to_num(u)) + 1.0
+    src2 = up(ctx, clean.astype(np.float32), cw, ch, 99.0)
+    ctx.median(src2, w, h, window, dst)
+    assert np.array_equal(dst.download(w, h), oracle.median(clean.astype(np.float32), w, h, window))
+
+
 @pytest.mark.parametrize("w,h,cw,ch", [(100, 70, 128, 80), (257, 33, 300, 40), (16, 8, 16, 8), (700, 133, 704, 140)])
 def test_two_plane_launches(ctx, flow2d, oracle, w, h, cw, ch):
     """add / median / resample on two planes per launch: each plane gets what the single-plane entry gives."""

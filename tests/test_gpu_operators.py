@@ -54,8 +54,7 @@ def test_operator_names_and_init(flow2d, rig):
                      "registration": "CUDA Registration 2D", "resample": "CUDA Resample 2D", "solve": "CUDA Solve 2D"}
     with pytest.raises(flow2d.Flow2DError):  # container_size is mandatory at Initialize
         make("add", omit_container_size=True)
-    with pytest.raises(flow2d.Flow2DError):  # LogDerivatives is refused by the solve operator
-        make("solve", constancy=2)
+    assert make("solve", constancy=2).name == "CUDA Solve 2D"  # DataConstancy::LogDerivatives selects solve_2d_log
 
 
 def test_add_convolution_median(flow2d, oracle, rig):

@@ -218,3 +218,70 @@ def test_committed_bench_line_has_the_contract_fields():
     for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
         assert key in roof, key
     assert roof["bound"] == "hbm" and roof["peak"] == 8000.0 and abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-3
+
+
+# ---- the product's host layer against THE REFERENCE'S OWN host code ---------------------------------------
+# tests/golden/ref_host_golden.npz was produced by running the reference's host sources (compiled where they lie)
+# in the build container: tests/golden/make_ref_host_golden.py.
+@pytest.fixture(scope="module")
+def ref_host_golden():
+    import json
+    g = np.load(os.path.join(ROOT, "tests", "golden", "ref_host_golden.npz"))
+    return g, json.loads(str(g["meta"]))
+
+
+def test_ref_host_levels_and_taps(flow2d, ref_host_golden):
+    _, meta = ref_host_golden
+    for w, h, s, want in meta["levels"]:
+        assert flow2d.max_warp_level(w, h, s) == want, (w, h, s)
+    for sigma, rec in meta["taps"].items():
+        taps, r = flow2d.gaussian_kernel(float(sigma))
+        assert r == rec["radius"] and ["%08x" % b for b in taps.view(np.uint32)] == rec["bits"], sigma
+
+
+def test_ref_host_parameter_bag(flow2d, ref_host_golden):
+    _, meta = ref_host_golden
+    # first push accepted, second refused, value of the first kept, missing key -> null, Clear() empties
+    assert meta["bag"] == [1, 0, 1, 0, 0]
+    assert flow2d.host_lib().flow2d_host_bag_selftest() == 0  # asserts exactly those five facts
+
+
+def test_ref_host_settings(flow2d, ref_host_golden, tmp_path):
+    _, meta = ref_host_golden
+    bits = lambda x: "%08x" % np.float32(x).view(np.uint32)
+    p = tmp_path / "variant.xml"
+    p.write_text(meta["settings_variant_xml"])
+    ref = meta["settings_variant"]
+    s = flow2d.load_settings(str(p))
+    assert ref["rc"] == "0" and s is not None
+    assert [s.width, s.height, s.iterInner, s.iterOuter, s.levels, s.medianRadius] == \
+        [int(ref[k]) for k in ("width", "height", "inner", "outer", "levels", "medianRadius")]
+    assert [bits(s.sigma), bits(s.alpha), bits(s.e_smooth), bits(s.e_data), bits(s.warpScale)] == \
+        [ref[k] for k in ("sigma", "alpha", "e_smooth", "e_data", "scaling")]
+    assert [s.inputPath.decode(), s.outputPath.decode(), s.fileName1.decode(), s.fileName2.decode()] == \
+        [ref[k] for k in ("inputPath", "outputPath", "file1", "file2")]
+    assert meta["settings_missing_file"]["rc"] == "-1"
+    # the reference's shipped settings.xml, field by field as the reference itself parses it
+    ref = meta["settings_reference_file"]
+    assert (ref["width"], ref["height"], ref["inner"], ref["outer"], ref["levels"], ref["medianRadius"]) == \
+        ("128", "128", "5", "20", "20", "5")
+    assert (ref["sigma"], ref["alpha"], ref["e_smooth"], ref["scaling"]) == \
+        (bits(0.45), bits(3.5), bits(0.001), bits(0.9))
+
+
+def test_ref_host_raw_io(flow2d, ref_host_golden, tmp_path):
+    g, _ = ref_host_golden
+    (tmp_path / "a8.raw").write_bytes(g["raw_u8_in"].tobytes())
+    h, w = g["raw_u8_in"].shape
+    assert np.array_equal(flow2d.read_raw(str(tmp_path / "a8.raw"), w, h, True), g["raw_u8_as_f32"])
+    assert flow2d.write_raw(g["raw_f32_in"], str(tmp_path / "f8.raw"), True)
+    assert np.array_equal(np.fromfile(tmp_path / "f8.raw", np.uint8).reshape(h, w), g["raw_f32_as_u8"])
+
+
+def test_ref_host_colour_wheel_ppm_and_magnitude(flow2d, ref_host_golden, tmp_path):
+    """WriteFlowToImageRGB / WriteMagnitudeToFileF32 (io_utils.cpp:35-114,140-225): byte-identical files."""
+    g, _ = ref_host_golden
+    ppm, amp = str(tmp_path / "res.pgm"), str(tmp_path / "amp.raw")
+    flow2d.write_outputs(g["flow_u"], g["flow_v"], ppm, amp, 10.0)
+    assert open(ppm, "rb").read() == g["ppm_bytes"].tobytes()
+    assert np.array_equal(np.fromfile(amp, np.float32).reshape(g["amp"].shape).view(np.uint32), g["amp"].view(np.uint32))
