@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- the measured hot path: OpticalFlow2D::ComputeFlowDevice (C++ host layer -> C-ABI -> HIP
 kernels for gfx950) on synthetic translating-sinusoid pairs, with the roofline of the dominant solver
-kernel and the CPU oracle timed beside it.
+kernel, the CPU oracle and (N = 1) the reference's own kernels timed beside it.
 
     python bench.py --gpus N --steps K --warmup W [--workload NAME]
 
@@ -9,16 +9,27 @@ One "step" = one full coarse-to-fine run over one image pair per rank (inputs al
 N > 1: one process per GPU (torch.distributed, backend nccl = RCCL), every rank works on its own pairs,
 no data-path collective (independent pairs: SURVEY 8e) -> weak scaling.  Rank 0 prints ONE JSON line.
 
+Order of a run
+  1. warm-up (records the HIP graphs), barrier
+  2. TIMED REGION: exactly K steps, replayed from the recorded graphs, nothing else; barrier; max over ranks
+  3. output check: the flow fields the timed steps left in HBM are hashed; an eager (un-graphed) recomputation
+     must give the same bits, and for single-pair workloads all streams must agree
+  4. roofline sample: eager passes with HIP events on the launch stream around every finest-level solver launch
+  5. batch leg (BASELINE.json configs[3]): 8 pairs of 1920x1080 per GPU on 4 streams, timed the same way, then the
+     flow fields of all ranks are gathered with ONE RCCL all_gather (timed separately: gather_ms)
+  6. baselines on rank 0 at N = 1: the CPU oracle on a bounded crop; the reference's own kernels (oracle/_ref,
+     compiled from its sources for gfx950) with the reference's launch schedule on this GPU
+
 metric  = Mpixel*solver-iterations/s at the finest level (BASELINE.json): finest-level pixel-iterations
-          (W*H*outer*inner per pair) of all ranks divided by the whole-pyramid wall time of the timed
-          region, i.e. a whole-job rate (the pure finest-level solve rate is reported in
-          "finest_level").  pairs_per_s is the second half of BASELINE.json's metric.
-roofline: the finest level's dominant solver kernel (Jacobi sweep, or the fused outer-iteration kernel):
-          achieved = algorithmic bytes per launch (40 B per pixel-sweep, 32 B per pixel for phi/ksi;
-          SURVEY 8d) / average launch duration measured with HIP events on the launch stream inside
-          the timed steps; peak = 8 TB/s HBM3E.
+          (W*H*outer*inner per pair) of all ranks / whole-pyramid wall time of the timed region (a whole-job
+          rate; the pure finest-level solve rate is in "finest_level").  pairs_per_s: the metric's second half.
+roofline: the finest level's dominant solver kernel.  achieved/frac are the contract's ALGORITHMIC figures
+          (40 B per pixel-sweep, 32 B per pixel for phi/ksi, i.e. the reference's per-sweep schedule)
+          over the measured launch duration -- above 1 for the fused kernel because it does not move those bytes.
+          What the kernel is really bound by is reported next to it: physical HBM bytes (PMC) and VALU issue.
 """
 import argparse
+import hashlib
 import importlib
 import json
 import os
@@ -31,7 +42,10 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0  # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
+HBM_PEAK_GBS = 8000.0      # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
+SIMDS = 256 * 4            # CUs x SIMDs per CU
+CLOCK_HZ = 2.4e9           # max shader clock
+VALU_ISSUE_CYCLES = 2.0    # a wave64 VALU instruction occupies a SIMD-32 for 2 cycles (same guide)
 
 # BASELINE.json configs[1..4] with the concrete parameters of SURVEY.md 8(d)
 WORKLOADS = {
@@ -51,6 +65,8 @@ WORKLOADS = {
                            inner=5, median=5, sigma=1.5, alpha=35.0, pairs_per_rank=1),
 }
 DEFAULT_WORKLOAD = "cfg3_4096_gradient"
+BATCH_WORKLOAD = "cfg4_1080p_batch"
+CONSTANCY_NAME = {0: "grey", 1: "gradient", 2: "gradient-untiled", 3: "log-derivatives"}
 
 
 def synthetic_pair(w, h, dx, dy):
@@ -63,6 +79,12 @@ def synthetic_pair(w, h, dx, dy):
                 + 30.0 * np.sin(2 * np.pi * (xx + 2 * yy) / 23.7))
 
     return img(x, y).astype(np.float32), img(x - dx, y - dy).astype(np.float32)
+
+
+def pair_shift(workload, cfg, k):
+    if workload == BATCH_WORKLOAD:
+        return 2.0 * np.cos(k), 2.0 * np.sin(k)  # pair k moves by (2 cos k, 2 sin k)
+    return cfg["dx"], cfg["dy"]
 
 
 def cpu_baseline(cfg, budget_s=20.0):
@@ -111,16 +133,217 @@ def cpu_baseline(cfg, budget_s=20.0):
     }
 
 
-def load_traffic(workload, algorithm):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes
-    (profiles/traffic.json, written by tools/pmc_traffic.py); None if not measured for this workload."""
-    path = os.path.join(ROOT, "profiles", "traffic.json")
+def reference_gpu_baseline(cfg, f0, f1):
+    """THE REFERENCE'S OWN KERNELS (src/kernels/*_2d.cu compiled for gfx950 from its sources: oracle/_ref) with the
+    reference's launch schedule -- one launch per sweep, a stream synchronisation after each, one pair at a time
+    (cuda_operation_solve_2d.cpp:263-299) -- on this GPU, whole ComputeFlow incl. the H<->D copies the reference's
+    own timer brackets (optical_flow_2d.cpp:173-179,548-554).  A checker-side baseline like cpu_baseline: runs after
+    the timed region, on rank 0 at N = 1; None when oracle/_ref was not built or the mode has no reference kernel."""
     try:
-        table = json.load(open(path))
-    except (OSError, ValueError):
+        from oracle import ref_kernels as RK
+    except Exception:  # noqa: BLE001 - the checker is optional here
         return None
-    entry = table.get("%s/algorithm%d" % (workload, algorithm))
-    return entry.get("hbm_bytes_per_launch") if entry else None
+    ref_mode = {0: 0, 1: 1, 3: 2}.get(cfg["constancy"])
+    if not RK.available() or ref_mode is None:
+        return None
+    try:
+        with RK.RefKernels(cfg["w"], cfg["h"]) as R:
+            best = None
+            for _ in range(2):
+                _, _, total_ms, finest_ms = R.compute_flow(f0, f1, cfg["levels"], cfg["scale"], cfg["outer"],
+                                                           cfg["inner"], cfg["alpha"], 0.001, 0.001, cfg["median"],
+                                                           cfg["sigma"], constancy=ref_mode)
+                if best is None or total_ms < best[0]:
+                    best = (total_ms, finest_ms)
+    except Exception as e:  # noqa: BLE001
+        return {"error": str(e)[:200]}
+    px_iters = float(cfg["w"]) * cfg["h"] * cfg["outer"] * cfg["inner"]
+    return {
+        "what": "the reference's kernels (hipcc -ffp-contract=off build of its .cu files) under the reference's "
+                "schedule: per-sweep launches, host sync after every sweep, one pair at a time, H<->D inside the bracket",
+        "value": round(px_iters / (best[0] * 1e-3) / 1e6, 1),
+        "unit": "Mpixel*iters/s",
+        "pairs_per_s": round(1e3 / best[0], 3),
+        "ms_per_pair": round(best[0], 3),
+        "finest_level_solve_ms": round(best[1], 3),
+        "finest_level_mpix_iters_per_s": round(px_iters / (best[1] * 1e-3) / 1e6, 1),
+    }
+
+
+def load_pmc(workload, algorithm):
+    """Per-launch PMC figures of the dominant kernel from the committed rocprofv3 --pmc passes
+    (profiles/traffic.json, written by tools/pmc_traffic.py); {} if not measured for this workload."""
+    try:
+        table = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+    except (OSError, ValueError):
+        return {}
+    return table.get("%s/algorithm%d" % (workload, algorithm)) or {}
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a, np.float32).tobytes()).hexdigest()[:16]
+
+
+class Job:
+    """One workload on this rank: lanes = independent (stream, OpticalFlow2D, plane pool) triples.  A rank with
+    several pairs per step spreads them over up to 4 lanes so the launch-bound coarse levels of one pair overlap
+    another pair's work; with one pair per step, consecutive steps rotate over the lanes (every lane has a copy)."""
+
+    def __init__(self, flow2d, batch, workload, cfg, args, rank, local_rank, world, out_tensor=None):
+        self.flow2d, self.batch, self.workload, self.cfg, self.args = flow2d, batch, workload, cfg, args
+        self.rank, self.world = rank, world
+        w, h = cfg["w"], cfg["h"]
+        self.single = cfg["pairs_per_rank"] == 1
+        self.n_lanes = max(1, min(4, cfg["pairs_per_rank"] * args.pipeline))
+        self.lanes = []
+        for _ in range(self.n_lanes):
+            c = flow2d.Context(local_rank)
+            self.lanes.append({"ctx": c, "flow": flow2d.OpticalFlow(w, h, cfg["constancy"], ctx=c), "pairs": []})
+        self.flow = self.lanes[0]["flow"]
+        # rank 0's parameter block on every rank (RCCL broadcast; SURVEY 8e), then the same solve everywhere
+        block = batch.broadcast_params([cfg["levels"], cfg["scale"], cfg["outer"], cfg["inner"], cfg["alpha"], 0.001,
+                                        0.001, cfg["median"], cfg["sigma"], args.algorithm])
+        self.params = self.flow.params(int(block[0]), block[1], int(block[2]), int(block[3]), block[4], block[5],
+                                       block[6], int(block[7]), block[8], int(block[9]))
+        # this rank's pairs, resident in HBM before any timed region; pair k -> rank k mod world (SURVEY 8e)
+        self.owned = batch.pairs_of_rank(cfg["pairs_per_rank"] * world, rank, world)
+        self.first_pair = None
+        for n, gk in enumerate(self.owned):
+            dx, dy = pair_shift(workload, cfg, gk)
+            f0, f1 = synthetic_pair(w, h, dx, dy)
+            if self.first_pair is None:
+                self.first_pair = (f0, f1)
+            targets = self.lanes if self.single else [self.lanes[n % self.n_lanes]]
+            for lane in targets:
+                c = lane["ctx"]
+                if out_tensor is not None:  # flow fields written straight into the gather buffer
+                    assert out_tensor.shape[-1] * 4 == lane["flow"].pitch
+                    pu = _Borrowed(c, out_tensor[n, 0].data_ptr(), lane["flow"].pitch, w, h)
+                    pv = _Borrowed(c, out_tensor[n, 1].data_ptr(), lane["flow"].pitch, w, h)
+                else:
+                    pu, pv = c.plane(w, h), c.plane(w, h)
+                lane["pairs"].append((c.plane(w, h, f0), c.plane(w, h, f1), pu, pv, gk))
+
+    def sync(self):
+        for lane in self.lanes:
+            lane["ctx"].synchronize()
+
+    def step(self, index, eager=False, timing=0, only_lane=None):
+        """One pass over this rank's pairs (replayed from recorded HIP graphs unless eager)."""
+        active = [self.lanes[index % self.n_lanes]] if self.single else self.lanes
+        if only_lane is not None:
+            active = [self.lanes[only_lane]]
+        for lane in active:
+            lane["flow"].use_graph(not eager and not self.args.no_graph)
+        for k in range(max(len(l["pairs"]) for l in active)):
+            for lane in active:
+                if k < len(lane["pairs"]):
+                    pf0, pf1, pu, pv, _ = lane["pairs"][k]
+                    lane["flow"].compute_flow_device(pf0.ptr, pf1.ptr, pu.ptr, pv.ptr, self.params, timing)
+
+    def digests(self):
+        """{(lane, pair index): (sha(u), sha(v))} of what is in HBM now."""
+        self.sync()
+        return {(li, gk): (sha(pu.download()), sha(pv.download()))
+                for li, lane in enumerate(self.lanes) for (_, _, pu, pv, gk) in lane["pairs"]}
+
+    def close(self):
+        for lane in self.lanes:
+            lane["flow"].close()
+            lane["ctx"].close()
+
+
+class _Borrowed:
+    """A plane living in someone else's allocation (a torch tensor): same download interface as flow2d.Plane."""
+
+    def __init__(self, ctx, ptr, pitch, width, height):
+        self.ctx, self.ptr, self.pitch, self.width, self.height = ctx, ptr, pitch, width, height
+
+    def download(self):
+        return importlib.import_module("cuda-flow2d_amd").Plane.download(self)
+
+
+def timed_region(job, batch, torch, steps, warmup):
+    def barrier():
+        batch.barrier()
+        job.sync()
+        torch.cuda.synchronize()
+
+    for k in range(max(warmup, 1) * job.n_lanes):
+        job.step(k)  # also records the graphs of every lane
+    barrier()
+    t0 = time.perf_counter()
+    for k in range(steps):
+        job.step(k)
+    barrier()
+    return batch.max_over_ranks(time.perf_counter() - t0)
+
+
+def output_check(job):
+    """The timed steps' results against an eager recomputation; single-pair workloads: all streams agree."""
+    replayed = job.digests()
+    for li in range(job.n_lanes):
+        job.step(0, eager=True, only_lane=li)
+    eager = job.digests()
+    lanes_identical = True
+    if job.single:
+        lanes_identical = len({v for v in replayed.values()}) == 1
+    return {
+        "ok": bool(replayed == eager and lanes_identical),
+        "graph_replay_equals_eager": bool(replayed == eager),
+        "streams_identical": bool(lanes_identical) if job.single else None,
+        "fields_hashed": 2 * len(replayed),
+        "sha256_u_v_first_pair": list(replayed[min(replayed)]),
+    }
+
+
+def roofline_sample(job, passes=3):
+    """Eager passes on stream 0, alone on the GPU, with HIP events on that stream around every level's solve
+    and every finest-level solver launch (flow2d_timing_enable mode 2)."""
+    job.sync()
+    job.flow.reset_timings()
+    for _ in range(passes):
+        job.step(0, eager=True, timing=2, only_lane=0)
+    job.sync()
+    w, h = job.cfg["w"], job.cfg["h"]
+    return [r for r in job.flow.level_timings() if (r[0], r[1]) == (w, h)]
+
+
+def batch_leg(flow2d, batch, torch, args, rank, local_rank, world):
+    """BASELINE.json configs[3]: 8 pairs of 1920x1080 per GPU (64 on 8 GPUs), then ONE all_gather of the flow fields."""
+    cfg = WORKLOADS[BATCH_WORKLOAD]
+    w, h = cfg["w"], cfg["h"]
+    pitch_floats = flow2d.hip_lib().flow2d_plane_pitch_bytes(w) // 4
+    n_local = cfg["pairs_per_rank"]
+    local = torch.zeros((n_local, 2, h, pitch_floats), dtype=torch.float32, device=torch.device("cuda", local_rank))
+    job = Job(flow2d, batch, BATCH_WORKLOAD, cfg, args, rank, local_rank, world, out_tensor=local)
+    steps = max(3, min(args.steps, 20))
+    elapsed = timed_region(job, batch, torch, steps, 1)
+    check = output_check(job)
+    # gather: every rank's [8, 2, H, pitch] block -> [world, 8, 2, H, pitch] on every rank; pair k = [k % world, k // world]
+    torch.cuda.synchronize()
+    gathered = batch.all_gather_fields(local)
+    batch.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    gathered = batch.all_gather_fields(local, out=gathered)
+    torch.cuda.synchronize()
+    gather_s = batch.max_over_ranks(time.perf_counter() - t0)
+    mine_ok = all(bool(torch.equal(gathered[rank, n], local[n])) for n in range(n_local))
+    nonzero = bool((gathered.abs().amax(dim=(2, 3, 4)) > 0).all().item())
+    job.close()
+    pairs = steps * n_local * world
+    px_iters = float(w) * h * cfg["outer"] * cfg["inner"]
+    return {
+        "workload": BATCH_WORKLOAD, "pairs_per_gpu": n_local, "pairs_total_per_step": n_local * world, "steps": steps,
+        "value": round(px_iters * pairs / elapsed / 1e6, 1), "unit": "Mpixel*iters/s",
+        "pairs_per_s": round(pairs / elapsed, 2), "ms_per_step": round(elapsed / steps * 1e3, 3),
+        "streams_per_gpu": job.n_lanes,
+        "gather": {"collective": "all_gather_into_tensor (RCCL)" if world > 1 else "none (one process)",
+                   "bytes_per_rank": int(local.numel() * 4), "ms": round(gather_s * 1e3, 3),
+                   "own_block_intact": mine_ok, "every_pair_present": nonzero},
+        "output_check": check,
+    }
 
 
 def main():
@@ -131,6 +354,8 @@ def main():
     ap.add_argument("--workload", default=DEFAULT_WORKLOAD, choices=sorted(WORKLOADS))
     ap.add_argument("--algorithm", type=int, default=0, help="flow2d_solver_algorithm: 0 auto, 1 per-sweep, 2 fused")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-reference-baseline", action="store_true")
+    ap.add_argument("--no-batch-leg", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="launch every step eagerly instead of replaying HIP graphs")
     ap.add_argument("--pipeline", type=int, default=4,
                     help="independent pairs in flight per GPU when a step holds a single pair: consecutive steps go to "
@@ -156,91 +381,71 @@ def main():
                      (args.gpus, world))
         args.gpus = world
 
-    import torch  # device plumbing only: barrier, device-wide synchronise, max-over-ranks
+    import torch  # device plumbing only: barrier, device-wide synchronise, max-over-ranks, the RCCL gather buffer
 
     if not torch.cuda.is_available():
         sys.exit("bench.py needs an MI355X: the flow2d path has no CPU fallback")
     torch.cuda.set_device(local_rank)
     batch.init(backend="nccl", device=torch.device("cuda", local_rank))  # RCCL; no-op for one process
 
-    # "lanes": independent (stream, OpticalFlow2D, plane pool) triples.  A rank with several pairs per step
-    # spreads them over up to 4 lanes so the launch-bound coarse levels of one pair overlap another pair's work.
     w, h = cfg["w"], cfg["h"]
-    n_lanes = max(1, min(4, cfg["pairs_per_rank"] * args.pipeline))
-    lanes = []
-    for _ in range(n_lanes):
-        c = flow2d.Context(local_rank)
-        f = flow2d.OpticalFlow(w, h, cfg["constancy"], ctx=c)
-        lanes.append({"ctx": c, "flow": f, "pairs": []})
-    ctx, flow = lanes[0]["ctx"], lanes[0]["flow"]
-    # rank 0's parameter block on every rank (RCCL broadcast), then the same solve everywhere
-    block = batch.broadcast_params([cfg["levels"], cfg["scale"], cfg["outer"], cfg["inner"], cfg["alpha"], 0.001,
-                                    0.001, cfg["median"], cfg["sigma"], args.algorithm])
-    params = flow.params(int(block[0]), block[1], int(block[2]), int(block[3]), block[4], block[5], block[6],
-                         int(block[7]), block[8], int(block[9]))
+    job = Job(flow2d, batch, args.workload, cfg, args, rank, local_rank, world)
+    free_b, total_b = job.lanes[0]["ctx"].mem_info()
+    elapsed = timed_region(job, batch, torch, args.steps, args.warmup)   # <- the number
+    check = output_check(job)
+    finest = roofline_sample(job)
+    first_pair = job.first_pair
+    n_lanes = job.n_lanes
+    levels_run = int(min(cfg["levels"], job.flow.max_warp_level(w, h, cfg["scale"])))
+    job.close()
 
-    # this rank's pairs, resident in HBM before the timed region
-    total_pairs = cfg["pairs_per_rank"] * world
-    for n, gk in enumerate(batch.pairs_of_rank(total_pairs, rank, world)):  # pair k -> rank k mod world
-        if args.workload == "cfg4_1080p_batch":
-            dx, dy = 2.0 * np.cos(gk), 2.0 * np.sin(gk)
-        else:
-            dx, dy = cfg["dx"], cfg["dy"]
-        f0, f1 = synthetic_pair(w, h, dx, dy)
-        targets = [lanes[n % n_lanes]] if cfg["pairs_per_rank"] > 1 else lanes  # single pair: every lane has a copy
-        for lane in targets:
-            c = lane["ctx"]
-            lane["pairs"].append((c.plane(w, h, f0), c.plane(w, h, f1), c.plane(w, h), c.plane(w, h)))
-    free_b, total_b = ctx.mem_info()
-    single = cfg["pairs_per_rank"] == 1
+    batch_result = None
+    if not args.no_batch_leg and args.workload != BATCH_WORKLOAD:
+        batch_result = batch_leg(flow2d, batch, torch, args, rank, local_rank, world)
 
-    def barrier():
-        batch.barrier()
-        for lane in lanes:
-            lane["ctx"].synchronize()
-        torch.cuda.synchronize()
-
-    def step(index, instrumented):
-        """One pass over this rank's pairs.  Replayed from recorded HIP graphs, except the instrumented pass,
-        which launches eagerly with events around every level's solve and every finest-level solver launch.
-        With one pair per step, step `index` goes to stream index mod n_lanes, so consecutive steps overlap."""
-        active = [lanes[index % n_lanes]] if single else lanes
-        if instrumented:  # the instrumented pass runs alone on lane 0 so its launch durations are undisturbed
-            for lane in lanes:
-                lane["ctx"].synchronize()
-            active = [lanes[0]] if single else lanes
-        for lane in active:
-            lane["flow"].use_graph(not instrumented and not args.no_graph)
-        for k in range(max(len(l["pairs"]) for l in active)):
-            for lane in active:
-                if k < len(lane["pairs"]):
-                    pf0, pf1, pu, pv = lane["pairs"][k]
-                    lane["flow"].compute_flow_device(pf0.ptr, pf1.ptr, pu.ptr, pv.ptr, params,
-                                                     2 if instrumented else 0)
-
-    for k in range(max(args.warmup, 1) * n_lanes):
-        step(k, False)  # also records the graphs of every lane
-    if args.warmup > 0:
-        step(0, True)
-    flow.reset_timings()
-    barrier()
-    t0 = time.perf_counter()
-    for k in range(args.steps):
-        step(k, k == args.steps - 1)  # the last timed step is the instrumented one (roofline sample)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    finest = [r for r in flow.level_timings() if (r[0], r[1]) == (w, h)]
-    elapsed = batch.max_over_ranks(elapsed)
-
+    ok = check["ok"] and (batch_result is None or batch_result["output_check"]["ok"])
     if rank == 0:
         pairs_total = args.steps * cfg["pairs_per_rank"] * world
         px_iters = float(w) * h * cfg["outer"] * cfg["inner"]
         solve_ms = float(np.mean([r[2] for r in finest]))
-        kernel_ms = float(np.mean([r[3] / r[4] for r in finest]))
+        launch_ms = [r[3] / r[4] for r in finest]
+        kernel_ms = float(np.mean(launch_ms))
         launches = finest[-1][4]
         bytes_per_launch = float(finest[-1][5])
         algorithm_used = 2 if launches == cfg["outer"] and cfg["inner"] > 1 else 1
         achieved = bytes_per_launch / (kernel_ms * 1e-3) / 1e9
+        pmc = load_pmc(args.workload, algorithm_used)
+        phys = pmc.get("hbm_bytes_per_launch")
+        valu = pmc.get("valu_insts_per_launch")
+        roof = {
+            "bound": "hbm",
+            "kernel": ("fused outer-iteration kernel (phi/ksi + %d Jacobi sweeps)" % cfg["inner"])
+            if algorithm_used == 2 else "Jacobi sweep kernel (%s)" %
+            {0: "solve_2d", 1: "solve_2d_grad", 3: "solve_2d_log"}.get(cfg["constancy"], "gradient-untiled"),
+            "achieved": round(achieved, 1),
+            "peak": HBM_PEAK_GBS,
+            "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBS, 4),
+            "traffic": phys,
+            "algorithmic_bytes_per_launch": bytes_per_launch,
+            "avg_launch_ms": round(kernel_ms, 5),
+            "launch_samples": len(finest) * launches,
+            "launches_per_level_solve": launches,
+            "note": "achieved/frac: algorithmic bytes of the reference's per-sweep schedule (SURVEY 8d) over the measured "
+                    "launch time; the fused kernel does not move them, hence frac > 1.  physical_* and valu_* say what "
+                    "the kernel is bound by.",
+            # what the launch physically moves through HBM (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, steady-state
+            # launches; the first launch of a level skips reading du, dv) and how busy it keeps the vector ALUs
+            "physical_bytes_per_launch": phys,
+            "physical_bytes_first_launch_of_level": pmc.get("hbm_bytes_first_launch"),
+            "physical_gbs": round(phys / (kernel_ms * 1e-3) / 1e9, 1) if phys else None,
+            "physical_frac": round(phys / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if phys else None,
+            "valu_instr_per_launch": valu,
+            "valu_issue_frac": round(valu * VALU_ISSUE_CYCLES / (SIMDS * CLOCK_HZ * kernel_ms * 1e-3), 4) if valu else None,
+            "bound_actual": ("vector-ALU issue latency at 2 waves/SIMD (256 VGPRs): neither HBM nor VALU throughput is "
+                             "saturated; see DESIGN.md section 3.1") if algorithm_used == 2 else "HBM",
+            "pmc_source": "profiles/traffic.json" if pmc else None,
+        }
         out = {
             "metric": "Mpixels*SOR-iters/sec at finest level (whole-pyramid wall time); full-pyramid pairs/sec in pairs_per_s",
             "value": round(px_iters * pairs_total / elapsed / 1e6, 1),
@@ -256,45 +461,39 @@ def main():
             "data": "synthetic",
             "config": {
                 "workload": args.workload, "width": w, "height": h, "pairs_per_gpu_per_step": cfg["pairs_per_rank"],
-                "pyramid_levels": int(min(cfg["levels"], flow.max_warp_level(w, h, cfg["scale"]))),
+                "pyramid_levels": levels_run,
                 "warp_scale": cfg["scale"], "outer_iterations": cfg["outer"], "inner_iterations": cfg["inner"],
-                "data_constancy": "gradient" if cfg["constancy"] else "grey", "median_radius": cfg["median"],
+                "data_constancy": CONSTANCY_NAME[cfg["constancy"]], "median_radius": cfg["median"],
                 "gaussian_sigma": cfg["sigma"], "alpha": cfg["alpha"], "solver_algorithm": algorithm_used,
                 "relaxation": "Jacobi, reference iteration counts (bit-exact parity mode)",
                 "parallelism": "independent pairs, one process per GPU, no data-path collective",
                 "streams_per_gpu": n_lanes, "hip_graph_replay": not args.no_graph,
+                "timed_region": "graph-replayed steps only; output check, roofline sample, batch leg and baselines follow it",
             },
             "pairs_per_s": round(pairs_total / elapsed, 3),
             "finest_level": {
                 "solve_ms": round(solve_ms, 4),
                 "mpix_iters_per_s": round(px_iters / (solve_ms * 1e-3) / 1e6, 1),
                 "algorithmic_gbs": round(w * h * cfg["outer"] * (32 + 40 * cfg["inner"]) / (solve_ms * 1e-3) / 1e9, 1),
+                "sampled": "eager passes after the timed region, alone on the GPU",
             },
-            "roofline": {
-                "bound": "hbm",
-                "kernel": ("fused outer-iteration kernel (phi/ksi + %d Jacobi sweeps)" % cfg["inner"])
-                if algorithm_used == 2 else "Jacobi sweep kernel (solve_2d%s)" % ("_grad" if cfg["constancy"] else ""),
-                "achieved": round(achieved, 1),
-                "peak": HBM_PEAK_GBS,
-                "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4),
-                "traffic": load_traffic(args.workload, algorithm_used),
-                "algorithmic_bytes_per_launch": bytes_per_launch,
-                "avg_launch_ms": round(kernel_ms, 5),
-                "launches_per_level_solve": launches,
-            },
+            "roofline": roof,
+            "output_check": check,
+            "batch": batch_result,
             "device_memory": {"used_gib": round((total_b - free_b) / 2 ** 30, 3), "total_gib": round(total_b / 2 ** 30, 1)},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg)
         else:
             out["cpu_baseline"] = None
+        if world == 1 and not args.no_reference_baseline:
+            out["reference_gpu_baseline"] = reference_gpu_baseline(cfg, *first_pair)
+        else:
+            out["reference_gpu_baseline"] = None
         print(json.dumps(out))
-
-    for lane in lanes:
-        lane["flow"].close()
-        lane["ctx"].close()
     batch.shutdown()
+    if not ok:
+        sys.exit("bench.py: output check failed (graph replay and eager recomputation disagree)")
 
 
 if __name__ == "__main__":

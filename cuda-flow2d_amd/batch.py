@@ -1,7 +1,7 @@
 """Sharding of independent image pairs over the GPUs of one node: one process per GPU,
 pair k -> rank k mod world, no data-path collective.  torch.distributed is used only for the start/stop
-barrier, the broadcast of rank 0's parameter block, the max-over-ranks of the elapsed time and (optionally)
-gathering per-pair result digests or flow fields.
+barrier, the broadcast of rank 0's parameter block, the max-over-ranks of the elapsed time and, after the work, ONE
+all_gather of the flow fields (or of per-pair digests).
 Backend "nccl" is RCCL on ROCm; "gloo" is what the CPU tests use."""
 import os
 
@@ -56,21 +56,43 @@ def broadcast_params(values, device=None):
     return t.tolist()
 
 
+def all_gather_fields(local, out=None):
+    """ONE collective for the flow fields of a batch: every rank contributes its block `local` (a tensor
+    [pairs_per_rank, 2, H, W], on the GPU for RCCL) and receives [world, pairs_per_rank, 2, H, W]; with the shard rule
+    of pairs_of_rank, pair k is out[k % world, k // world].  all_gather moves each byte once per receiving rank
+    (a ring all-gather over xGMI), unlike a sum-reduction of a dense zero-padded array."""
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        return local.unsqueeze(0) if out is None else out.copy_(local.unsqueeze(0))
+    world = dist.get_world_size()
+    if out is None:
+        out = torch.empty((world,) + tuple(local.shape), dtype=local.dtype, device=local.device)
+    # the collective's own layout is the concatenation along dim 0: [world * pairs_per_rank, ...]
+    dist.all_gather_into_tensor(out.view((-1,) + tuple(local.shape[1:])), local.contiguous())
+    return out
+
+
 def gather_fields(local, total_pairs, height, width, device=None):
     """local: {global_pair_index: (u, v)} float32 arrays of this rank's pairs.  Returns on every rank a float32
-    array [total_pairs, 2, height, width] with all flow fields (the owners are disjoint, so summing gathers)."""
+    array [total_pairs, 2, height, width] with all flow fields (host-array front end of all_gather_fields; ranks
+    with fewer pairs than the others pad their block)."""
     import numpy as np
     import torch
     import torch.distributed as dist
     initialised = dist.is_available() and dist.is_initialized()
-    out = torch.zeros((total_pairs, 2, height, width), dtype=torch.float32,
-                      device=_collective_device(device) if initialised else "cpu")
+    world = dist.get_world_size() if initialised else 1
+    per_rank = -(-total_pairs // world) if total_pairs else 0
+    block = torch.zeros((per_rank, 2, height, width), dtype=torch.float32,
+                        device=_collective_device(device) if initialised else "cpu")
     for k, (u, v) in local.items():
-        out[k, 0] = torch.from_numpy(np.ascontiguousarray(u)).to(out.device)
-        out[k, 1] = torch.from_numpy(np.ascontiguousarray(v)).to(out.device)
-    if initialised:
-        dist.all_reduce(out, op=dist.ReduceOp.SUM)
-    return out.cpu().numpy()
+        block[k // world, 0] = torch.from_numpy(np.ascontiguousarray(u)).to(block.device)
+        block[k // world, 1] = torch.from_numpy(np.ascontiguousarray(v)).to(block.device)
+    everything = all_gather_fields(block).cpu().numpy()
+    out = np.zeros((total_pairs, 2, height, width), np.float32)
+    for k in range(total_pairs):
+        out[k] = everything[k % world, k // world]
+    return out
 
 
 def max_over_ranks(value, device=None):

@@ -25,6 +25,7 @@
 // are in DESIGN.md section 3.1.
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <utility>
 
 #include "common.hpp"
@@ -53,6 +54,8 @@ struct FusedArgs {
     const float* start_dv;
     int continue_sweeps;
     float hx, hy, alpha, e_smooth, e_data;
+    // developer diagnostics (FLOW2D_FUSED_STAMPS=1): per wave {start, end} in 100 MHz ticks, hardware id, xcc id
+    unsigned long long* stamps;
 };
 
 // Plane rows are fetched with buffer loads: a 128-bit descriptor per plane in scalar registers, the row offset
@@ -391,6 +394,7 @@ __global__ __launch_bounds__(256, 2) void fused_outer_kernel(FusedArgs a)
     const int lane = threadIdx.x & 63;
     const int strip_x = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (strip_x * S::kValid >= a.w) return;  // whole wave leaves; waves never synchronise with each other
+    const unsigned long long t_start = a.stamps ? __builtin_amdgcn_s_memrealtime() : 0ull;
     const int x = strip_x * S::kValid - S::kHalo + lane;
     const int xc = min(max(x, 0), a.w - 1);
     const int y0 = blockIdx.y * a.rows_per_strip;
@@ -460,17 +464,41 @@ __global__ __launch_bounds__(256, 2) void fused_outer_kernel(FusedArgs a)
         strip_tail<INNER, GRAD, false, POW2, CONT>(s, a, r, r_last, x, xc, at_l, at_r, lane_stores, y0, y1, xpm, hx_2, hy_2,
                                                    std::make_index_sequence<S::kRing - 1>{});
     }
+    if (a.stamps && lane == 0) {
+        unsigned long long* rec = a.stamps + 4ull * ((static_cast<size_t>(blockIdx.y) * gridDim.x + blockIdx.x) * 4 + (threadIdx.x >> 6));
+        rec[0] = t_start;
+        rec[1] = __builtin_amdgcn_s_memrealtime();
+        rec[2] = __builtin_amdgcn_s_getreg((31 << 11) | 4);   // HW_ID: wave, simd, cu, sh, se
+        rec[3] = __builtin_amdgcn_s_getreg((31 << 11) | 20);  // XCC_ID
+    }
 }
+
+// developer diagnostics: wave start/end stamps of the most recent fused launch (FLOW2D_FUSED_STAMPS=1)
+static const bool g_stamps_enabled = std::getenv("FLOW2D_FUSED_STAMPS") != nullptr;
+static unsigned long long* g_stamps = nullptr;
+static size_t g_stamps_bytes = 0, g_stamps_waves = 0;
+
+// developer knob for occupancy experiments: dynamic LDS bytes per workgroup (81920 leaves one workgroup per CU)
+static const unsigned kLdsPad = std::getenv("FLOW2D_FUSED_LDS_PAD") ? (unsigned)std::atoi(std::getenv("FLOW2D_FUSED_LDS_PAD")) : 0u;
+
+#define FUSED_LAUNCH(N)                                                                                       \
+    do {                                                                                                      \
+        if (kLdsPad > 65536)                                                                                  \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fused_outer_kernel<N, GRAD, POW2, CONT>), \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsPad);              \
+        fused_outer_kernel<N, GRAD, POW2, CONT><<<grid, 256, kLdsPad, stream>>>(a);                           \
+        return 0;                                                                                             \
+    } while (0)
 
 template <int GRAD, bool POW2, bool CONT>
 int launch_for_inner_cont(int inner, dim3 grid, hipStream_t stream, const FusedArgs& a)
 {
     switch (inner) {
-        case 1: fused_outer_kernel<1, GRAD, POW2, CONT><<<grid, 256, 0, stream>>>(a); return 0;
-        case 2: fused_outer_kernel<2, GRAD, POW2, CONT><<<grid, 256, 0, stream>>>(a); return 0;
-        case 3: fused_outer_kernel<3, GRAD, POW2, CONT><<<grid, 256, 0, stream>>>(a); return 0;
-        case 4: fused_outer_kernel<4, GRAD, POW2, CONT><<<grid, 256, 0, stream>>>(a); return 0;
-        case 5: fused_outer_kernel<5, GRAD, POW2, CONT><<<grid, 256, 0, stream>>>(a); return 0;
+        case 1: FUSED_LAUNCH(1);
+        case 2: FUSED_LAUNCH(2);
+        case 3: FUSED_LAUNCH(3);
+        case 4: FUSED_LAUNCH(4);
+        case 5: FUSED_LAUNCH(5);
         default: return 1;
     }
 }
@@ -542,11 +570,22 @@ int launch_fused_outer(flow2d_context* ctx, int constancy, const float* f0, cons
     if (!fused_supports(inner)) return FLOW2D_ERR_UNSUPPORTED;
     FusedArgs a{f0, f1, u, v, du, dv, out_du, out_dv, (int)w, (int)h, (int)(pitch_bytes / 4), rows_per_strip,
                 zero_increment ? 1 : 0, start_du, start_dv, (start_du && start_dv) ? 1 : 0, hx, hy, alpha, e_smooth,
-                e_data};
+                e_data, nullptr};
     const int valid = 64 - 2 * ((int)inner + 1);
     const unsigned strips_x = div_up(w, valid);
     const dim3 grid(div_up(strips_x, 4), div_up(h, rows_per_strip));
     const bool pow2 = is_power_of_two(hx) && is_power_of_two(hy);
+    if (g_stamps_enabled) {
+        const size_t need = static_cast<size_t>(grid.x) * grid.y * 4 * 4 * sizeof(unsigned long long);
+        if (need > g_stamps_bytes) {
+            if (g_stamps) (void)hipFree(g_stamps);
+            FLOW2D_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&g_stamps), need));
+            g_stamps_bytes = need;
+        }
+        FLOW2D_HIP_TRY(hipMemsetAsync(g_stamps, 0, need, ctx->stream));
+        a.stamps = g_stamps;
+        g_stamps_waves = static_cast<size_t>(grid.x) * grid.y * 4;
+    }
     int rc;
     if (constancy == FLOW2D_CONSTANCY_GRADIENT)
         rc = pow2 ? launch_for_inner<1, true>((int)inner, grid, ctx->stream, a)
@@ -566,3 +605,16 @@ int launch_fused_outer(flow2d_context* ctx, int constancy, const float* f0, cons
 }
 
 }  // namespace flow2d
+
+// developer diagnostics, not part of the C-ABI header: copies the stamps of the most recent fused launch
+// (4 x u64 per wave: start, end [100 MHz ticks], HW_ID, XCC_ID; all zero for waves that left at once)
+extern "C" __attribute__((visibility("default"))) int flow2d_debug_fused_stamps(unsigned long long* host, size_t capacity_waves,
+                                                                                size_t* waves)
+{
+    if (!g_stamps || !host || !waves) return FLOW2D_ERR_INVALID_ARGUMENT;
+    *waves = g_stamps_waves;
+    const size_t n = g_stamps_waves < capacity_waves ? g_stamps_waves : capacity_waves;
+    FLOW2D_HIP_TRY(hipDeviceSynchronize());
+    FLOW2D_HIP_TRY(hipMemcpy(host, g_stamps, n * 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    return FLOW2D_OK;
+}

@@ -42,6 +42,35 @@ WORKER = textwrap.dedent("""
 """) % (ROOT, ROOT)
 
 
+def run_workers(tmp_path, world, port):
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE=str(world), OMP_NUM_THREADS="2")
+    procs = []
+    for rank in range(world):
+        e = dict(env, RANK=str(rank), LOCAL_RANK=str(rank))
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=e, stdout=subprocess.PIPE,
+                                      stderr=subprocess.PIPE, text=True))
+    outs = []
+    for p in procs:
+        out, err = p.communicate(timeout=240)
+        assert p.returncode == 0, err[-2000:]
+        outs.append(__import__("json").loads(out.strip().splitlines()[-1]))
+    outs.sort(key=lambda o: o["rank"])
+    return outs
+
+
+def test_four_ranks_uneven_pair_counts(tmp_path):
+    """5 pairs on 4 ranks: rank 0 owns two, the others one; the all_gather blocks are padded and every pair's
+    field arrives on every rank exactly once."""
+    outs = run_workers(tmp_path, 4, 29541)
+    assert [o["mine"] for o in outs] == [[0, 4], [1], [2], [3]]
+    assert all(o["digests"] == outs[0]["digests"] for o in outs) and all(d != 0.0 for d in outs[0]["digests"])
+    assert all(o["field_digests"] == outs[0]["digests"] for o in outs)
+    assert all(o["slowest"] == outs[0]["slowest"] for o in outs)
+    assert all(o["params"] == [3.0, 0.5, 2.0, 2.0, 35.0] for o in outs)
+
+
 def test_two_rank_sharding_with_gloo(tmp_path):
     script = tmp_path / "worker.py"
     script.write_text(WORKER)

@@ -206,18 +206,25 @@ def test_cli_exit_codes_without_device(flow2d, tmp_path):
 
 
 def test_committed_bench_line_has_the_contract_fields():
-    """The bench line committed with the rocprof summary carries every field the bench contract names."""
+    """The bench line committed under profiles/ carries every field the bench contract names, and the roofline block
+    says both what the contract defines (algorithmic bytes over the launch time) and what the kernel is bound by."""
     import json
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    line = json.loads(open(os.path.join(root, "profiles", "r01_final_bench_line_under_rocprof.json")).read())
+    line = json.loads(open(os.path.join(root, "profiles", "r02_default_bench_line.json")).read())
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
-                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "output_check", "batch",
+                "reference_gpu_baseline"):
         assert key in line, key
     assert line["config"]["workload"] == "cfg3_4096_gradient" and line["scaling"] == "weak" and line["dtype"] == "f32"
+    assert line["output_check"]["ok"] and line["batch"]["output_check"]["ok"]
     roof = line["roofline"]
-    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic", "physical_bytes_per_launch", "physical_gbs",
+                "physical_frac", "valu_instr_per_launch", "valu_issue_frac", "bound_actual"):
         assert key in roof, key
-    assert roof["bound"] == "hbm" and roof["peak"] == 8000.0 and abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-3
+    assert roof["bound"] in ("hbm", "mfma") and roof["peak"] == 8000.0
+    assert abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-3
+    # the fused kernel moves a fraction of the algorithmic bytes: its physical HBM fraction is far below frac
+    assert roof["traffic"] == roof["physical_bytes_per_launch"] and 0.05 < roof["physical_frac"] < 0.6 < roof["frac"]
 
 
 # ---- the product's host layer against THE REFERENCE'S OWN host code ---------------------------------------

@@ -5,7 +5,8 @@ Launches, at 4096^2 (working set 12 x 64 MiB, far beyond the 256 MiB Infinity Ca
     a 1-tap Gaussian row pass (4 B per lane: 1 plane read, 1 written) -- MI355X_MICROARCH.md says FETCH_SIZE
     halves wide coalesced reads on gfx950 and that other widths must be calibrated on a known byte count;
   * the fused outer-iteration kernel and the per-sweep kernels, Grey and Gradient.
-Run under:  rocprofv3 --kernel-trace --pmc FETCH_SIZE -- python3 tools/pmc_workload.py   (and again with WRITE_SIZE)
+Run under:  rocprofv3 --kernel-trace --pmc FETCH_SIZE -- python3 tools/pmc_workload.py   (and again with WRITE_SIZE,
+"TCC_HIT_sum TCC_MISS_sum" and "SQ_INSTS_VALU SQ_WAVES"; tools/pmc_passes.sh runs the four passes)
 """
 import importlib
 import os
@@ -29,7 +30,8 @@ def main():
         ctx.convolution_rows(tdv, planes[1], w, h, one_tap, 0)
     for constancy in (0, 1):
         for algo in (2, 1):
-            ctx.solve_level(*planes, du, dv, phi, ksi, tdu, tdv, w, h, 1.0, 1.0, 35.0, 0.001, 0.001, 3, 5, constancy, algo)
+            # 4 outer iterations: the fused path's first launch of a level (du = dv = 0, planes not read) + 3 steady ones
+            ctx.solve_level(*planes, du, dv, phi, ksi, tdu, tdv, w, h, 1.0, 1.0, 35.0, 0.001, 0.001, 4, 5, constancy, algo)
     ctx.synchronize()
     ctx.close()
 
