@@ -116,6 +116,7 @@ def hip_lib():
         L.flow2d_solve_2d_grad.argtypes = [vp] * 9 + [sz, sz, sz, f, f, f, vp, vp]
         L.flow2d_solve_2d_grad_untiled.argtypes = [vp] * 9 + [sz, sz, sz, f, f, f, vp, vp]
         L.flow2d_solve_2d_log.argtypes = [vp] * 9 + [sz, sz, sz, f, f, f, vp, vp]
+        L.flow2d_solver_algorithm_for.argtypes = [i, sz, sz, sz, sz, sz]
         L.flow2d_solve_2d_sor.argtypes = [vp] * 9 + [sz, sz, sz, f, f, f, f, i]
         L.flow2d_solve_level.argtypes = [vp] * 11 + [C.POINTER(SolveParams), C.POINTER(i)]
         L.flow2d_timing_enable.argtypes = [vp, i]

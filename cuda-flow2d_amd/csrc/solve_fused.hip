@@ -523,6 +523,10 @@ namespace flow2d {
 
 bool fused_supports(size_t inner) { return inner >= 1 && inner <= 5; }
 
+// The fused kernel addresses a plane through a buffer descriptor with 32-bit byte offsets (row offset as the scalar
+// offset, column as a 32-bit vector offset): the plane, height x pitch bytes, must stay below 4 GiB.
+bool fused_addressable(size_t h, size_t pitch_bytes) { return h != 0 && pitch_bytes <= 0xffffffffull / h; }
+
 // Rows per strip.  A wave spends (rows + 2*inner + 3) row steps on `rows` stored rows, so tall strips
 // waste less; but the launch should fill the chip in whole co-resident rounds (two 256-thread
 // workgroups per CU at ~200 VGPRs).  Cost model in row steps: a full round of 2 workgroups per CU
@@ -567,7 +571,7 @@ int launch_fused_outer(flow2d_context* ctx, int constancy, const float* f0, cons
                        float* out_dv, int rows_per_strip, bool zero_increment, const float* start_du,
                        const float* start_dv)
 {
-    if (!fused_supports(inner)) return FLOW2D_ERR_UNSUPPORTED;
+    if (!fused_supports(inner) || !fused_addressable(h, pitch_bytes)) return FLOW2D_ERR_UNSUPPORTED;
     FusedArgs a{f0, f1, u, v, du, dv, out_du, out_dv, (int)w, (int)h, (int)(pitch_bytes / 4), rows_per_strip,
                 zero_increment ? 1 : 0, start_du, start_dv, (start_du && start_dv) ? 1 : 0, hx, hy, alpha, e_smooth,
                 e_data, nullptr};

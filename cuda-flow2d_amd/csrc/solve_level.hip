@@ -23,6 +23,7 @@ int launch_small_level(flow2d_context* ctx, int constancy, const float* f0, cons
                        const float* v, size_t w, size_t h, size_t pitch_bytes, float hx, float hy, float alpha,
                        float e_smooth, float e_data, size_t outer, size_t inner, float* out_du, float* out_dv);
 bool fused_supports(size_t inner);
+bool fused_addressable(size_t h, size_t pitch_bytes);
 int fused_rows_per_strip(const flow2d_context* ctx, size_t w, size_t h, size_t inner);
 int launch_fused_outer(flow2d_context* ctx, int constancy, const float* f0, const float* f1, const float* u,
                        const float* v, const float* du, const float* dv, size_t w, size_t h, size_t pitch_bytes,
@@ -55,6 +56,29 @@ hipError_t mark(flow2d_context* ctx, flow2d_timing_slot* slot)
 
 extern "C" {
 
+// The algorithm flow2d_solve_level runs for a request (never AUTO), or -1 when the requested one cannot run the
+// level.  Pure host logic, no device needed.
+int flow2d_solver_algorithm_for(int requested, size_t width, size_t height, size_t pitch_bytes, size_t outer, size_t inner)
+{
+    if (requested < FLOW2D_SOLVER_AUTO || requested > FLOW2D_SOLVER_SINGLE_WORKGROUP) return -1;
+    if (requested == FLOW2D_SOLVER_AUTO) {
+        // Up to 64 x 32 the whole level runs in one launch on one CU (solve_small.hip; measured 0.06-0.10 ms
+        // against 0.16-0.19 ms for 60 per-sweep launches; at 64 x 64 four pixels per thread spill and lose).
+        // Everything else goes through the fused kernel: since its strip start-up is peeled it also wins on the
+        // launch-bound levels (10 launches of ~15 us instead of 60 of ~4 us: 0.15 against 0.21 ms at 64^2 .. 256^2),
+        // and above 512^2 it wins by 1.7-2.9x.  A single sweep per outer iteration leaves nothing to fuse, and a
+        // plane of 4 GiB or more is beyond the fused kernel's 32-bit buffer offsets: both take the per-sweep kernels.
+        if (flow2d::small_level_supports(width, height) && height <= 32) return FLOW2D_SOLVER_SINGLE_WORKGROUP;
+        return (inner >= 2 && flow2d::fused_addressable(height, pitch_bytes)) ? FLOW2D_SOLVER_FUSED : FLOW2D_SOLVER_PER_SWEEP;
+    }
+    if (requested == FLOW2D_SOLVER_SINGLE_WORKGROUP && !flow2d::small_level_supports(width, height)) return -1;
+    if (requested == FLOW2D_SOLVER_FUSED) {
+        if (inner == 0 && outer != 0) return -1;  // nothing to fuse: an outer iteration without sweeps leaves du, dv as they are
+        if (!flow2d::fused_addressable(height, pitch_bytes)) return -1;
+    }
+    return requested;
+}
+
 int flow2d_solve_level(flow2d_context* ctx, const float* frame_0, const float* frame_1, const float* flow_u,
                        const float* flow_v, float* flow_du, float* flow_dv, float* phi, float* ksi, float* temp_du,
                        float* temp_dv, const flow2d_solve_params* p, int* result_in_temp)
@@ -79,23 +103,10 @@ int flow2d_solve_level(flow2d_context* ctx, const float* frame_0, const float* f
     if (sor && (!(p->sor_omega > 0.f) || !(p->sor_omega < 2.f))) return FLOW2D_ERR_INVALID_ARGUMENT;
     if (sor && p->algorithm != FLOW2D_SOLVER_AUTO && p->algorithm != FLOW2D_SOLVER_PER_SWEEP) return FLOW2D_ERR_UNSUPPORTED;
     if (sor && p->data_constancy == FLOW2D_CONSTANCY_LOG_DERIVATIVES) return FLOW2D_ERR_UNSUPPORTED;
-    int algorithm = sor ? FLOW2D_SOLVER_PER_SWEEP : p->algorithm;
-    if (algorithm == FLOW2D_SOLVER_AUTO) {
-        // Up to 64 x 32 the whole level runs in one launch on one CU (solve_small.hip; measured 0.06-0.10 ms
-        // against 0.16-0.19 ms for 60 per-sweep launches; at 64 x 64 four pixels per thread spill and lose).
-        // Everything else goes through the fused kernel: since its strip start-up is peeled it also wins on the
-        // launch-bound levels (10 launches of ~15 us instead of 60 of ~4 us: 0.15 against 0.21 ms at 64^2 .. 256^2),
-        // and above 512^2 it wins by 1.7-2.9x.  A single sweep per outer iteration leaves nothing to fuse.
-        const bool big = p->inner_iterations_count >= 2;
-        if (flow2d::small_level_supports(p->width, p->height) && p->height <= 32)
-            algorithm = FLOW2D_SOLVER_SINGLE_WORKGROUP;
-        else
-            algorithm = big ? FLOW2D_SOLVER_FUSED : FLOW2D_SOLVER_PER_SWEEP;
-    }
-    if (algorithm == FLOW2D_SOLVER_SINGLE_WORKGROUP && !flow2d::small_level_supports(p->width, p->height))
-        return FLOW2D_ERR_UNSUPPORTED;
-    if (algorithm == FLOW2D_SOLVER_FUSED && p->inner_iterations_count == 0 && p->outer_iterations_count != 0)
-        return FLOW2D_ERR_UNSUPPORTED;  // nothing to fuse: an outer iteration without sweeps leaves du, dv as they are
+    const int algorithm = sor ? FLOW2D_SOLVER_PER_SWEEP
+                              : flow2d_solver_algorithm_for(p->algorithm, p->width, p->height, p->pitch_bytes,
+                                                            p->outer_iterations_count, p->inner_iterations_count);
+    if (algorithm < 0) return FLOW2D_ERR_UNSUPPORTED;
 
     flow2d_timing_slot* slot = nullptr;
     if (ctx->timing) {

@@ -47,13 +47,17 @@ CudaOperationBase::~CudaOperationBase() = default;
 
 bool CudaOperationBase::IsInitialized() const
 {
-    if (!initialized_) std::printf("Error: Operation '%s' was not initialized.\n", name_);
+    if (!initialized_) {
+        std::printf("Error: Operation '%s' was not initialized.\n", name_);
+        failed_ = true;
+    }
     return initialized_;
 }
 
 bool CudaOperationBase::Failed(int status, const char* what) const
 {
     if (status == FLOW2D_OK) return false;
+    failed_ = true;
     std::printf("Operation '%s': %s failed: %s. %s\n", name_, what, flow2d_status_string(status), flow2d_last_error());
     return true;
 }

@@ -22,6 +22,16 @@ public:
 
     virtual ~CudaOperationBase();
 
+    // Execute() is void like the reference's (which prints and goes on after a failed driver call, leaving stale
+    // buffers to be swapped in: SURVEY section 5).  A superset for callers that want to know: true when an Execute()
+    // since the last call refused its arguments, missed a key or had a C-ABI call fail; reading clears it.
+    bool TakeFailure()
+    {
+        const bool f = failed_;
+        failed_ = false;
+        return f;
+    }
+
 protected:
     explicit CudaOperationBase(const char* name) : name_(name) {}
 
@@ -32,6 +42,7 @@ protected:
     flow2d_context* context_ = nullptr;
     DataSize3 dev_container_size_{0, 0, 0};
     bool initialized_ = false;
+    mutable bool failed_ = false;  // sticky until TakeFailure()
 
 private:
     const char* name_ = nullptr;
@@ -43,6 +54,7 @@ private:
     do {                                                                                       \
         if (!(PARAMS).Read<TYPE>((KEY), (VAR))) {                                              \
             std::printf("Operation: '%s'. Missing parameter '%s'.\n", GetName(), (KEY));       \
+            failed_ = true;                                                                    \
             return;                                                                            \
         }                                                                                      \
     } while (0)
@@ -52,6 +64,7 @@ private:
         (PTR) = static_cast<TYPE*>((PARAMS).GetValuePtr((KEY)));                               \
         if (!(PTR)) {                                                                          \
             std::printf("Operation: '%s'. Missing parameter '%s'.\n", GetName(), (KEY));       \
+            failed_ = true;                                                                    \
             return;                                                                            \
         }                                                                                      \
     } while (0)

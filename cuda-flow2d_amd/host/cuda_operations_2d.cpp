@@ -37,6 +37,7 @@ void CudaOperationConvolution2D::ComputeGaussianKernel(float sigma, size_t preci
     kernel_radius_ = 0;
     if (precision != 3 || pixel_size != 1.0f) {
         std::printf("<%s>: only precision 3 / pixel size 1 Gaussian kernels are supported.\n", GetName());
+        failed_ = true;
         return;
     }
     if (Failed(flow2d_gaussian_kernel(sigma, kernel_, &radius), "flow2d_gaussian_kernel")) return;
@@ -68,6 +69,7 @@ void CudaOperationConvolution2D::Execute(OperationParameters& params)
     FLOW2D_PARAM_OR_RETURN(params, float, gaussian_sigma, "gaussian_sigma");
     if (dev_input == dev_output) {
         std::printf("Operation '%s': Error. Input buffer cannot serve as output buffer.", GetName());
+        failed_ = true;
         return;
     }
     ComputeGaussianKernel(gaussian_sigma, 3, 1.0f);
@@ -93,6 +95,7 @@ void CudaOperationMedian2D::Execute(OperationParameters& params)
     FLOW2D_PARAM_OR_RETURN(params, size_t, radius, "radius");
     if (dev_input == dev_output) {
         std::printf("Operation '%s': Error. Input buffer cannot serve as output buffer.", GetName());
+        failed_ = true;
         return;
     }
     DevicePtr dev_input_b = 0, dev_output_b = 0;  // optional second plane (not in the reference's bag)
@@ -100,6 +103,7 @@ void CudaOperationMedian2D::Execute(OperationParameters& params)
                       params.Read<DevicePtr>("dev_output_b", dev_output_b);
     if (pair && dev_input_b == dev_output_b) {
         std::printf("Operation '%s': Error. Input buffer cannot serve as output buffer.", GetName());
+        failed_ = true;
         return;
     }
     if (radius == 1) {  // no filtering: copy the whole container (cuda_operation_median_2d.cpp:100-104)
@@ -127,6 +131,7 @@ void CudaOperationMedian2D::Execute(OperationParameters& params)
                "flow2d_median_2d");
     } else {
         std::printf("Error. Wrong median raduis (%zu). Supported values: 3, 5, 7\n", radius);
+        failed_ = true;
     }
 }
 
@@ -147,6 +152,7 @@ void CudaOperationRegistration2D::Execute(OperationParameters& params)
     FLOW2D_PARAM_OR_RETURN(params, float, hy, "hy");
     if (dev_frame_1 == dev_output) {
         std::printf("Operation '%s': Error. Input buffer cannot serve as output buffer.", GetName());
+        failed_ = true;
         return;
     }
     Failed(flow2d_registration_2d(context_, AsPlane(dev_frame_0), AsPlane(dev_frame_1), AsPlane(dev_flow_u),
@@ -168,6 +174,7 @@ void CudaOperationResample2D::Execute(OperationParameters& params)
     FLOW2D_PARAM_OR_RETURN(params, DataSize3, resample_size, "resample_size");
     if (dev_input == dev_output) {
         std::printf("Operation '%s': Error. Input buffer cannot serve as output buffer.", GetName());
+        failed_ = true;
         return;
     }
     // optional second plane set (not in the reference's bag): two planes of the same geometry per launch

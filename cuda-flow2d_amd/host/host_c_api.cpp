@@ -91,7 +91,8 @@ HOST_API size_t flow2d_host_max_warp_level_static(size_t width, size_t height, f
     return flow.GetMaxWarpLevel(width, height, scale);
 }
 
-// OpticalFlow2D::ComputeFlow on tight host images (width*height floats each).  0 on success.
+// OpticalFlow2D::ComputeFlow on tight host images (width*height floats each).  0 on success, 2 when the run
+// delivered no flow.
 HOST_API int flow2d_host_compute_flow(flow2d_host_flow* h, const float* frame_0, const float* frame_1, float* flow_u,
                                       float* flow_v, const flow2d_host_params* params, float* total_ms)
 {
@@ -109,7 +110,7 @@ HOST_API int flow2d_host_compute_flow(flow2d_host_flow* h, const float* frame_0,
     std::memcpy(flow_u, u.DataPtr(), n * sizeof(float));
     std::memcpy(flow_v, v.DataPtr(), n * sizeof(float));
     if (total_ms) *total_ms = h->flow.LastTotalMs();
-    return 0;
+    return h->flow.LastRunSucceeded() ? 0 : 2;  // 2: the run was refused or an operator failed (outputs keep the poison)
 }
 
 // OpticalFlow2D::ComputeFlowDevice: frames and flow already in pitched device containers.  Queued on

@@ -150,6 +150,13 @@ int main(int argc, char** argv)
         params.PushValuePtr("gaussian_sigma", &gaussian_sigma);
         if (sor_omega != 0.f) params.PushValuePtr("solver_sor_omega", &sor_omega);
         optical_flow.ComputeFlow(frame_0, frame_1, flow_u, flow_v, params);
+        if (!optical_flow.LastRunSucceeded()) {
+            // the reference writes whatever its buffers hold after a failed run; no output files here instead
+            std::cout << "Error: the flow computation failed, no output written." << std::endl;
+            optical_flow.Destroy();
+            DestroyDeviceContext();
+            return 4;  // superset of the reference's exit codes (0, 1, 2, 3, 255)
+        }
 
         const std::string suffix = "-" + std::to_string(width) + "-" + std::to_string(height) + ".raw";
         flow_u.WriteRAWToFileF32((output_path + counter + "flow-u" + suffix).c_str());

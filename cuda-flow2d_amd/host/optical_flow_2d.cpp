@@ -248,6 +248,7 @@ std::vector<FlowLevelTiming> OpticalFlow2D::LastLevelTimings()
 void OpticalFlow2D::ComputeFlow(Data2D& frame_0, Data2D& frame_1, Data2D& flow_u, Data2D& flow_v,
                                 OperationParameters& params)
 {
+    last_run_ok_ = false;
     if (!IsInitialized()) return;
     const size_t W = dev_container_size_.width, H = dev_container_size_.height;
     if (frame_0.Width() != W || frame_0.Height() != H || frame_1.Width() != W || frame_1.Height() != H ||
@@ -269,9 +270,10 @@ void OpticalFlow2D::ComputeFlow(Data2D& frame_0, Data2D& frame_1, Data2D& flow_u
               CopyData2DtoDevice(frame_1, dev_frame_1_, H, dev_container_size_.pitch);
     ok = ok && RunPyramid(params);
     if (ok) {
-        CopyData2DFromDevice(dev_flow_u_, flow_u, H, dev_container_size_.pitch);
-        CopyData2DFromDevice(dev_flow_v_, flow_v, H, dev_container_size_.pitch);
+        ok = CopyData2DFromDevice(dev_flow_u_, flow_u, H, dev_container_size_.pitch) &&
+             CopyData2DFromDevice(dev_flow_v_, flow_v, H, dev_container_size_.pitch);
     }
+    last_run_ok_ = ok;
     flow2d_event_record(context_, ev_stop);
     flow2d_event_synchronize(context_, ev_stop);  // the only host wait of a pair
     flow2d_event_elapsed_ms(context_, ev_start, ev_stop, &last_total_ms_);
@@ -335,7 +337,11 @@ bool OpticalFlow2D::ComputeFlowDevice(DevicePtr dev_frame_0, DevicePtr dev_frame
     std::vector<unsigned char> key = GraphKey(dev_frame_0, dev_frame_1, dev_flow_u, dev_flow_v, params);
     auto it = graphs_.find(key);
     if (it == graphs_.end()) {
-        if (graphs_.size() >= kMaxGraphs) DropGraphs();
+        if (graphs_.size() >= kMaxGraphs) {
+            // the recorded graphs may still be running on the stream (replays are not synchronised by contract)
+            flow2d_synchronize(context_);
+            DropGraphs();
+        }
         if (CheckFlow2DError(flow2d_capture_begin(context_), "flow2d_capture_begin")) return false;
         const bool queued = QueuePair(dev_frame_0, dev_frame_1, dev_flow_u, dev_flow_v, params);
         void* exec = nullptr;
@@ -441,6 +447,11 @@ bool OpticalFlow2D::RunPyramid(OperationParameters& params)
     DevicePtr frame_0 = dev_frame_0_, frame_1 = dev_frame_1_, flow_u = dev_flow_u_, flow_v = dev_flow_v_;
     DevicePtr frame_0_res = Acquire(), frame_1_res = Acquire(), flow_du = Acquire(), flow_dv = Acquire();
     OperationParameters op;
+    // The operators' Execute() is void, like the reference's, whose ComputeFlow never learns of a failed launch and
+    // swaps the stale output plane in.  Here every operator's failure flag is collected and the
+    // run is abandoned at the end of the level it happened in: ComputeFlow then leaves the caller's flow untouched,
+    // ComputeFlowDevice returns false and no graph of the broken run is kept.
+    bool failed = false;
 
     const bool sequence = sequence_frames_[0] != nullptr;
     if (sequence) {  // a frame's level 0 is blurred once (or is the caller's own plane) and then only read
@@ -459,6 +470,7 @@ bool OpticalFlow2D::RunPyramid(OperationParameters& params)
                     op.PushValuePtr("data_size", &original_size);
                     op.PushValuePtr("gaussian_sigma", &gaussian_sigma);
                     cuop_convolution_.Execute(op);
+                failed |= cuop_convolution_.TakeFailure();
                 }
             } else {
                 pyramid.level0 = callers[i];
@@ -478,6 +490,7 @@ bool OpticalFlow2D::RunPyramid(OperationParameters& params)
             op.PushValuePtr("data_size", &original_size);
             op.PushValuePtr("gaussian_sigma", &gaussian_sigma);
             cuop_convolution_.Execute(op);
+        failed |= cuop_convolution_.TakeFailure();
         }
         Release(temp);
     } else if (gaussian_sigma > 0.0) {  // optical_flow_2d.cpp:218-246: blur into the flow planes, then swap roles
@@ -491,6 +504,7 @@ bool OpticalFlow2D::RunPyramid(OperationParameters& params)
             op.PushValuePtr("data_size", &original_size);
             op.PushValuePtr("gaussian_sigma", &gaussian_sigma);
             cuop_convolution_.Execute(op);
+            failed |= cuop_convolution_.TakeFailure();
             std::swap(*pair[0], *pair[1]);
         }
         Release(temp);
@@ -528,6 +542,7 @@ bool OpticalFlow2D::RunPyramid(OperationParameters& params)
                     op.PushValuePtr("data_size", &original_size);
                     op.PushValuePtr("resample_size", &current_size);
                     cuop_resample_.Execute(op);
+                failed |= cuop_resample_.TakeFailure();
                 }
                 sequence_level[i] = plane;
             }
@@ -547,6 +562,7 @@ bool OpticalFlow2D::RunPyramid(OperationParameters& params)
             op.PushValuePtr("data_size", &original_size);
             op.PushValuePtr("resample_size", &current_size);
             cuop_resample_.Execute(op);
+            failed |= cuop_resample_.TakeFailure();
             Release(temp_b);
             Release(temp);
         }
@@ -568,6 +584,7 @@ bool OpticalFlow2D::RunPyramid(OperationParameters& params)
             op.PushValuePtr("data_size", &prev_size);
             op.PushValuePtr("resample_size", &current_size);
             cuop_resample_.Execute(op);
+            failed |= cuop_resample_.TakeFailure();
             std::swap(flow_u, flow_du);
             std::swap(flow_v, flow_dv);
             Release(temp_b);
@@ -586,6 +603,7 @@ bool OpticalFlow2D::RunPyramid(OperationParameters& params)
             op.PushValuePtr("hx", &hx);
             op.PushValuePtr("hy", &hy);
             cuop_register_.Execute(op);
+            failed |= cuop_register_.TakeFailure();
             solve_frame_0 = sequence_level[0];
         } else {  // backward registration of frame 1 by the current flow; the warped frame replaces it
             DevicePtr temp = Acquire();
@@ -599,6 +617,7 @@ bool OpticalFlow2D::RunPyramid(OperationParameters& params)
             op.PushValuePtr("hx", &hx);
             op.PushValuePtr("hy", &hy);
             cuop_register_.Execute(op);
+            failed |= cuop_register_.TakeFailure();
             std::swap(frame_1_res, temp);
             Release(temp);
         }
@@ -629,6 +648,7 @@ bool OpticalFlow2D::RunPyramid(OperationParameters& params)
             op.PushValuePtr("solver_sor_omega", &solver_sor_omega);
             cuop_solve_.silent = true;  // per-level printing would need a host wait; timings are collected instead
             cuop_solve_.Execute(op);
+            failed |= cuop_solve_.TakeFailure();
             Release(phi);
             Release(ksi);
             Release(temp_du);
@@ -643,8 +663,10 @@ bool OpticalFlow2D::RunPyramid(OperationParameters& params)
             op.PushValuePtr("operand_1_b", &flow_dv);
             op.PushValuePtr("data_size", &current_size);
             cuop_add_.Execute(op);
+        failed |= cuop_add_.TakeFailure();
         }
         prev_size = current_size;
+        if (failed) break;
 
         {  // median of u and v after every level, the finest included (one launch for both)
             DevicePtr temp = Acquire(), temp_b = Acquire();
@@ -659,6 +681,7 @@ bool OpticalFlow2D::RunPyramid(OperationParameters& params)
             op.PushValuePtr("data_size", &current_size);
             op.PushValuePtr("radius", &median_radius);
             cuop_median_.Execute(op);
+            failed |= cuop_median_.TakeFailure();
             if (!deliver) {
                 std::swap(flow_u, temp);
                 std::swap(flow_v, temp_b);
@@ -680,5 +703,6 @@ bool OpticalFlow2D::RunPyramid(OperationParameters& params)
     Release(flow_du);
     Release(flow_dv);
     flow2d_timing_enable(context_, 0);
-    return true;
+    if (failed) std::printf("Error: '%s': an operator failed; the flow of this run is not valid.\n", GetName());
+    return !failed;
 }

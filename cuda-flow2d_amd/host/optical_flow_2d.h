@@ -89,6 +89,9 @@ public:
     const DataSize3& ContainerSize() const { return dev_container_size_; }
     // Device time of the last ComputeFlow (events around upload..download), milliseconds.
     float LastTotalMs() const { return last_total_ms_; }
+    // ComputeFlow is void, like the reference's: whether the last call delivered a flow (false after a missing key,
+    // a parameter no level can run with, or a failed operator -- the caller's flow images are then left untouched)
+    bool LastRunSucceeded() const { return last_run_ok_; }
     int timing_mode = 0;  // flow2d_timing_enable mode used during a run (0 off, 1 per level, 2 + per kernel launch)
     // One record per level solved since the last ResetLevelTimings() (oldest first); call after the
     // context has been synchronised.  Records accumulate across runs while timing_mode is non-zero.
@@ -130,6 +133,7 @@ private:
     void FreeSequenceCache();
     flow2d_context* context_ = nullptr;
     float last_total_ms_ = 0.f;
+    bool last_run_ok_ = false;
     // recorded pyramids, keyed by the caller buffers and parameters they were recorded for
     std::map<std::vector<unsigned char>, void*> graphs_;
     static constexpr size_t kMaxGraphs = 32;

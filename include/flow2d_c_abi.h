@@ -254,6 +254,13 @@ typedef struct flow2d_solve_params {
                                     launches only; the result stays in flow_du / flow_dv). */
 } flow2d_solve_params;
 
+/* Which algorithm flow2d_solve_level runs for a request: `requested` resolved (AUTO -> one of the three), or -1 when the
+ * requested algorithm cannot run the level (SINGLE_WORKGROUP above 64 x 64; FUSED without sweeps, or on planes of
+ * 4 GiB and more, which its 32-bit buffer offsets cannot address -- AUTO takes the per-sweep kernels there).  Host
+ * logic only, needs no device. */
+FLOW2D_API int flow2d_solver_algorithm_for(int requested, size_t width, size_t height, size_t pitch_bytes,
+                                           size_t outer_iterations_count, size_t inner_iterations_count);
+
 FLOW2D_API int flow2d_solve_level(flow2d_context* ctx, const float* frame_0, const float* frame_1,
                                   const float* flow_u, const float* flow_v, float* flow_du, float* flow_dv,
                                   float* phi, float* ksi, float* temp_du, float* temp_dv,

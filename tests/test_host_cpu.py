@@ -43,6 +43,24 @@ def test_c_abi_rejects_bad_arguments_without_a_device(flow2d):
     assert lib.flow2d_gaussian_kernel(9.0, taps, ctypes.byref(r)) == 5  # 55 taps > 51
 
 
+def test_solver_algorithm_selection_and_32bit_guard(flow2d):
+    """flow2d_solve_level's choice of algorithm, checked without a device: AUTO = one workgroup up to 64 x 32, the
+    fused kernel when there are >= 2 sweeps to fuse, per-sweep launches otherwise -- and whenever the plane reaches
+    4 GiB, which the fused kernel's 32-bit buffer offsets cannot address (an explicit FUSED request is refused there
+    instead of wrapping around)."""
+    pick = flow2d.hip_lib().flow2d_solver_algorithm_for
+    AUTO, SWEEP, FUSED, ONE = 0, 1, 2, 3
+    pitch = lambda w: flow2d.hip_lib().flow2d_plane_pitch_bytes(w)
+    assert pick(AUTO, 64, 32, pitch(64), 10, 5) == ONE and pick(AUTO, 64, 33, pitch(64), 10, 5) == FUSED
+    assert pick(AUTO, 4096, 4096, pitch(4096), 10, 5) == FUSED and pick(AUTO, 4096, 4096, pitch(4096), 10, 1) == SWEEP
+    assert pick(ONE, 65, 40, pitch(65), 1, 1) == -1 and pick(FUSED, 640, 480, pitch(640), 2, 0) == -1
+    assert pick(FUSED, 640, 480, pitch(640), 0, 0) == FUSED and pick(7, 64, 64, 256, 1, 1) == -1
+    # 32768 x 32767 floats: 4 GiB minus one row -> still addressable; 32768 x 32768: exactly 4 GiB -> not
+    assert pick(FUSED, 32768, 32767, pitch(32768), 10, 5) == FUSED and pick(AUTO, 32768, 32767, pitch(32768), 10, 5) == FUSED
+    assert pick(FUSED, 32768, 32768, pitch(32768), 10, 5) == -1 and pick(AUTO, 32768, 32768, pitch(32768), 10, 5) == SWEEP
+    assert pick(AUTO, 100000, 20000, pitch(100000), 10, 5) == SWEEP
+
+
 def test_gaussian_taps_match_oracle(flow2d, oracle):
     for sigma in (0.45, 1.0, 1.5, 3.0, 8.3):
         taps, r = flow2d.gaussian_kernel(sigma)
