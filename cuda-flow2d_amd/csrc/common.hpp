@@ -58,10 +58,13 @@ inline unsigned div_up(size_t a, size_t b) { return static_cast<unsigned>((a + b
         }                                                 \
     } while (0)
 
+// (hipGetLastError() is sticky per thread: an error some earlier, already reported or deliberately ignored runtime call
+// left behind must not be taken for a failed launch of this entry, so the slate is wiped on the way in.)
 #define FLOW2D_ENTER(ctx)                                               \
     if ((ctx) == nullptr) return FLOW2D_ERR_INVALID_ARGUMENT;           \
     ::flow2d::DeviceGuard flow2d_guard_(ctx);                           \
-    if (!flow2d_guard_.ok()) return FLOW2D_ERR_DEVICE
+    if (!flow2d_guard_.ok()) return FLOW2D_ERR_DEVICE;                  \
+    (void)hipGetLastError()
 
 #define FLOW2D_CHECK_LAUNCH() FLOW2D_HIP_TRY(hipGetLastError())
 
