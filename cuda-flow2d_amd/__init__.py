@@ -23,7 +23,7 @@ CLI_PATH = os.path.join(_HERE, "host", "flow2d")
 # flow2d_constancy; 2 = true-neighbour gradient term (not in the reference), 3 = the reference's LogDerivatives
 GREY, GRADIENT, GRADIENT_UNTILED, LOG_DERIVATIVES = 0, 1, 2, 3
 _HOST_CONSTANCY = {GREY: 0, GRADIENT: 1, GRADIENT_UNTILED: 3, LOG_DERIVATIVES: 2}  # enum class DataConstancy
-SOLVER_AUTO, SOLVER_PER_SWEEP, SOLVER_FUSED, SOLVER_SINGLE_WORKGROUP = 0, 1, 2, 3
+SOLVER_AUTO, SOLVER_PER_SWEEP, SOLVER_FUSED, SOLVER_SINGLE_WORKGROUP, SOLVER_TILED = 0, 1, 2, 3, 4
 
 STATUS = {0: "ok", 1: "invalid argument", 2: "no usable HIP device", 3: "HIP runtime error",
           4: "out of device memory", 5: "unsupported parameter"}
@@ -111,12 +111,13 @@ def hip_lib():
         L.flow2d_median_2d_pair.argtypes = [vp, vp, vp, sz, sz, sz, sz, vp, vp]
         L.flow2d_resample_x_pair.argtypes = [vp, vp, vp, vp, vp, sz, sz, sz, sz]
         L.flow2d_resample_y_pair.argtypes = [vp, vp, vp, vp, vp, sz, sz, sz, sz]
+        L.flow2d_resample_x_levels.argtypes = [vp, vp, vp, vp, vp, sz, sz, sz, sz, C.POINTER(sz), C.POINTER(sz)]
         L.flow2d_compute_phi_ksi.argtypes = [vp] * 7 + [sz, sz, sz, f, f, f, f, vp, vp]
         L.flow2d_solve_2d.argtypes = [vp] * 9 + [sz, sz, sz, f, f, f, vp, vp]
         L.flow2d_solve_2d_grad.argtypes = [vp] * 9 + [sz, sz, sz, f, f, f, vp, vp]
         L.flow2d_solve_2d_grad_untiled.argtypes = [vp] * 9 + [sz, sz, sz, f, f, f, vp, vp]
         L.flow2d_solve_2d_log.argtypes = [vp] * 9 + [sz, sz, sz, f, f, f, vp, vp]
-        L.flow2d_solver_algorithm_for.argtypes = [i, sz, sz, sz, sz, sz]
+        L.flow2d_solver_algorithm_for.argtypes = [i, sz, sz, sz, sz, sz, i]
         L.flow2d_solve_2d_sor.argtypes = [vp] * 9 + [sz, sz, sz, f, f, f, f, i]
         L.flow2d_solve_level.argtypes = [vp] * 11 + [C.POINTER(SolveParams), C.POINTER(i)]
         L.flow2d_timing_enable.argtypes = [vp, i]
@@ -289,6 +290,15 @@ class Context:
     def resample_y(self, src, dst, out_w, out_h, in_h):
         _check(hip_lib().flow2d_resample_y(self.handle, src.ptr, dst.ptr, out_w, out_h, in_h, src.pitch),
                "flow2d_resample_y")
+
+    def resample_x_levels(self, src, packed, in_w, h, widths, columns, src_b=None, packed_b=None):
+        """x pass for several output widths in one trip over `src`; level l lands in columns[l] .. of `packed`."""
+        n = len(widths)
+        ws = (C.c_size_t * n)(*widths)
+        cs = (C.c_size_t * n)(*columns)
+        _check(hip_lib().flow2d_resample_x_levels(self.handle, src.ptr, packed.ptr, src_b.ptr if src_b else None,
+                                                  packed_b.ptr if packed_b else None, in_w, h, src.pitch, n, ws, cs),
+               "flow2d_resample_x_levels")
 
     # two planes of the same geometry per launch
     def add_pair(self, op0_a, op1_a, op0_b, op1_b, w, h):

@@ -330,6 +330,50 @@ __global__ __launch_bounds__(256) void resample_x_lds_kernel(const float* __rest
     if (active) out[static_cast<size_t>(y) * pitch + x] = value * normalization;
 }
 
+// One trip over the input for the x pass of several pyramid levels (flow2d_resample_x_levels): a workgroup owns one
+// image row, stages it in LDS (one pad word per 32, so the lanes' strided cell walks are conflict-free for the
+// power-of-two ratios of a 0.5 pyramid) and produces every level's outputs from there.  Per output the cells are
+// accumulated left to right exactly as in resample_kernel<true> (resample_2d.cu:46-72): same bits.
+struct ResampleLevels {
+    int count;
+    int out_w[FLOW2D_RESAMPLE_MAX_LEVELS];
+    int col[FLOW2D_RESAMPLE_MAX_LEVELS];
+};
+
+__global__ __launch_bounds__(256) void resample_x_levels_kernel(const float* __restrict__ in_a, float* __restrict__ out_a,
+                                                                const float* __restrict__ in_b, float* __restrict__ out_b,
+                                                                int in_w, int pitch, ResampleLevels lv)
+{
+    extern __shared__ float row[];
+    const float* __restrict__ in = blockIdx.z ? in_b : in_a;
+    float* __restrict__ out = blockIdx.z ? out_b : out_a;
+    const size_t line = static_cast<size_t>(blockIdx.x) * pitch;
+    for (int i = threadIdx.x; i < in_w; i += 256) row[i + (i >> 5)] = in[line + i];
+    __syncthreads();
+    for (int l = 0; l < lv.count; ++l) {
+        const int out_w = lv.out_w[l];
+        const float delta = static_cast<float>(in_w) / static_cast<float>(out_w);
+        const float normalization = static_cast<float>(out_w) / static_cast<float>(in_w);
+        for (int g = threadIdx.x; g < out_w; g += 256) {
+            const float left_f = static_cast<float>(static_cast<unsigned>(g)) * delta;
+            const float right_f = static_cast<float>(static_cast<unsigned>(g) + 1u) * delta;
+            const int left_i = static_cast<int>(floorf(left_f));
+            const int right_i = min(in_w, static_cast<int>(ceilf(right_f)));
+            const int cells = right_i - left_i;
+            float value = 0.f;
+            for (int j = 0; j < cells; ++j) {
+                float frac = 1.f;
+                if (j == 0) frac = static_cast<float>(left_i + 1) - left_f;
+                if (j == cells - 1) frac = right_f - static_cast<float>(left_i + j);
+                if (cells == 1) frac = delta;
+                const int k = left_i + j;
+                value += row[k + (k >> 5)] * frac;
+            }
+            out[line + lv.col[l] + g] = value * normalization;
+        }
+    }
+}
+
 // ---- backward registration: src/kernels/registration_2d.cu:34-73 --------------------------------
 __global__ __launch_bounds__(256) void registration_kernel(const float* __restrict__ f0, const float* __restrict__ f1,
                                                            const float* __restrict__ u, const float* __restrict__ v,
@@ -507,6 +551,41 @@ static int launch_resample(flow2d_context* ctx, bool along_x, const float* input
             resample_kernel<false><<<grid, dim3(kBlockX, kBlockY), 0, ctx->stream>>>(
                 input, output, input_b, output_b, (int)out_width, (int)out_height, (int)in_extent, (int)(pitch_bytes / 4));
     }
+    FLOW2D_CHECK_LAUNCH();
+    return FLOW2D_OK;
+}
+
+int flow2d_resample_x_levels(flow2d_context* ctx, const float* input_a, float* packed_a, const float* input_b,
+                             float* packed_b, size_t in_width, size_t height, size_t pitch_bytes, size_t level_count,
+                             const size_t* out_widths, const size_t* column_offsets)
+{
+    FLOW2D_ENTER(ctx);
+    if (!out_widths || !column_offsets || level_count == 0) return FLOW2D_ERR_INVALID_ARGUMENT;
+    if (level_count > FLOW2D_RESAMPLE_MAX_LEVELS || in_width > 15360) return FLOW2D_ERR_UNSUPPORTED;
+    const bool pair = input_b || packed_b;
+    if (!flow2d::plane_args_ok(input_a, in_width, height, pitch_bytes) || !packed_a || input_a == packed_a ||
+        (reinterpret_cast<uintptr_t>(packed_a) % 16) != 0)
+        return FLOW2D_ERR_INVALID_ARGUMENT;
+    if (pair && (!flow2d::plane_args_ok(input_b, in_width, height, pitch_bytes) || !packed_b || input_b == packed_b ||
+                 packed_b == packed_a || packed_b == input_a || packed_a == input_b ||
+                 (reinterpret_cast<uintptr_t>(packed_b) % 16) != 0))
+        return FLOW2D_ERR_INVALID_ARGUMENT;
+    ResampleLevels lv{};
+    lv.count = static_cast<int>(level_count);
+    const size_t pitch = pitch_bytes / 4;
+    for (size_t l = 0; l < level_count; ++l) {
+        if (out_widths[l] == 0 || out_widths[l] >= (1u << 30) || column_offsets[l] % 4 != 0 ||
+            column_offsets[l] + out_widths[l] > pitch)
+            return FLOW2D_ERR_INVALID_ARGUMENT;
+        for (size_t m = 0; m < l; ++m)  // segments must not overlap
+            if (column_offsets[l] < column_offsets[m] + out_widths[m] && column_offsets[m] < column_offsets[l] + out_widths[l])
+                return FLOW2D_ERR_INVALID_ARGUMENT;
+        lv.out_w[l] = static_cast<int>(out_widths[l]);
+        lv.col[l] = static_cast<int>(column_offsets[l]);
+    }
+    const size_t lds_bytes = (in_width + in_width / 32 + 1) * sizeof(float);
+    resample_x_levels_kernel<<<dim3(static_cast<unsigned>(height), 1, pair ? 2 : 1), 256, lds_bytes, ctx->stream>>>(
+        input_a, packed_a, input_b, packed_b, static_cast<int>(in_width), static_cast<int>(pitch), lv);
     FLOW2D_CHECK_LAUNCH();
     return FLOW2D_OK;
 }

@@ -24,6 +24,11 @@ int launch_small_level(flow2d_context* ctx, int constancy, const float* f0, cons
                        float e_smooth, float e_data, size_t outer, size_t inner, float* out_du, float* out_dv);
 bool fused_supports(size_t inner);
 bool fused_addressable(size_t h, size_t pitch_bytes);
+bool tiled_supports(int constancy, size_t inner);
+int launch_tiled_outer(flow2d_context* ctx, int constancy, const float* f0, const float* f1, const float* u,
+                       const float* v, const float* du, const float* dv, size_t w, size_t h, size_t pitch_bytes, float hx,
+                       float hy, float alpha, float e_smooth, float e_data, size_t inner, float* out_du, float* out_dv,
+                       bool zero_increment);
 int fused_rows_per_strip(const flow2d_context* ctx, size_t w, size_t h, size_t inner);
 int launch_fused_outer(flow2d_context* ctx, int constancy, const float* f0, const float* f1, const float* u,
                        const float* v, const float* du, const float* dv, size_t w, size_t h, size_t pitch_bytes,
@@ -54,13 +59,19 @@ hipError_t mark(flow2d_context* ctx, flow2d_timing_slot* slot)
 }
 }  // namespace
 
+// largest level (pixels) AUTO gives to the tiled kernel; FLOW2D_TILED_MAX_PIXELS overrides (developer knob)
+static const size_t kTiledMaxPixels = std::getenv("FLOW2D_TILED_MAX_PIXELS")
+                                          ? static_cast<size_t>(std::atoll(std::getenv("FLOW2D_TILED_MAX_PIXELS")))
+                                          : static_cast<size_t>(640) * 640;
+
 extern "C" {
 
 // The algorithm flow2d_solve_level runs for a request (never AUTO), or -1 when the requested one cannot run the
 // level.  Pure host logic, no device needed.
-int flow2d_solver_algorithm_for(int requested, size_t width, size_t height, size_t pitch_bytes, size_t outer, size_t inner)
+int flow2d_solver_algorithm_for(int requested, size_t width, size_t height, size_t pitch_bytes, size_t outer, size_t inner,
+                                int data_constancy)
 {
-    if (requested < FLOW2D_SOLVER_AUTO || requested > FLOW2D_SOLVER_SINGLE_WORKGROUP) return -1;
+    if (requested < FLOW2D_SOLVER_AUTO || requested > FLOW2D_SOLVER_TILED) return -1;
     if (requested == FLOW2D_SOLVER_AUTO) {
         // Up to 64 x 32 the whole level runs in one launch on one CU (solve_small.hip; measured 0.06-0.10 ms
         // against 0.16-0.19 ms for 60 per-sweep launches; at 64 x 64 four pixels per thread spill and lose).
@@ -69,8 +80,14 @@ int flow2d_solver_algorithm_for(int requested, size_t width, size_t height, size
         // and above 512^2 it wins by 1.7-2.9x.  A single sweep per outer iteration leaves nothing to fuse, and a
         // plane of 4 GiB or more is beyond the fused kernel's 32-bit buffer offsets: both take the per-sweep kernels.
         if (flow2d::small_level_supports(width, height) && height <= 32) return FLOW2D_SOLVER_SINGLE_WORKGROUP;
+        // Up to kTiledMaxPixels (640 x 640) the outer iteration runs on small LDS tiles (solve_tile.hip): a strip wave
+        // needs (rows + halo) x ~1.1 us whatever the level size, tiles spread a small level over the whole chip
+        // (level solve 10 x 5 at 256^2: 0.07 against 0.14 ms, at 512^2 0.17 against 0.20; at 1024^2 the strips win).
+        if (inner >= 2 && width * height <= kTiledMaxPixels && flow2d::tiled_supports(data_constancy, inner))
+            return FLOW2D_SOLVER_TILED;
         return (inner >= 2 && flow2d::fused_addressable(height, pitch_bytes)) ? FLOW2D_SOLVER_FUSED : FLOW2D_SOLVER_PER_SWEEP;
     }
+    if (requested == FLOW2D_SOLVER_TILED && !flow2d::tiled_supports(data_constancy, inner)) return -1;
     if (requested == FLOW2D_SOLVER_SINGLE_WORKGROUP && !flow2d::small_level_supports(width, height)) return -1;
     if (requested == FLOW2D_SOLVER_FUSED) {
         if (inner == 0 && outer != 0) return -1;  // nothing to fuse: an outer iteration without sweeps leaves du, dv as they are
@@ -96,7 +113,7 @@ int flow2d_solve_level(flow2d_context* ctx, const float* frame_0, const float* f
     if (p->data_constancy != FLOW2D_CONSTANCY_GREY && p->data_constancy != FLOW2D_CONSTANCY_GRADIENT &&
         p->data_constancy != FLOW2D_CONSTANCY_GRADIENT_UNTILED && p->data_constancy != FLOW2D_CONSTANCY_LOG_DERIVATIVES)
         return FLOW2D_ERR_UNSUPPORTED;
-    if (p->algorithm < FLOW2D_SOLVER_AUTO || p->algorithm > FLOW2D_SOLVER_SINGLE_WORKGROUP)
+    if (p->algorithm < FLOW2D_SOLVER_AUTO || p->algorithm > FLOW2D_SOLVER_TILED)
         return FLOW2D_ERR_INVALID_ARGUMENT;
 
     const bool sor = p->sor_omega != 0.f;
@@ -105,7 +122,8 @@ int flow2d_solve_level(flow2d_context* ctx, const float* frame_0, const float* f
     if (sor && p->data_constancy == FLOW2D_CONSTANCY_LOG_DERIVATIVES) return FLOW2D_ERR_UNSUPPORTED;
     const int algorithm = sor ? FLOW2D_SOLVER_PER_SWEEP
                               : flow2d_solver_algorithm_for(p->algorithm, p->width, p->height, p->pitch_bytes,
-                                                            p->outer_iterations_count, p->inner_iterations_count);
+                                                            p->outer_iterations_count, p->inner_iterations_count,
+                                                            p->data_constancy);
     if (algorithm < 0) return FLOW2D_ERR_UNSUPPORTED;
 
     flow2d_timing_slot* slot = nullptr;
@@ -120,7 +138,8 @@ int flow2d_solve_level(flow2d_context* ctx, const float* frame_0, const float* f
 
     // du = dv = 0 over level width x container height (cuda_operation_solve_2d.cpp:229-232).  The fused path
     // starts its first outer iteration from zero increments without reading the planes, so it needs no memset.
-    if (algorithm == FLOW2D_SOLVER_PER_SWEEP || (algorithm == FLOW2D_SOLVER_FUSED && p->outer_iterations_count == 0)) {
+    const bool one_per_outer = algorithm == FLOW2D_SOLVER_FUSED || algorithm == FLOW2D_SOLVER_TILED;
+    if (algorithm == FLOW2D_SOLVER_PER_SWEEP || (one_per_outer && p->outer_iterations_count == 0)) {
         FLOW2D_HIP_TRY(hipMemset2DAsync(flow_du, p->pitch_bytes, 0, p->width * sizeof(float), p->container_height,
                                         ctx->stream));
         FLOW2D_HIP_TRY(hipMemset2DAsync(flow_dv, p->pitch_bytes, 0, p->width * sizeof(float), p->container_height,
@@ -173,6 +192,19 @@ int flow2d_solve_level(flow2d_context* ctx, const float* frame_0, const float* f
         }
         source = in;
     }
+    // Tiled path: one launch per outer iteration, ping-pong between the caller's two pairs
+    for (size_t i = 0; algorithm == FLOW2D_SOLVER_TILED && i < p->outer_iterations_count; ++i) {
+        const int out = source == 0 ? 1 : 0;
+        if (per_launch) FLOW2D_HIP_TRY(mark(ctx, slot));
+        int st = flow2d::launch_tiled_outer(ctx, p->data_constancy, frame_0, frame_1, flow_u, flow_v, pair_u[source],
+                                            pair_v[source], p->width, p->height, p->pitch_bytes, p->hx, p->hy,
+                                            p->equation_alpha, p->equation_smoothness, p->equation_data, inner,
+                                            pair_u[out], pair_v[out], i == 0);
+        if (st != FLOW2D_OK) return st;
+        if (per_launch) FLOW2D_HIP_TRY(mark(ctx, slot));
+        source = out;
+        ++launches;
+    }
     if (algorithm == FLOW2D_SOLVER_FUSED && source == 2) {  // the caller only knows two pairs: hand the result over
         FLOW2D_HIP_TRY(hipMemcpy2DAsync(flow_du, p->pitch_bytes, phi, p->pitch_bytes, p->width * sizeof(float), p->height,
                                         hipMemcpyDeviceToDevice, ctx->stream));
@@ -180,7 +212,7 @@ int flow2d_solve_level(flow2d_context* ctx, const float* frame_0, const float* f
                                         hipMemcpyDeviceToDevice, ctx->stream));
         source = 0;
     }
-    if (algorithm == FLOW2D_SOLVER_FUSED && source == 1) {
+    if (one_per_outer && source == 1) {
         std::swap(du, tdu);
         std::swap(dv, tdv);
     }
@@ -223,6 +255,7 @@ int flow2d_solve_level(flow2d_context* ctx, const float* frame_0, const float* f
         double per_px = 40.0;  // one Jacobi sweep
         if (algorithm == FLOW2D_SOLVER_FUSED)  // an outer iteration's bytes, spread over its launches
             per_px = (32.0 + 40.0 * p->inner_iterations_count) / static_cast<double>(std::max<size_t>(1, chunks));
+        if (algorithm == FLOW2D_SOLVER_TILED) per_px = 32.0 + 40.0 * p->inner_iterations_count;
         if (algorithm == FLOW2D_SOLVER_SINGLE_WORKGROUP)
             per_px = p->outer_iterations_count * (32.0 + 40.0 * p->inner_iterations_count);
         slot->rec.algorithmic_bytes_per_launch = per_px * static_cast<double>(p->width) * static_cast<double>(p->height);

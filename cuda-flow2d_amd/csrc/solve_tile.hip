@@ -1,0 +1,297 @@
+// One outer iteration of the variational solver on small LDS tiles: the kernel shape for the MID-SIZE and small
+// pyramid levels (64 x 33 ... about 1024 x 1024 pixels).
+//
+// The fused strip kernel (solve_fused.hip) gives a wave a 64-column strip and lets it walk down the image; a wave
+// issues one instruction every ~4 cycles whatever it is, so a launch lasts (rows + halo) x ~1.1 us however few strips
+// there are -- at 256 x 256 twelve microseconds for work that would occupy the chip's vector ALUs for half a
+// microsecond.  Here the same outer iteration (compute_phi_ksi + `inner` Jacobi sweeps, solve_2d.cu:43-377) is cut into
+// tiles of 8 x 8 or 16 x 16 pixels, one workgroup each with ONE THREAD PER PIXEL of the tile and its (inner + 1)-pixel
+// halo (20 x 20 or 28 x 28 threads' worth), so that even a 64 x 64 level spreads over 64 compute units: the region
+// lives in LDS, a pixel's coefficients in its thread's registers, and a sweep is one pass between two workgroup
+// barriers.  The halo is recomputed by every tile (6x / 3x the pixels of the tile itself in the first stage, shrinking
+// by one ring per stage), which is why the large levels stay with the strips (1.3x).
+//
+// Arithmetic: the solver_math.hpp expressions in the reference's order, no FMA contraction -- the same bits as the
+// per-sweep, fused and single-workgroup kernels and as the oracle.
+#include <cstdlib>
+
+#include "common.hpp"
+#include "solver_math.hpp"
+
+namespace {
+
+using namespace flow2d_math;
+
+constexpr int kMaxInner = 5;
+
+struct TileArgs {
+    const float* f0;
+    const float* f1;
+    const float* u;
+    const float* v;
+    const float* du;
+    const float* dv;
+    float* out_du;
+    float* out_dv;
+    int w, h, pitch;
+    int inner;
+    int zero_increment;  // first outer iteration of a level: du = dv = 0, the planes are not read
+    float hx, hy, alpha, e_smooth, e_data;
+};
+
+// GRAD: 0 brightness constancy (solve_2d), 1 gradient constancy with the reference's 16x8 block rule (solve_2d_grad),
+// 2 gradient constancy over true neighbours (FLOW2D_CONSTANCY_GRADIENT_UNTILED)
+template <int TX, int TY, int GRAD, int kThreads>
+__global__ __launch_bounds__(kThreads) void tile_outer_kernel(TileArgs a)
+{
+    constexpr int kHalo = kMaxInner + 1;
+    constexpr int RW = TX + 2 * kHalo, RH = TY + 2 * kHalo, RN = RW * RH;
+    constexpr int PPT = (RN + kThreads - 1) / kThreads;  // pixels per thread
+    constexpr int kPlanes = GRAD ? 10 : 7;
+    __shared__ float lds[kPlanes * RN];
+    float* const P_u = lds + 0 * RN;   // later: ping (u + du^k)
+    float* const P_v = lds + 1 * RN;   //        ping (v + dv^k)
+    float* const P_du = lds + 2 * RN;  // later: pong
+    float* const P_dv = lds + 3 * RN;
+    float* const P_f0 = lds + 4 * RN;
+    float* const P_f1 = lds + 5 * RN;
+    float* const P_phi = lds + 6 * RN;
+    float* const P_fx = lds + (GRAD ? 7 : 0) * RN;
+    float* const P_fy = lds + (GRAD ? 8 : 0) * RN;
+    float* const P_ft = lds + (GRAD ? 9 : 0) * RN;
+
+    const int w = a.w, h = a.h;
+    const int x_org = blockIdx.x * TX - kHalo, y_org = blockIdx.y * TY - kHalo;
+    // the launch may hold fewer sweeps than the halo was sized for: the valid rings are counted from the tile outwards
+    const int slack = kMaxInner - a.inner;
+
+    // ---- this thread's pixels: pixel j is region slot p = threadIdx.x + j * 256 -------------------------------------
+    // One word of facts per pixel instead of coordinates and neighbour slots in registers:
+    //   bit 0..3  left / right / up / down neighbour lies on the other side (reflect rule of solve_2d.cu:75-134 at the
+    //             image border; at the region's own edge too, which only keeps the access inside the region: such a
+    //             pixel is in ring 0 and never valid)
+    //   bit 4..7  the pixel is in image column 0 / w-1, row 0 / h-1      bit 8  inside the image
+    //   bit 16..  its ring (distance from the region's edge), less the rings this launch does not need
+    int facts[PPT];
+#pragma unroll
+    for (int j = 0; j < PPT; ++j) {
+        const int p = threadIdx.x + j * kThreads;
+        const int rx = p % RW, ry = p / RW;
+        const int gx = x_org + rx, gy = y_org + ry;
+        const bool inside = p < RN && gx >= 0 && gx < w && gy >= 0 && gy < h;
+        const int ring = max(min(min(rx, RW - 1 - rx), min(ry, RH - 1 - ry)) - slack, 0);
+        facts[j] = (gx == 0 || rx == 0 ? 1 : 0) | (gx == w - 1 || rx == RW - 1 ? 2 : 0) | (gy == 0 || ry == 0 ? 4 : 0) |
+                   (gy == h - 1 || ry == RH - 1 ? 8 : 0) | (gx == 0 ? 16 : 0) | (gx == w - 1 ? 32 : 0) | (gy == 0 ? 64 : 0) |
+                   (gy == h - 1 ? 128 : 0) | (inside ? 256 : 0) | (ring << 16);
+    }
+    auto slot = [&](int j) { return static_cast<int>(threadIdx.x) + j * kThreads; };
+    auto inside = [&](int j) { return (facts[j] & 256) != 0; };
+    auto ring_of = [&](int j) { return facts[j] >> 16; };
+    auto left_of = [&](int j) { return slot(j) + ((facts[j] & 1) ? 1 : -1); };
+    auto right_of = [&](int j) { return slot(j) + ((facts[j] & 2) ? -1 : 1); };
+    auto up_of = [&](int j) { return slot(j) + ((facts[j] & 4) ? RW : -RW); };
+    auto down_of = [&](int j) { return slot(j) + ((facts[j] & 8) ? -RW : RW); };
+    auto global_x = [&](int j) { return x_org + slot(j) % RW; };
+    auto global_y = [&](int j) { return y_org + slot(j) / RW; };
+
+    // ---- load ----------------------------------------------------------------------------------------------------
+    float uc[PPT], vc[PPT], dv_cur[PPT], du0[PPT];
+#pragma unroll
+    for (int j = 0; j < PPT; ++j) {
+        uc[j] = vc[j] = dv_cur[j] = du0[j] = 0.f;
+        if (inside(j)) {
+            const size_t o = static_cast<size_t>(global_y(j)) * a.pitch + global_x(j);
+            uc[j] = a.u[o];
+            vc[j] = a.v[o];
+            if (!a.zero_increment) {
+                du0[j] = a.du[o];
+                dv_cur[j] = a.dv[o];
+            }
+            P_u[slot(j)] = uc[j];
+            P_v[slot(j)] = vc[j];
+            P_du[slot(j)] = du0[j];
+            P_dv[slot(j)] = dv_cur[j];
+            P_f0[slot(j)] = a.f0[o];
+            P_f1[slot(j)] = a.f1[o];
+        }
+    }
+    __syncthreads();
+
+    // ---- stage A (rings >= 1): phi, brightness derivatives, ksi -- compute_phi_ksi, solve_2d.cu:138-197 ----------
+    float fx[PPT], fy[PPT], ft[PPT], ksi[PPT];
+#pragma unroll
+    for (int j = 0; j < PPT; ++j) {
+        fx[j] = fy[j] = ft[j] = ksi[j] = 0.f;
+        if (inside(j) && ring_of(j) >= 1) {
+            const int p = slot(j), nl = left_of(j), nr = right_of(j), nu = up_of(j), nd = down_of(j);
+            const float dux = diff4(P_u[nr], P_u[nl], P_du[nr], P_du[nl], 2.f * a.hx);
+            const float duy = diff4(P_u[nd], P_u[nu], P_du[nd], P_du[nu], 2.f * a.hy);
+            const float dvx = diff4(P_v[nr], P_v[nl], P_dv[nr], P_dv[nl], 2.f * a.hx);
+            const float dvy = diff4(P_v[nd], P_v[nu], P_dv[nd], P_dv[nu], 2.f * a.hy);
+            P_phi[p] = phi_value(dux, duy, dvx, dvy, a.e_smooth);
+            fx[j] = diff4(P_f0[nr], P_f0[nl], P_f1[nr], P_f1[nl], 4.f * a.hx);
+            fy[j] = diff4(P_f0[nd], P_f0[nu], P_f1[nd], P_f1[nu], 4.f * a.hy);
+            ft[j] = P_f1[p] - P_f0[p];
+            ksi[j] = ksi_value(fx[j], fy[j], ft[j], du0[j], dv_cur[j], a.e_data);
+            if (GRAD) {
+                P_fx[p] = fx[j];
+                P_fy[p] = fy[j];
+                P_ft[p] = ft[j];
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- stage B (rings >= 2): face weights, motion tensor, denominators; u + du, v + dv become visible -----------
+    const float hx_2 = a.alpha / (a.hx * a.hx);
+    const float hy_2 = a.alpha / (a.hy * a.hy);
+    float wxp[PPT], wxm[PPT], wyp[PPT], wym[PPT], den_u[PPT], den_v[PPT], J12[PPT], J13[PPT], J23[PPT];
+#pragma unroll
+    for (int j = 0; j < PPT; ++j) {
+        wxp[j] = wxm[j] = wyp[j] = wym[j] = J12[j] = J13[j] = J23[j] = 0.f;
+        den_u[j] = den_v[j] = 1.f;
+        if (inside(j) && ring_of(j) >= 2) {
+            const int p = slot(j), nl = left_of(j), nr = right_of(j), nu = up_of(j), nd = down_of(j);
+            const float xp = static_cast<float>((facts[j] & 32) == 0) * hx_2;   // x < w - 1
+            const float xm = static_cast<float>((facts[j] & 16) == 0) * hx_2;   // x > 0
+            const float yp = static_cast<float>((facts[j] & 128) == 0) * hy_2;  // y < h - 1
+            const float ym = static_cast<float>((facts[j] & 64) == 0) * hy_2;   // y > 0
+            const float pc = P_phi[p];
+            wxp[j] = face_phi(P_phi[nr], pc) * xp;
+            wxm[j] = face_phi(P_phi[nl], pc) * xm;
+            wyp[j] = face_phi(P_phi[nd], pc) * yp;
+            wym[j] = face_phi(P_phi[nu], pc) * ym;
+            const float sumH = sum_weights(wxp[j], wxm[j], wyp[j], wym[j]);
+            float J11, J22;
+            if (!GRAD) {
+                J11 = fx[j] * fx[j];
+                J22 = fy[j] * fy[j];
+                J12[j] = fx[j] * fy[j];
+                J13[j] = fx[j] * ft[j];
+                J23[j] = fy[j] * ft[j];
+            } else {
+                int xa, xb, ya, yb;  // slots of the second derivatives' neighbours
+                if (GRAD == 1) {     // own value at the reference's 16x8 block edge and at the image edge (:816-841,872-876)
+                    const int gx = global_x(j), gy = global_y(j);
+                    xa = ((gx & 15) == 0) ? p : p - 1;
+                    xb = ((gx & 15) == 15 || (facts[j] & 32)) ? p : p + 1;
+                    ya = ((gy & 7) == 0) ? p : p - RW;
+                    yb = ((gy & 7) == 7 || (facts[j] & 128)) ? p : p + RW;
+                } else {             // true neighbours, reflected at the image border
+                    xa = nl, xb = nr, ya = nu, yb = nd;
+                }
+                const float hx_1 = 1.0 / (2.0 * a.hx);  // double, rounded to float (solve_2d.cu:868-869)
+                const float hy_1 = 1.0 / (2.0 * a.hy);
+                const float fxx = (P_fx[xb] - P_fx[xa]) * hx_1;
+                const float fxy = (P_fx[yb] - P_fx[ya]) * hy_1;
+                const float fyy = (P_fy[yb] - P_fy[ya]) * hy_1;
+                const float fxt = (P_ft[xb] - P_ft[xa]) * hx_1;
+                const float fyt = (P_ft[yb] - P_ft[ya]) * hy_1;
+                gradient_tensor(fxx, fxy, fyy, fxt, fyt, J11, J22, J12[j], J13[j], J23[j]);
+            }
+            den_u[j] = update_denominator(ksi[j], J11, sumH);
+            den_v[j] = update_denominator(ksi[j], J22, sumH);
+        }
+        if (inside(j)) {  // every ring: the sweeps read these as neighbours (the planes of u, v are no longer needed as such)
+            P_u[slot(j)] = uc[j] + du0[j];
+            P_v[slot(j)] = vc[j] + dv_cur[j];
+        }
+    }
+    __syncthreads();
+
+    // ---- sweeps k = 1 .. inner (rings >= k + 1): solve_2d.cu:349-367; ping-pong between the two plane pairs --------
+    float* ping_u = P_u;
+    float* ping_v = P_v;
+    float* pong_u = P_du;
+    float* pong_v = P_dv;
+    float du_new[PPT];
+#pragma unroll
+    for (int j = 0; j < PPT; ++j) du_new[j] = 0.f;
+    for (int k = 1; k <= a.inner; ++k) {
+#pragma unroll
+        for (int j = 0; j < PPT; ++j) {
+            if (inside(j) && ring_of(j) >= k + 1) {
+                const int nl = left_of(j), nr = right_of(j), nu = up_of(j), nd = down_of(j);
+                const float sumU = sum_flux(wxp[j], wxm[j], wyp[j], wym[j], ping_u[nr], ping_u[nl], ping_u[nd],
+                                            ping_u[nu], uc[j]);
+                const float sumV = sum_flux(wxp[j], wxm[j], wyp[j], wym[j], ping_v[nr], ping_v[nl], ping_v[nd],
+                                            ping_v[nu], vc[j]);
+                float ndv;
+                point_update(ksi[j], den_u[j], den_v[j], J12[j], J13[j], J23[j], sumU, sumV, dv_cur[j], du_new[j], ndv);
+                dv_cur[j] = ndv;
+                pong_u[slot(j)] = uc[j] + du_new[j];
+                pong_v[slot(j)] = vc[j] + ndv;
+            }
+        }
+        __syncthreads();
+        float* t = ping_u;
+        ping_u = pong_u;
+        pong_u = t;
+        t = ping_v;
+        ping_v = pong_v;
+        pong_v = t;
+    }
+
+#pragma unroll
+    for (int j = 0; j < PPT; ++j) {
+        if (inside(j) && ring_of(j) >= a.inner + 1) {  // the tile itself
+            const size_t o = static_cast<size_t>(global_y(j)) * a.pitch + global_x(j);
+            a.out_du[o] = du_new[j];
+            a.out_dv[o] = dv_cur[j];
+        }
+    }
+}
+
+template <int TX, int TY, int kThreads>
+void launch_tiles(int grad, dim3 grid, hipStream_t stream, const TileArgs& a)
+{
+    if (grad == 1)
+        tile_outer_kernel<TX, TY, 1, kThreads><<<grid, kThreads, 0, stream>>>(a);
+    else if (grad == 2)
+        tile_outer_kernel<TX, TY, 2, kThreads><<<grid, kThreads, 0, stream>>>(a);
+    else
+        tile_outer_kernel<TX, TY, 0, kThreads><<<grid, kThreads, 0, stream>>>(a);
+}
+
+}  // namespace
+
+namespace flow2d {
+
+bool tiled_supports(int constancy, size_t inner)
+{
+    return inner >= 1 && inner <= kMaxInner &&
+           (constancy == FLOW2D_CONSTANCY_GREY || constancy == FLOW2D_CONSTANCY_GRADIENT ||
+            constancy == FLOW2D_CONSTANCY_GRADIENT_UNTILED);
+}
+
+// One outer iteration: reads du/dv (previous outer iteration, unless zero_increment), writes out_du/out_dv.
+int launch_tiled_outer(flow2d_context* ctx, int constancy, const float* f0, const float* f1, const float* u,
+                       const float* v, const float* du, const float* dv, size_t w, size_t h, size_t pitch_bytes, float hx,
+                       float hy, float alpha, float e_smooth, float e_data, size_t inner, float* out_du, float* out_dv,
+                       bool zero_increment)
+{
+    if (!tiled_supports(constancy, inner)) return FLOW2D_ERR_UNSUPPORTED;
+    TileArgs a{f0, f1, u, v, du, dv, out_du, out_dv, (int)w, (int)h, (int)(pitch_bytes / 4), (int)inner,
+               zero_increment ? 1 : 0, hx, hy, alpha, e_smooth, e_data};
+    const int grad = constancy == FLOW2D_CONSTANCY_GRADIENT ? 1 : (constancy == FLOW2D_CONSTANCY_GRADIENT_UNTILED ? 2 : 0);
+    // Tile size by level size (measured on MI355X, level solve of 10 x 5, Grey / Gradient, fused strips for comparison):
+    //   64^2   8x8: 0.052 / 0.055 ms   16x16: 0.061 / 0.064   strips 0.110 / 0.120
+    //   128^2  8x8: 0.054 / 0.058      16x16: 0.061 / 0.065   strips 0.110 / 0.126
+    //   256^2  8x8: 0.097 / 0.106      16x16: 0.068 / 0.072   strips 0.132 / 0.149
+    //   512^2  16x16: 0.169 / 0.181    32x16: 0.169 / 0.178   strips 0.196 / 0.217
+    //   1024^2 16x16: 0.60 / 0.63                             strips 0.37 / 0.40   (-> AUTO keeps the strips there)
+    // 8 x 8 tiles (one pixel per thread over the 20 x 20 region, 6x the tile's pixels) while that still spreads the
+    // level thinly; 16 x 16 (3x) above.
+    static const int variant = std::getenv("FLOW2D_TILE_VARIANT") ? std::atoi(std::getenv("FLOW2D_TILE_VARIANT")) : 0;  // developer knob
+    const bool tiny = w * h <= 160 * 160;
+    if (variant == 1 || (variant == 0 && tiny))
+        launch_tiles<8, 8, 512>(grad, dim3(div_up(w, 8), div_up(h, 8)), ctx->stream, a);
+    else if (variant == 3)
+        launch_tiles<32, 16, 1024>(grad, dim3(div_up(w, 32), div_up(h, 16)), ctx->stream, a);
+    else
+        launch_tiles<16, 16, 1024>(grad, dim3(div_up(w, 16), div_up(h, 16)), ctx->stream, a);
+    FLOW2D_CHECK_LAUNCH();
+    return FLOW2D_OK;
+}
+
+}  // namespace flow2d

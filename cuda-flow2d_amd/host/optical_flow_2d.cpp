@@ -68,7 +68,7 @@ bool OpticalFlow2D::InitMemory()
     size_t free_bytes = 0, total_bytes = 0;
     if (CheckFlow2DError(flow2d_mem_info(context_, &free_bytes, &total_bytes), "flow2d_mem_info")) return false;
     const size_t pitch = flow2d_plane_pitch_bytes(dev_container_size_.width);
-    const size_t needed = pitch * dev_container_size_.height * kContainersCount;
+    const size_t needed = pitch * dev_container_size_.height * (kContainersCount + 2);  // + the two packed x-pass planes
     if (!silent)
         std::printf("Available\t:\t%.0fMB / %.0fMB\nNeeded\t\t:\t%.0fMB\n", free_bytes / 1048576.f,
                     total_bytes / 1048576.f, needed / 1048576.f);
@@ -86,6 +86,18 @@ bool OpticalFlow2D::InitMemory()
         all_planes_.push_back(static_cast<DevicePtr>(reinterpret_cast<uintptr_t>(plane)));
     }
     free_planes_ = all_planes_;
+    for (DevicePtr& packed : packed_frames_) {  // outside the pool: they hold one pair's x-resampled rows of all levels
+        void* plane = nullptr;
+        size_t got_pitch = 0;
+        if (CheckFlow2DError(flow2d_plane_alloc(context_, dev_container_size_.width, dev_container_size_.height, &plane,
+                                                &got_pitch),
+                             "flow2d_plane_alloc") ||
+            got_pitch != pitch) {
+            std::printf("Error during device memory allocation.");
+            return false;
+        }
+        packed = static_cast<DevicePtr>(reinterpret_cast<uintptr_t>(plane));
+    }
     dev_container_size_.pitch = pitch;
     return true;
 }
@@ -122,6 +134,10 @@ void OpticalFlow2D::Destroy()
         if (free_planes_.size() != all_planes_.size())
             std::printf("Warning. Not all device memory allocations were freed.\n");
         for (DevicePtr p : all_planes_) flow2d_plane_free(context_, AsPlane(p));
+        for (DevicePtr& p : packed_frames_) {
+            if (p) flow2d_plane_free(context_, AsPlane(p));
+            p = 0;
+        }
     }
     all_planes_.clear();
     free_planes_.clear();
@@ -510,6 +526,34 @@ bool OpticalFlow2D::RunPyramid(OperationParameters& params)
         Release(temp);
     }
 
+    // The reference resamples both frames from FULL resolution at every level (optical_flow_2d.cpp:284-303): one read
+    // of each frame per level.  Here the x passes of all levels > 0 are one trip over the frames (every row read once,
+    // the x-resampled rows of all levels written side by side into a packed plane per frame; same cell sums, same
+    // bits); a level's y pass then reads its segment.  Used when the segments fit one row (scale factors up to ~0.5).
+    std::vector<size_t> packed_width, packed_column;
+    bool packed = false;
+    if (!sequence && level >= 2 && original_size.width <= 15360 && level <= FLOW2D_RESAMPLE_MAX_LEVELS) {
+        size_t column = 0;
+        for (int l = level; l >= 1; --l) {
+            const float s = std::pow(warp_scale_factor, static_cast<float>(l));
+            const size_t lw = static_cast<size_t>(std::ceil(original_size.width * s));
+            packed_width.push_back(lw);
+            packed_column.push_back(column);
+            column += (lw + 3) / 4 * 4;  // 16-byte aligned segments (what a plane pointer must be)
+        }
+        if (column <= dev_container_size_.pitch / sizeof(float)) {
+            packed = true;
+            if (CheckFlow2DError(flow2d_resample_x_levels(context_, AsPlane(frame_0), AsPlane(packed_frames_[0]),
+                                                          AsPlane(frame_1), AsPlane(packed_frames_[1]),
+                                                          original_size.width, original_size.height,
+                                                          dev_container_size_.pitch, packed_width.size(),
+                                                          packed_width.data(), packed_column.data()),
+                                 "flow2d_resample_x_levels"))
+                failed = true;
+        }
+    }
+    const int first_level = level;
+
     DataSize3 current_size = {0, 0, 0}, prev_size = {0, 0, 0};
     for (; level >= 0; --level) {
         const float scale = std::pow(warp_scale_factor, static_cast<float>(level));
@@ -550,6 +594,14 @@ bool OpticalFlow2D::RunPyramid(OperationParameters& params)
         } else if (level == 0) {
             std::swap(frame_0, frame_0_res);
             std::swap(frame_1, frame_1_res);
+        } else if (packed) {  // x pass done for all levels: this level's y pass, both frames in one launch
+            const size_t column = packed_column[static_cast<size_t>(first_level - level)];
+            if (CheckFlow2DError(flow2d_resample_y_pair(context_, AsPlane(packed_frames_[0]) + column, AsPlane(frame_0_res),
+                                                        AsPlane(packed_frames_[1]) + column, AsPlane(frame_1_res),
+                                                        current_size.width, current_size.height, original_size.height,
+                                                        dev_container_size_.pitch),
+                                 "flow2d_resample_y_pair"))
+                failed = true;
         } else {  // both frames of the level in one resample call (two planes per launch)
             DevicePtr temp = Acquire(), temp_b = Acquire();
             op.Clear();

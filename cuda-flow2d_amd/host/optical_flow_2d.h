@@ -115,6 +115,9 @@ private:
     std::vector<DevicePtr> all_planes_;
     std::vector<DevicePtr> free_planes_;
     DevicePtr dev_frame_0_ = 0, dev_frame_1_ = 0, dev_flow_u_ = 0, dev_flow_v_ = 0;  // valid inside a run
+    // Two planes beside the pool: the x-resampled rows of all pyramid levels of frame 0 / frame 1, side by side
+    // (flow2d_resample_x_levels: one read of each frame for the x passes of the whole pyramid)
+    DevicePtr packed_frames_[2] = {0, 0};
     // ComputeFlowDevice only: the caller's planes.  With a pre-blur the frames are read once (by the blur), so
     // they are read in place instead of copied; the last level's median writes the caller's flow planes.
     DevicePtr caller_frame_0_ = 0, caller_frame_1_ = 0, caller_flow_u_ = 0, caller_flow_v_ = 0;

@@ -174,6 +174,19 @@ FLOW2D_API int flow2d_resample_y_pair(flow2d_context* ctx, const float* input_a,
                                       const float* input_b, float* output_b, size_t out_width, size_t out_height,
                                       size_t in_height, size_t pitch_bytes);
 
+/* The x pass of resample_2d.cu:34-75 for SEVERAL output widths in one trip over the input.  The reference resamples
+ * both frames from full resolution at every pyramid level (optical_flow_2d.cpp:284-303), i.e. reads each frame once per
+ * level; here every input row is read once, kept in LDS, and the x-resampled rows of all `level_count` widths are written
+ * side by side into one "packed" plane: level l occupies columns [column_offsets[l], column_offsets[l] + out_widths[l])
+ * of every row (offsets in floats, multiples of 4, segments disjoint, all within the pitch).  Each output is the same
+ * left-to-right cell sum as flow2d_resample_x produces for that width (bit-identical).  The y pass of a level is then
+ * flow2d_resample_y on `packed + column_offsets[l]`.  input_b / packed_b: optional second plane (both or neither).
+ * Needs in_width <= 15360 (a row lives in LDS); FLOW2D_ERR_UNSUPPORTED beyond, or for more than 16 levels. */
+#define FLOW2D_RESAMPLE_MAX_LEVELS 16
+FLOW2D_API int flow2d_resample_x_levels(flow2d_context* ctx, const float* input_a, float* packed_a, const float* input_b,
+                                        float* packed_b, size_t in_width, size_t height, size_t pitch_bytes,
+                                        size_t level_count, const size_t* out_widths, const size_t* column_offsets);
+
 /* compute_phi_ksi (src/kernels/solve_2d.cu:43-198). */
 FLOW2D_API int flow2d_compute_phi_ksi(flow2d_context* ctx, const float* frame_0, const float* frame_1,
                                       const float* flow_u, const float* flow_v, const float* flow_du,
@@ -233,8 +246,11 @@ typedef enum flow2d_solver_algorithm {
     FLOW2D_SOLVER_PER_SWEEP = 1, /* one launch per reference kernel launch (K6, K7/K9/K11) */
     FLOW2D_SOLVER_FUSED = 2,     /* phi/ksi + the inner sweeps of an outer iteration fused into ceil(inner / 5)
                                   * launches (one for inner <= 5); needs inner >= 1 */
-    FLOW2D_SOLVER_SINGLE_WORKGROUP = 3 /* the whole level (all outer x inner iterations) in one launch on one
+    FLOW2D_SOLVER_SINGLE_WORKGROUP = 3, /* the whole level (all outer x inner iterations) in one launch on one
                                           CU; levels up to 64 x 64 pixels */
+    FLOW2D_SOLVER_TILED = 4      /* one launch per outer iteration like FUSED, on 16x16 / 32x16 LDS tiles with a halo:
+                                  * spreads small and mid-size levels over the whole chip; 1 <= inner <= 5; Grey,
+                                  * Gradient and Gradient-untiled data terms */
 } flow2d_solver_algorithm;
 
 typedef struct flow2d_solve_params {
@@ -254,12 +270,13 @@ typedef struct flow2d_solve_params {
                                     launches only; the result stays in flow_du / flow_dv). */
 } flow2d_solve_params;
 
-/* Which algorithm flow2d_solve_level runs for a request: `requested` resolved (AUTO -> one of the three), or -1 when the
+/* Which algorithm flow2d_solve_level runs for a request: `requested` resolved (AUTO -> one of the four), or -1 when the
  * requested algorithm cannot run the level (SINGLE_WORKGROUP above 64 x 64; FUSED without sweeps, or on planes of
- * 4 GiB and more, which its 32-bit buffer offsets cannot address -- AUTO takes the per-sweep kernels there).  Host
- * logic only, needs no device. */
+ * 4 GiB and more, which its 32-bit buffer offsets cannot address -- AUTO takes the per-sweep kernels there; TILED with
+ * more than 5 sweeps or the LogDerivatives term).  Host logic only, needs no device. */
 FLOW2D_API int flow2d_solver_algorithm_for(int requested, size_t width, size_t height, size_t pitch_bytes,
-                                           size_t outer_iterations_count, size_t inner_iterations_count);
+                                           size_t outer_iterations_count, size_t inner_iterations_count,
+                                           int data_constancy);
 
 FLOW2D_API int flow2d_solve_level(flow2d_context* ctx, const float* frame_0, const float* frame_1,
                                   const float* flow_u, const float* flow_v, float* flow_du, float* flow_dv,

@@ -70,6 +70,32 @@ def test_resample(ctx, oracle, w, h, ow, oh):
     assert np.array_equal(dst.download(ow, oh), want)
 
 
+@pytest.mark.parametrize("w,h,scale,levels", [(4096, 24, 0.5, 7), (1920, 17, 0.5, 7), (1000, 33, 0.45, 5), (257, 40, 0.3, 3),
+                                              (640, 12, 0.5, 2), (100, 70, 0.33, 3)])
+def test_resample_x_levels(ctx, flow2d, oracle, w, h, scale, levels):
+    """The x pass of all pyramid levels in one trip over the frame: every level's segment of the packed plane is
+    bit-identical to the single-level x pass (resample_2d.cu:34-75), for both planes of the launch."""
+    f0, f1, *_ = level_fields(oracle, w, h, 33)
+    widths = [int(np.ceil(np.float32(w) * np.float32(scale) ** np.float32(l))) for l in range(levels, 0, -1)]
+    columns, col = [], 0
+    for lw in widths:
+        columns.append(col)
+        col += (lw + 3) // 4 * 4
+    assert col <= ctx.plane(w, h).pitch // 4
+    a, b = up(ctx, f0, w, h), up(ctx, f1, w, h)
+    pa, pb = ctx.plane(w, h).fill_bytes(0x7f), ctx.plane(w, h).fill_bytes(0x7f)
+    ctx.resample_x_levels(a, pa, w, h, widths, columns, b, pb)
+    ga, gb = pa.download(), pb.download()
+    for lw, c in zip(widths, columns):
+        assert np.array_equal(ga[:, c:c + lw], oracle.resample_x(f0, lw, h, w)[:, :lw]), lw
+        assert np.array_equal(gb[:, c:c + lw], oracle.resample_x(f1, lw, h, w)[:, :lw]), lw
+    single = ctx.plane(w, h).fill_bytes(0x7f)  # one plane, one level
+    ctx.resample_x_levels(a, single, w, h, widths[:1], [0])
+    assert np.array_equal(single.download()[:, :widths[0]], oracle.resample_x(f0, widths[0], h, w)[:, :widths[0]])
+    with pytest.raises(flow2d.Flow2DError):  # overlapping segments
+        ctx.resample_x_levels(a, pa, w, h, widths[:2], [0, 0])
+
+
 @pytest.mark.parametrize("hx,hy", [(1.0, 1.0), (1.25, 1.1), (7.3, 5.5)])
 @pytest.mark.parametrize("w,h,cw,ch", SIZES)
 def test_registration(ctx, oracle, w, h, cw, ch, hx, hy):
@@ -182,7 +208,7 @@ def test_median_rejects_bad_window(ctx, flow2d, oracle):
     assert e.value.status == 1
 
 
-@pytest.mark.parametrize("algorithm", [1, 2, 0])
+@pytest.mark.parametrize("algorithm", [1, 2, 4, 0])
 @pytest.mark.parametrize("constancy", [0, 1, 2])  # 2 = gradient term over true neighbours (not in the reference)
 @pytest.mark.parametrize("outer,inner", [(2, 3), (3, 2), (1, 5), (2, 1), (1, 4)])
 @pytest.mark.parametrize("w,h,cw,ch", SIZES[:4] + [(300, 150, 320, 160), (52, 64, 64, 64), (53, 65, 64, 80), (640, 520, 640, 520)])
@@ -199,7 +225,7 @@ def test_solve_level(ctx, oracle, w, h, cw, ch, outer, inner, constancy, algorit
     # which pair holds the result: per-sweep = the reference's swap parity (cuda_operation_solve_2d.cpp:288-289),
     # fused = one swap per outer iteration; either way the library reports it
     single = algorithm == 0 and w <= 64 and h <= 32
-    fused = algorithm == 2 or (algorithm == 0 and not single and inner >= 2)
+    fused = algorithm in (2, 4) or (algorithm == 0 and not single and inner >= 2)  # one launch per outer iteration
     launches = 0 if single else (outer if fused else outer * inner)
     assert (rdu is tdu) == (launches % 2 == 1)
 
@@ -247,7 +273,7 @@ def test_solve_level_single_workgroup_rejects_large_levels(ctx, flow2d, oracle):
     assert e.value.status == 5
 
 
-@pytest.mark.parametrize("algorithm", [1, 2, 0])
+@pytest.mark.parametrize("algorithm", [1, 2, 4, 0])
 @pytest.mark.parametrize("case", ["zero frames", "constant frames", "alpha 0", "epsilon 0", "huge values"])
 def test_solve_level_degenerate_inputs(ctx, oracle, case, algorithm):
     """Flat images, vanishing regularisation or robustifier, overflowing intermediates: zeros, infinities and NaNs

@@ -108,7 +108,7 @@ def test_solver_kernels(ctx, flow2d, oracle, RK, w, h, cw, ch):
                 assert bits_equal(odu, rdu) and bits_equal(odv, rdv)
 
 
-@pytest.mark.parametrize("algorithm", [1, 2, 3, 0])
+@pytest.mark.parametrize("algorithm", [1, 2, 3, 4, 0])
 @pytest.mark.parametrize("constancy", [0, 1, 3])
 @pytest.mark.parametrize("outer,inner", [(2, 3), (3, 5), (1, 7)])
 @pytest.mark.parametrize("w,h,cw,ch", [(64, 32, 64, 32), (96, 64, 128, 64), (320, 160, 320, 160), (640, 264, 640, 264)])
@@ -117,6 +117,8 @@ def test_solve_level(ctx, flow2d, RK, oracle, w, h, cw, ch, outer, inner, consta
     against CudaOperationSolve2D::Execute over the reference's kernels."""
     if algorithm == 3 and (w > 64 or h > 64):
         pytest.skip("single-workgroup kernel: levels up to 64 x 64")
+    if algorithm == 4 and (constancy == flow2d.LOG_DERIVATIVES or inner > 5):
+        pytest.skip("tiled kernel: Grey / Gradient, up to 5 sweeps per launch")
     f0, f1, u, v, _, _ = level_fields(oracle, w, h, 53)
     hx, hy = np.float32(cw / w), np.float32(1.5)
     alpha = 3.5 if constancy != flow2d.LOG_DERIVATIVES else 0.001  # log derivatives are ~1/I of the grey ones

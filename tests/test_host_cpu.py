@@ -44,14 +44,20 @@ def test_c_abi_rejects_bad_arguments_without_a_device(flow2d):
 
 
 def test_solver_algorithm_selection_and_32bit_guard(flow2d):
-    """flow2d_solve_level's choice of algorithm, checked without a device: AUTO = one workgroup up to 64 x 32, the
-    fused kernel when there are >= 2 sweeps to fuse, per-sweep launches otherwise -- and whenever the plane reaches
+    """flow2d_solve_level's choice of algorithm, checked without a device: AUTO = one workgroup up to 64 x 32, LDS tiles
+    up to 640 x 640, the fused strip kernel above (when there are >= 2 sweeps to fuse), per-sweep launches
+    otherwise -- and whenever the plane reaches
     4 GiB, which the fused kernel's 32-bit buffer offsets cannot address (an explicit FUSED request is refused there
     instead of wrapping around)."""
-    pick = flow2d.hip_lib().flow2d_solver_algorithm_for
-    AUTO, SWEEP, FUSED, ONE = 0, 1, 2, 3
+    raw = flow2d.hip_lib().flow2d_solver_algorithm_for
+    pick = lambda req, w, h, pitch_bytes, outer, inner, constancy=0: raw(req, w, h, pitch_bytes, outer, inner, constancy)
+    AUTO, SWEEP, FUSED, ONE, TILED = 0, 1, 2, 3, 4
     pitch = lambda w: flow2d.hip_lib().flow2d_plane_pitch_bytes(w)
-    assert pick(AUTO, 64, 32, pitch(64), 10, 5) == ONE and pick(AUTO, 64, 33, pitch(64), 10, 5) == FUSED
+    assert pick(AUTO, 64, 32, pitch(64), 10, 5) == ONE and pick(AUTO, 64, 33, pitch(64), 10, 5) == TILED
+    assert pick(AUTO, 512, 512, pitch(512), 10, 5) == TILED and pick(AUTO, 512, 512, pitch(512), 10, 7) == FUSED
+    assert pick(AUTO, 1024, 1024, pitch(1024), 10, 5) == FUSED
+    assert pick(AUTO, 512, 512, pitch(512), 10, 5, flow2d.LOG_DERIVATIVES) == FUSED  # no tiled Log kernel
+    assert pick(TILED, 1024, 1024, pitch(1024), 10, 6) == -1 and pick(TILED, 4096, 4096, pitch(4096), 10, 5) == TILED
     assert pick(AUTO, 4096, 4096, pitch(4096), 10, 5) == FUSED and pick(AUTO, 4096, 4096, pitch(4096), 10, 1) == SWEEP
     assert pick(ONE, 65, 40, pitch(65), 1, 1) == -1 and pick(FUSED, 640, 480, pitch(640), 2, 0) == -1
     assert pick(FUSED, 640, 480, pitch(640), 0, 0) == FUSED and pick(7, 64, 64, 256, 1, 1) == -1
