@@ -13,6 +13,7 @@ def main():
     w = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
     h = int(sys.argv[2]) if len(sys.argv) > 2 else w
     algos = [int(a) for a in sys.argv[3].split(",")] if len(sys.argv) > 3 else [1]
+    inner = int(sys.argv[4]) if len(sys.argv) > 4 else 5
     ctx = F.Context(0)
     print(ctx.device_name(), ctx.mem_info())
     rng = np.random.default_rng(0)
@@ -23,13 +24,13 @@ def main():
             for rep in range(3):
                 e0, e1 = ctx.event(), ctx.event()
                 ctx.record(e0)
-                ctx.solve_level(*planes, du, dv, phi, ksi, tdu, tdv, w, h, 1.0, 1.0, 35.0, 0.001, 0.001, 10, 5,
+                ctx.solve_level(*planes, du, dv, phi, ksi, tdu, tdv, w, h, 1.0, 1.0, 35.0, 0.001, 0.001, 10, inner,
                                 constancy, algo)
                 ctx.record(e1)
                 ms = ctx.elapsed_ms(e0, e1)
-            bytes_ = w * h * 10 * (32 + 40 * 5)
+            bytes_ = w * h * 10 * (32 + 40 * inner)
             print("constancy %d algo %d: level solve %.3f ms -> %.1f Mpix-iters/s, %.2f TB/s algorithmic" %
-                  (constancy, algo, ms, w * h * 50 / ms / 1e3, bytes_ / ms / 1e9))
+                  (constancy, algo, ms, w * h * 10 * inner / ms / 1e3, bytes_ / ms / 1e9))
     ctx.close()
 
 
