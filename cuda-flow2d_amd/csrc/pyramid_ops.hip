@@ -334,11 +334,52 @@ __global__ __launch_bounds__(256) void resample_x_lds_kernel(const float* __rest
 // image row, stages it in LDS (one pad word per 32, so the lanes' strided cell walks are conflict-free for the
 // power-of-two ratios of a 0.5 pyramid) and produces every level's outputs from there.  Per output the cells are
 // accumulated left to right exactly as in resample_kernel<true> (resample_2d.cu:46-72): same bits.
+//
+// An output of a level `in_w / out_w` cells wide is one dependent chain of that many additions, so the deep levels of a
+// large frame (8192 -> 4: 2048 cells per output, 4 outputs per row) are all latency and no parallelism.  Levels at
+// least a workgroup wide are walked one after the other with every thread busy; ALL narrower levels are then walked
+// together, one output per thread, so the row's critical path is its longest chain instead of the sum of them
+// (8192^2, 12 levels, both frames: 3.7 ms -> see profiles/).  Inside a chain only the first and the last cell carry
+// a fraction other than 1 (resample_2d.cu:58-66), the others are plain additions with eight LDS reads in flight.
 struct ResampleLevels {
     int count;
     int out_w[FLOW2D_RESAMPLE_MAX_LEVELS];
     int col[FLOW2D_RESAMPLE_MAX_LEVELS];
 };
+
+__device__ __forceinline__ float resample_x_output_lds(const float* __restrict__ row, int in_w, int g, float delta,
+                                                       float normalization)
+{
+    const float left_f = static_cast<float>(static_cast<unsigned>(g)) * delta;
+    const float right_f = static_cast<float>(static_cast<unsigned>(g) + 1u) * delta;
+    const int left_i = static_cast<int>(floorf(left_f));
+    const int right_i = min(in_w, static_cast<int>(ceilf(right_f)));
+    const int cells = right_i - left_i;
+    auto cell = [&](int k) { return row[k + (k >> 5)]; };
+    float value = 0.f;
+    if (cells == 1) {
+        value += cell(left_i) * delta;
+    } else if (cells > 1) {
+        const int last = left_i + cells - 1;
+        value += cell(left_i) * (static_cast<float>(left_i + 1) - left_f);
+        int k = left_i + 1;
+        for (; k + 8 <= last; k += 8) {  // fraction 1: value += row[k] * 1.f is value += row[k]
+            const float c0 = cell(k), c1 = cell(k + 1), c2 = cell(k + 2), c3 = cell(k + 3);
+            const float c4 = cell(k + 4), c5 = cell(k + 5), c6 = cell(k + 6), c7 = cell(k + 7);
+            value += c0;
+            value += c1;
+            value += c2;
+            value += c3;
+            value += c4;
+            value += c5;
+            value += c6;
+            value += c7;
+        }
+        for (; k < last; ++k) value += cell(k);
+        value += cell(last) * (right_f - static_cast<float>(last));
+    }
+    return value * normalization;
+}
 
 __global__ __launch_bounds__(256) void resample_x_levels_kernel(const float* __restrict__ in_a, float* __restrict__ out_a,
                                                                 const float* __restrict__ in_b, float* __restrict__ out_b,
@@ -350,27 +391,34 @@ __global__ __launch_bounds__(256) void resample_x_levels_kernel(const float* __r
     const size_t line = static_cast<size_t>(blockIdx.x) * pitch;
     for (int i = threadIdx.x; i < in_w; i += 256) row[i + (i >> 5)] = in[line + i];
     __syncthreads();
+    // levels at least a workgroup wide: one after the other, all threads busy
+    int narrow_total = 0;
     for (int l = 0; l < lv.count; ++l) {
         const int out_w = lv.out_w[l];
+        if (out_w < 256) {
+            narrow_total += out_w;
+            continue;
+        }
         const float delta = static_cast<float>(in_w) / static_cast<float>(out_w);
         const float normalization = static_cast<float>(out_w) / static_cast<float>(in_w);
-        for (int g = threadIdx.x; g < out_w; g += 256) {
-            const float left_f = static_cast<float>(static_cast<unsigned>(g)) * delta;
-            const float right_f = static_cast<float>(static_cast<unsigned>(g) + 1u) * delta;
-            const int left_i = static_cast<int>(floorf(left_f));
-            const int right_i = min(in_w, static_cast<int>(ceilf(right_f)));
-            const int cells = right_i - left_i;
-            float value = 0.f;
-            for (int j = 0; j < cells; ++j) {
-                float frac = 1.f;
-                if (j == 0) frac = static_cast<float>(left_i + 1) - left_f;
-                if (j == cells - 1) frac = right_f - static_cast<float>(left_i + j);
-                if (cells == 1) frac = delta;
-                const int k = left_i + j;
-                value += row[k + (k >> 5)] * frac;
-            }
-            out[line + lv.col[l] + g] = value * normalization;
+        for (int g = threadIdx.x; g < out_w; g += 256)
+            out[line + lv.col[l] + g] = resample_x_output_lds(row, in_w, g, delta, normalization);
+    }
+    // all narrower levels together: item i of their concatenation -> (level, g)
+    for (int i = threadIdx.x; i < narrow_total; i += 256) {
+        int g = i, level = -1;
+        for (int l = 0; l < lv.count; ++l) {
+            const int out_w = lv.out_w[l];
+            if (out_w >= 256 || level >= 0) continue;
+            if (g < out_w)
+                level = l;
+            else
+                g -= out_w;
         }
+        const int out_w = lv.out_w[level];
+        const float delta = static_cast<float>(in_w) / static_cast<float>(out_w);
+        const float normalization = static_cast<float>(out_w) / static_cast<float>(in_w);
+        out[line + lv.col[level] + g] = resample_x_output_lds(row, in_w, g, delta, normalization);
     }
 }
 

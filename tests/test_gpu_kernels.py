@@ -70,7 +70,7 @@ def test_resample(ctx, oracle, w, h, ow, oh):
     assert np.array_equal(dst.download(ow, oh), want)
 
 
-@pytest.mark.parametrize("w,h,scale,levels", [(4096, 24, 0.5, 7), (1920, 17, 0.5, 7), (1000, 33, 0.45, 5), (257, 40, 0.3, 3),
+@pytest.mark.parametrize("w,h,scale,levels", [(8192, 5, 0.5, 11), (4096, 24, 0.5, 7), (1920, 17, 0.5, 7), (1000, 33, 0.45, 5), (257, 40, 0.3, 3),
                                               (640, 12, 0.5, 2), (100, 70, 0.33, 3)])
 def test_resample_x_levels(ctx, flow2d, oracle, w, h, scale, levels):
     """The x pass of all pyramid levels in one trip over the frame: every level's segment of the packed plane is
