@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""bench.py -- the measured hot path: OpticalFlow2D::ComputeFlowDevice (C++ host layer -> C-ABI -> HIP
+"""bench.py -- the measured hot path: OpticalFlowBatch2D / OpticalFlow2D::ComputeFlowDevice (C++ host layer -> C-ABI -> HIP
 kernels for gfx950) on synthetic translating-sinusoid pairs, with the roofline of the dominant solver
 kernel, the CPU oracle and (N = 1) the reference's own kernels timed beside it.
 
@@ -185,72 +185,77 @@ def sha(a):
 
 
 class Job:
-    """One workload on this rank: lanes = independent (stream, OpticalFlow2D, plane pool) triples.  A rank with
-    several pairs per step spreads them over up to 4 lanes so the launch-bound coarse levels of one pair overlap
-    another pair's work; with one pair per step, consecutive steps rotate over the lanes (every lane has a copy)."""
+    """One workload on this rank, run through the C++ batch entry (OpticalFlowBatch2D, host/optical_flow_batch_2d.cpp):
+    lanes = independent (stream, OpticalFlow2D, plane pool) triples.  A rank with several pairs per step hands them all
+    to one ComputeFlowBatchDevice call (pair k -> lane k mod lanes), so the launch-bound coarse levels of one pair
+    overlap another pair's work; with one pair per step, consecutive steps rotate over the lanes (every lane has its own
+    copy of the pair's planes)."""
 
     def __init__(self, flow2d, batch, workload, cfg, args, rank, local_rank, world, out_tensor=None):
         self.flow2d, self.batch, self.workload, self.cfg, self.args = flow2d, batch, workload, cfg, args
-        self.rank, self.world = rank, world
+        self.rank, self.world, self.local_rank = rank, world, local_rank
         w, h = cfg["w"], cfg["h"]
         self.single = cfg["pairs_per_rank"] == 1
         self.n_lanes = max(1, min(4, cfg["pairs_per_rank"] * args.pipeline))
-        self.lanes = []
-        for _ in range(self.n_lanes):
-            c = flow2d.Context(local_rank)
-            self.lanes.append({"ctx": c, "flow": flow2d.OpticalFlow(w, h, cfg["constancy"], ctx=c), "pairs": []})
-        self.flow = self.lanes[0]["flow"]
+        self.runner = flow2d.OpticalFlowBatch(w, h, cfg["constancy"], lanes=self.n_lanes, device=local_rank)
+        self.ctx = flow2d.Context(local_rank)  # plane allocation, uploads, downloads (created after the lanes' streams)
+        self.runner.use_graph(not args.no_graph)
         # rank 0's parameter block on every rank (RCCL broadcast; SURVEY 8e), then the same solve everywhere
         block = batch.broadcast_params([cfg["levels"], cfg["scale"], cfg["outer"], cfg["inner"], cfg["alpha"], 0.001,
                                         0.001, cfg["median"], cfg["sigma"], args.algorithm])
-        self.params = self.flow.params(int(block[0]), block[1], int(block[2]), int(block[3]), block[4], block[5],
-                                       block[6], int(block[7]), block[8], int(block[9]))
+        self.params = self.runner.params(int(block[0]), block[1], int(block[2]), int(block[3]), block[4], block[5],
+                                         block[6], int(block[7]), block[8], int(block[9]))
         # this rank's pairs, resident in HBM before any timed region; pair k -> rank k mod world (SURVEY 8e)
         self.owned = batch.pairs_of_rank(cfg["pairs_per_rank"] * world, rank, world)
         self.first_pair = None
+        self.sets = []  # (frame 0, frame 1, u, v, global pair index); single-pair workloads: one copy per lane
+        c = self.ctx
         for n, gk in enumerate(self.owned):
             dx, dy = pair_shift(workload, cfg, gk)
             f0, f1 = synthetic_pair(w, h, dx, dy)
             if self.first_pair is None:
                 self.first_pair = (f0, f1)
-            targets = self.lanes if self.single else [self.lanes[n % self.n_lanes]]
-            for lane in targets:
-                c = lane["ctx"]
+            for _ in range(self.n_lanes if self.single else 1):
                 if out_tensor is not None:  # flow fields written straight into the gather buffer
-                    assert out_tensor.shape[-1] * 4 == lane["flow"].pitch
-                    pu = _Borrowed(c, out_tensor[n, 0].data_ptr(), lane["flow"].pitch, w, h)
-                    pv = _Borrowed(c, out_tensor[n, 1].data_ptr(), lane["flow"].pitch, w, h)
+                    assert out_tensor.shape[-1] * 4 == self.runner.pitch
+                    pu = _Borrowed(c, out_tensor[n, 0].data_ptr(), self.runner.pitch, w, h)
+                    pv = _Borrowed(c, out_tensor[n, 1].data_ptr(), self.runner.pitch, w, h)
                 else:
                     pu, pv = c.plane(w, h), c.plane(w, h)
-                lane["pairs"].append((c.plane(w, h, f0), c.plane(w, h, f1), pu, pv, gk))
+                self.sets.append((c.plane(w, h, f0), c.plane(w, h, f1), pu, pv, gk))
+        c.synchronize()
 
     def sync(self):
-        for lane in self.lanes:
-            lane["ctx"].synchronize()
+        self.runner.synchronize()
+        self.ctx.synchronize()
 
-    def step(self, index, eager=False, timing=0, only_lane=None):
-        """One pass over this rank's pairs (replayed from recorded HIP graphs unless eager)."""
-        active = [self.lanes[index % self.n_lanes]] if self.single else self.lanes
-        if only_lane is not None:
-            active = [self.lanes[only_lane]]
-        for lane in active:
-            lane["flow"].use_graph(not eager and not self.args.no_graph)
-        for k in range(max(len(l["pairs"]) for l in active)):
-            for lane in active:
-                if k < len(lane["pairs"]):
-                    pf0, pf1, pu, pv, _ = lane["pairs"][k]
-                    lane["flow"].compute_flow_device(pf0.ptr, pf1.ptr, pu.ptr, pv.ptr, self.params, timing)
+    def _queue(self, sets, first_lane):
+        cols = [[q[i].ptr for q in sets] for i in range(4)]
+        self.runner.compute_flow_batch_device(*cols, self.params, first_lane=first_lane)
+
+    def step(self, index):
+        """One pass over this rank's pairs: ONE call into the C++ batch entry (replayed HIP graphs unless --no-graph)."""
+        if self.single:
+            lane = index % self.n_lanes
+            self._queue([self.sets[lane]], lane)
+        else:
+            self._queue(self.sets, 0)
+
+    def eager_pass(self):
+        """Every plane set once, launched eagerly (no graph): the recomputation the output check compares with."""
+        self.runner.use_graph(False)
+        self._queue(self.sets, 0)
+        self.sync()
+        self.runner.use_graph(not self.args.no_graph)
 
     def digests(self):
-        """{(lane, pair index): (sha(u), sha(v))} of what is in HBM now."""
+        """{(set index, pair index): (sha(u), sha(v))} of what is in HBM now."""
         self.sync()
-        return {(li, gk): (sha(pu.download()), sha(pv.download()))
-                for li, lane in enumerate(self.lanes) for (_, _, pu, pv, gk) in lane["pairs"]}
+        return {(si, gk): (sha(pu.download()), sha(pv.download())) for si, (_, _, pu, pv, gk) in enumerate(self.sets)}
 
     def close(self):
-        for lane in self.lanes:
-            lane["flow"].close()
-            lane["ctx"].close()
+        self.runner.close()
+        self.ctx.close()
 
 
 class _Borrowed:
@@ -269,7 +274,7 @@ def timed_region(job, batch, torch, steps, warmup):
         job.sync()
         torch.cuda.synchronize()
 
-    for k in range(max(warmup, 1) * job.n_lanes):
+    for k in range(max(warmup, 1) * (job.n_lanes if job.single else 1)):
         job.step(k)  # also records the graphs of every lane
     barrier()
     t0 = time.perf_counter()
@@ -282,8 +287,7 @@ def timed_region(job, batch, torch, steps, warmup):
 def output_check(job):
     """The timed steps' results against an eager recomputation; single-pair workloads: all streams agree."""
     replayed = job.digests()
-    for li in range(job.n_lanes):
-        job.step(0, eager=True, only_lane=li)
+    job.eager_pass()
     eager = job.digests()
     lanes_identical = True
     if job.single:
@@ -298,15 +302,24 @@ def output_check(job):
 
 
 def roofline_sample(job, passes=3):
-    """Eager passes on stream 0, alone on the GPU, with HIP events on that stream around every level's solve
-    and every finest-level solver launch (flow2d_timing_enable mode 2)."""
+    """Eager passes of the first pair on a stream of its own, alone on the GPU, with HIP events on that stream around
+    every level's solve and every finest-level solver launch (flow2d_timing_enable mode 2)."""
+    flow2d, cfg = job.flow2d, job.cfg
+    w, h = cfg["w"], cfg["h"]
     job.sync()
-    job.flow.reset_timings()
-    for _ in range(passes):
-        job.step(0, eager=True, timing=2, only_lane=0)
-    job.sync()
-    w, h = job.cfg["w"], job.cfg["h"]
-    return [r for r in job.flow.level_timings() if (r[0], r[1]) == (w, h)]
+    c = flow2d.Context(job.local_rank)
+    flow = flow2d.OpticalFlow(w, h, cfg["constancy"], ctx=c)
+    try:
+        f0, f1 = (c.plane(w, h, a) for a in job.first_pair)
+        u, v = c.plane(w, h), c.plane(w, h)
+        flow.reset_timings()
+        for _ in range(passes):
+            flow.compute_flow_device(f0.ptr, f1.ptr, u.ptr, v.ptr, job.params, 2)
+        c.synchronize()
+        return [r for r in flow.level_timings() if (r[0], r[1]) == (w, h)]
+    finally:
+        flow.close()
+        c.close()
 
 
 def batch_leg(flow2d, batch, torch, args, rank, local_rank, world):
@@ -390,13 +403,13 @@ def main():
 
     w, h = cfg["w"], cfg["h"]
     job = Job(flow2d, batch, args.workload, cfg, args, rank, local_rank, world)
-    free_b, total_b = job.lanes[0]["ctx"].mem_info()
+    free_b, total_b = job.ctx.mem_info()
     elapsed = timed_region(job, batch, torch, args.steps, args.warmup)   # <- the number
     check = output_check(job)
     finest = roofline_sample(job)
     first_pair = job.first_pair
     n_lanes = job.n_lanes
-    levels_run = int(min(cfg["levels"], job.flow.max_warp_level(w, h, cfg["scale"])))
+    levels_run = int(min(cfg["levels"], flow2d.host_lib().flow2d_host_max_warp_level_static(w, h, cfg["scale"])))
     job.close()
 
     batch_result = None
@@ -467,6 +480,7 @@ def main():
                 "gaussian_sigma": cfg["sigma"], "alpha": cfg["alpha"], "solver_algorithm": algorithm_used,
                 "relaxation": "Jacobi, reference iteration counts (bit-exact parity mode)",
                 "parallelism": "independent pairs, one process per GPU, no data-path collective",
+                "host_path": "OpticalFlowBatch2D::ComputeFlowBatchDevice (C++): one call per step",
                 "streams_per_gpu": n_lanes, "hip_graph_replay": not args.no_graph,
                 "timed_region": "graph-replayed steps only; output check, roofline sample, batch leg and baselines follow it",
             },

@@ -430,6 +430,19 @@ def host_lib():
         L.flow2d_host_operator_name.argtypes = [vp]
         L.flow2d_host_operator_execute.argtypes = [vp, C.POINTER(C.c_char_p), C.POINTER(vp), sz]
         L.flow2d_host_operator_destroy.argtypes = [vp]
+        L.flow2d_host_batch_create.restype = vp
+        L.flow2d_host_batch_create.argtypes = [sz, sz, i, sz, i]
+        L.flow2d_host_batch_destroy.argtypes = [vp]
+        L.flow2d_host_batch_pitch.restype = sz
+        L.flow2d_host_batch_pitch.argtypes = [vp]
+        L.flow2d_host_batch_lanes.restype = sz
+        L.flow2d_host_batch_lanes.argtypes = [vp]
+        L.flow2d_host_batch_lane_context.restype = vp
+        L.flow2d_host_batch_lane_context.argtypes = [vp, sz]
+        L.flow2d_host_batch_use_graph.argtypes = [vp, i]
+        L.flow2d_host_batch_compute.argtypes = [vp, sz, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp),
+                                                C.POINTER(HostParams), sz]
+        L.flow2d_host_batch_synchronize.argtypes = [vp]
         _host = L
     return _host
 
@@ -524,6 +537,45 @@ class OpticalFlow:
             self.handle = None
             if self._adopted:  # the caller owns (and may now destroy) the adopted context
                 host_lib().flow2d_host_adopt_context(None)
+
+
+class OpticalFlowBatch:
+    """OpticalFlowBatch2D of the host layer: independent pairs spread over `lanes` (stream + OpticalFlow2D + plane
+    pool each) on one GPU; pair k of a call runs on lane (first_lane + k) mod lanes.  The scheduling is C++; this
+    class only marshals device addresses."""
+
+    def __init__(self, width, height, constancy=GREY, lanes=4, device=0):
+        L = host_lib()
+        self.width, self.height = width, height
+        self.handle = L.flow2d_host_batch_create(width, height, _HOST_CONSTANCY[constancy], lanes, device)
+        if not self.handle:
+            raise Flow2DError(1, "OpticalFlowBatch2D::Initialize")
+        self.pitch = L.flow2d_host_batch_pitch(self.handle)
+        self.lanes = L.flow2d_host_batch_lanes(self.handle)
+
+    params = staticmethod(OpticalFlow.params)
+
+    def use_graph(self, on=True):
+        host_lib().flow2d_host_batch_use_graph(self.handle, int(on))
+
+    def compute_flow_batch_device(self, dev_f0s, dev_f1s, dev_us, dev_vs, params, first_lane=0):
+        """Raw device addresses of pitched containers, one entry per pair; queued, not synchronised."""
+        n = len(dev_f0s)
+        if not (len(dev_f1s) == len(dev_us) == len(dev_vs) == n):
+            raise ValueError("one frame 0, frame 1, u and v plane per pair")
+        arrays = [(C.c_void_p * n)(*a) for a in (dev_f0s, dev_f1s, dev_us, dev_vs)]
+        rc = host_lib().flow2d_host_batch_compute(self.handle, n, *arrays, C.byref(params), first_lane)
+        if rc:
+            raise Flow2DError(rc, "OpticalFlowBatch2D::ComputeFlowBatchDevice")
+
+    def synchronize(self):
+        if host_lib().flow2d_host_batch_synchronize(self.handle) != 0:
+            raise Flow2DError(2, "OpticalFlowBatch2D::Synchronize")
+
+    def close(self):
+        if self.handle:
+            host_lib().flow2d_host_batch_destroy(self.handle)
+            self.handle = None
 
 
 def read_raw(path, width, height, u8):

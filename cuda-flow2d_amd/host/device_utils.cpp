@@ -51,6 +51,18 @@ void DestroyDeviceContext()
     g_owned = false;
 }
 
+ScopedDeviceContext::ScopedDeviceContext(flow2d_context* ctx) : previous_(g_context), previous_owned_(g_owned)
+{
+    g_context = ctx;
+    g_owned = false;
+}
+
+ScopedDeviceContext::~ScopedDeviceContext()
+{
+    g_context = previous_;
+    g_owned = previous_owned_;
+}
+
 bool CopyData2DtoDevice(Data2D& data, DevicePtr device_ptr, size_t device_height, size_t device_pitch)
 {
     if (!g_context || data.Height() > device_height || data.Width() * sizeof(float) > device_pitch) return false;

@@ -17,6 +17,19 @@ bool InitDeviceContext(int device_ordinal = 0);
 void AdoptDeviceContext(flow2d_context* ctx);
 flow2d_context* CurrentDeviceContext();
 void DestroyDeviceContext();
+// Makes `ctx` the process-wide context for the guard's lifetime and then puts the previous one back, ownership
+// included (OpticalFlowBatch2D: each lane's objects bind to the lane's own context when they are initialised).
+class ScopedDeviceContext {
+public:
+    explicit ScopedDeviceContext(flow2d_context* ctx);
+    ~ScopedDeviceContext();
+    ScopedDeviceContext(const ScopedDeviceContext&) = delete;
+    ScopedDeviceContext& operator=(const ScopedDeviceContext&) = delete;
+
+private:
+    flow2d_context* previous_;
+    bool previous_owned_;
+};
 
 // Prints "flow2d error = ..." and returns true when `status` is an error (same polarity as the
 // reference's CheckCudaError).

@@ -8,6 +8,7 @@
 #include "device_utils.h"
 #include "io_utils.h"
 #include "optical_flow_2d.h"
+#include "optical_flow_batch_2d.h"
 #include "settings.h"
 
 #define HOST_API extern "C" __attribute__((visibility("default")))
@@ -147,6 +148,63 @@ HOST_API int flow2d_host_compute_flow_sequence_device(flow2d_host_flow* h, void*
     }
     return h->flow.ComputeFlowSequenceDevice(frames.data(), frame_count, us.data(), vs.data(), bag) ? 0 : 2;
 }
+
+// ---- OpticalFlowBatch2D: pairs spread over lanes (stream + OpticalFlow2D + plane pool each) on one GPU -----------
+struct flow2d_host_batch {
+    OpticalFlowBatch2D batch;
+};
+
+HOST_API flow2d_host_batch* flow2d_host_batch_create(size_t width, size_t height, int constancy, size_t lanes, int device)
+{
+    flow2d_host_batch* h = new (std::nothrow) flow2d_host_batch();
+    if (!h) return nullptr;
+    DataSize3 size = {width, height, 1};
+    if (!h->batch.Initialize(size, static_cast<DataConstancy>(constancy), lanes, device)) {
+        delete h;
+        return nullptr;
+    }
+    return h;
+}
+
+HOST_API void flow2d_host_batch_destroy(flow2d_host_batch* h)
+{
+    if (!h) return;
+    h->batch.Destroy();
+    delete h;
+}
+
+HOST_API size_t flow2d_host_batch_pitch(flow2d_host_batch* h) { return h ? h->batch.ContainerSize().pitch : 0; }
+HOST_API size_t flow2d_host_batch_lanes(flow2d_host_batch* h) { return h ? h->batch.Lanes() : 0; }
+HOST_API flow2d_context* flow2d_host_batch_lane_context(flow2d_host_batch* h, size_t lane)
+{
+    return h ? h->batch.LaneContext(lane) : nullptr;
+}
+HOST_API void flow2d_host_batch_use_graph(flow2d_host_batch* h, int on)
+{
+    if (h) h->batch.use_graph = on != 0;
+}
+
+// OpticalFlowBatch2D::ComputeFlowBatchDevice: `count` pairs, pair k on lane (first_lane + k) mod lanes.  0 on success.
+HOST_API int flow2d_host_batch_compute(flow2d_host_batch* h, size_t count, void* const* dev_frames_0,
+                                       void* const* dev_frames_1, void* const* dev_flows_u, void* const* dev_flows_v,
+                                       const flow2d_host_params* params, size_t first_lane)
+{
+    if (!h || !params || (count && (!dev_frames_0 || !dev_frames_1 || !dev_flows_u || !dev_flows_v))) return 1;
+    flow2d_host_params p = *params;
+    OperationParameters bag;
+    FillBag(bag, p);
+    auto dp = [](void* q) { return static_cast<DevicePtr>(reinterpret_cast<uintptr_t>(q)); };
+    std::vector<DevicePtr> f0(count), f1(count), u(count), v(count);
+    for (size_t k = 0; k < count; ++k) {
+        f0[k] = dp(dev_frames_0[k]);
+        f1[k] = dp(dev_frames_1[k]);
+        u[k] = dp(dev_flows_u[k]);
+        v[k] = dp(dev_flows_v[k]);
+    }
+    return h->batch.ComputeFlowBatchDevice(count, f0.data(), f1.data(), u.data(), v.data(), bag, first_lane) ? 0 : 2;
+}
+
+HOST_API int flow2d_host_batch_synchronize(flow2d_host_batch* h) { return (h && h->batch.Synchronize()) ? 0 : 1; }
 
 // Per-level solve records of the last run (needs timing_mode >= 1 and a synchronised context).
 // Writes up to `capacity` records of 6 floats (width, height, solve_ms, kernel_ms, kernel_launches,

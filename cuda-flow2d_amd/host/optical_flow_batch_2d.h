@@ -1,0 +1,56 @@
+// Independent image pairs on one GPU, several in flight: the host side of the batched path (the
+// reference has no counterpart -- it holds one context and blocks the host after every sweep,
+// src/utils/cuda_utils.cpp:43, cuda_operation_solve_2d.cpp:291).
+//
+// A pair's pyramid is a chain of several hundred dependent launches whose coarse levels cannot fill the chip, so
+// pairs are spread over `lanes` independent (HIP stream, OpticalFlow2D, plane pool) triples: pair k of a call goes to
+// lane (first_lane + k) mod lanes, the calls of consecutive pairs are issued round-robin over the lanes so that one
+// pair's launch-bound coarse levels overlap another pair's fine levels, and with use_graph every (lane, buffers,
+// parameters) combination is recorded once as a HIP graph and replayed (one host call per pair).  Nothing is
+// synchronised until Synchronize().  Every pair's flow is bit-identical to OpticalFlow2D::ComputeFlowDevice on that
+// pair alone: the lanes share nothing but the device.
+//
+// Create the batch object BEFORE any other stream of the process: the HIP runtime deals streams onto its (four)
+// hardware queues in creation order, and a lane that shares a queue with another lane waits behind it (measured:
+// 205 instead of 224 pairs/s at 4096^2 with one idle stream created ahead of four lanes).
+#pragma once
+
+#include <cstddef>
+#include <memory>
+#include <vector>
+
+#include "optical_flow_2d.h"
+
+class OpticalFlowBatch2D {
+public:
+    OpticalFlowBatch2D();
+    ~OpticalFlowBatch2D();
+
+    // `lanes` contexts (one stream each) on `device`, each with an OpticalFlow2D of `data_size` and its plane pool
+    // (12 + 2 planes per lane).  false when the device, a stream or the memory is not to be had.
+    bool Initialize(const DataSize3& data_size, DataConstancy data_constancy, size_t lanes, int device = 0);
+
+    // `count` pairs already in pitched device containers of ContainerSize() (any allocation of this device):
+    // dev_frames_*[k] are read, dev_flows_*[k] written.  Queued, not synchronised.  false on a bad argument or when
+    // a pair's run was refused (the other pairs are still queued).
+    bool ComputeFlowBatchDevice(size_t count, const DevicePtr* dev_frames_0, const DevicePtr* dev_frames_1,
+                                const DevicePtr* dev_flows_u, const DevicePtr* dev_flows_v, OperationParameters& params,
+                                size_t first_lane = 0);
+
+    bool Synchronize();  // waits for every lane's stream
+    void Destroy();
+
+    bool use_graph = true;
+    bool silent = true;
+
+    size_t Lanes() const { return lanes_.size(); }
+    DataSize3 ContainerSize() const;
+    flow2d_context* LaneContext(size_t lane) const;
+
+private:
+    struct Lane {
+        flow2d_context* context = nullptr;
+        OpticalFlow2D flow;
+    };
+    std::vector<std::unique_ptr<Lane>> lanes_;
+};

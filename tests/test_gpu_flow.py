@@ -237,42 +237,75 @@ def test_config4_frame_size_parity(flow2d, oracle, make_flow):
 
 
 def test_config4_batch_on_four_streams_with_graph_replay(flow2d, oracle):
-    """Config 4 the way bench.py runs it: 8 distinct 1920 x 1080 pairs on 4 streams (2 per stream), every stream
-    with its own OpticalFlow2D replaying recorded HIP graphs, all in flight together.  Every pair of the second,
-    replayed round is bit-identical to the oracle."""
+    """Config 4 the way bench.py runs it: 8 distinct 1920 x 1080 pairs through OpticalFlowBatch2D (the C++ batch entry)
+    on 4 lanes -- 2 pairs per lane, every lane with its own stream and OpticalFlow2D replaying recorded HIP graphs,
+    all in flight together.  Every pair of the third, replayed round is bit-identical to the oracle."""
     w, h = 1920, 1080
     p = (8, 0.5, 10, 5, 35.0, 0.001, 0.001, 5, 1.5)
     pairs = [oracle.synthetic_pair(w, h, 2.0 * np.cos(k), 2.0 * np.sin(k)) for k in range(8)]
-    lanes = []
+    c = flow2d.Context(0)
+    batch = flow2d.OpticalFlowBatch(w, h, flow2d.GREY, lanes=4)
     try:
-        for li in range(4):
-            c = flow2d.Context(0)
-            f = flow2d.OpticalFlow(w, h, 0, ctx=c)
-            f.use_graph(True)
-            planes = [(c.plane(w, h, pairs[k][0]), c.plane(w, h, pairs[k][1]), c.plane(w, h).fill_bytes(0x7f),
-                       c.plane(w, h).fill_bytes(0x7f), k) for k in range(li, 8, 4)]
-            lanes.append((c, f, planes))
-        params = lanes[0][1].params(*p)
-        for rnd in range(3):  # round 0 records, rounds 1 and 2 replay
+        assert batch.lanes == 4 and batch.pitch == c.plane(w, h).pitch
+        planes = [(c.plane(w, h, f0), c.plane(w, h, f1), c.plane(w, h).fill_bytes(0x7f), c.plane(w, h).fill_bytes(0x7f))
+                  for f0, f1 in pairs]
+        columns = [[q[i].ptr for q in planes] for i in range(4)]
+        params = batch.params(*p)
+        for rnd in range(3):  # round 0 records the graphs, rounds 1 and 2 replay them
             if rnd == 2:
-                for c, _, planes in lanes:
-                    for _, _, pu, pv, _ in planes:
-                        pu.fill_bytes(0x7f)
-                        pv.fill_bytes(0x7f)
-            for i in range(2):
-                for c, f, planes in lanes:
-                    pf0, pf1, pu, pv, _ = planes[i]
-                    f.compute_flow_device(pf0.ptr, pf1.ptr, pu.ptr, pv.ptr, params)
-        for c, _, _ in lanes:
-            c.synchronize()
-        for c, f, planes in lanes:
-            for _, _, pu, pv, k in planes:
-                ou, ov, _ = oracle.compute_flow(pairs[k][0], pairs[k][1], *p)
-                assert np.array_equal(pu.download(), ou) and np.array_equal(pv.download(), ov), "pair %d" % k
+                batch.synchronize()
+                for _, _, pu, pv in planes:
+                    pu.fill_bytes(0x7f)
+                    pv.fill_bytes(0x7f)
+                c.synchronize()
+            batch.compute_flow_batch_device(*columns, params)
+        batch.synchronize()
+        for k, (_, _, pu, pv) in enumerate(planes):
+            ou, ov, _ = oracle.compute_flow(pairs[k][0], pairs[k][1], *p)
+            assert np.array_equal(pu.download(), ou) and np.array_equal(pv.download(), ov), "pair %d" % k
     finally:
-        for c, f, _ in lanes:
-            f.close()
-            c.close()
+        batch.close()
+        c.close()
+
+
+@pytest.mark.parametrize("constancy", [0, 1])
+def test_batch_entry_uneven_pairs_and_lane_offsets(flow2d, oracle, constancy):
+    """OpticalFlowBatch2D: 5 pairs on 3 lanes (uneven), eager and graph-replayed, then the same pairs one call at a
+    time with a rotating first lane: every flow equals the oracle, whichever lane and mode produced it."""
+    w, h = 208, 144
+    p = (4, 0.5, 3, 5, 35.0, 0.001, 0.001, 5, 1.5)
+    pairs = [oracle.synthetic_pair(w, h, 1.5 * np.cos(k), -1.0 + 0.5 * k, seed=k, noise=True) for k in range(5)]
+    want = [oracle.compute_flow(f0, f1, *p, constancy)[:2] for f0, f1 in pairs]
+    c = flow2d.Context(0)
+    batch = flow2d.OpticalFlowBatch(w, h, constancy, lanes=3)
+    try:
+        planes = [(c.plane(w, h, f0), c.plane(w, h, f1), c.plane(w, h), c.plane(w, h)) for f0, f1 in pairs]
+        columns = [[q[i].ptr for q in planes] for i in range(4)]
+        params = batch.params(*p)
+
+        def check(tag):
+            batch.synchronize()
+            for k, (_, _, pu, pv) in enumerate(planes):
+                assert np.array_equal(pu.download(), want[k][0]) and np.array_equal(pv.download(), want[k][1]), (tag, k)
+                pu.fill_bytes(0x7f)
+                pv.fill_bytes(0x7f)
+            c.synchronize()
+
+        batch.use_graph(False)
+        batch.compute_flow_batch_device(*columns, params)
+        check("eager")
+        batch.use_graph(True)
+        for rnd in range(2):  # record, replay
+            batch.compute_flow_batch_device(*columns, params)
+            check("graph round %d" % rnd)
+        for k in range(5):  # one pair per call, lanes 2, 0, 1, 2, 0
+            batch.compute_flow_batch_device(*[[col[k]] for col in columns], params, first_lane=2 + k)
+        check("single-pair calls")
+        with pytest.raises(ValueError):
+            batch.compute_flow_batch_device(columns[0], columns[1][:-1], columns[2], columns[3], params)
+    finally:
+        batch.close()
+        c.close()
 
 
 def test_config5_full_size_parity(flow2d, oracle, make_flow):
