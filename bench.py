@@ -42,6 +42,11 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+# The HIP runtime deals a process's streams onto GPU_MAX_HW_QUEUES (default 4) hardware queues; RCCL's own stream
+# (created by the process group before the four lanes exist) would make two lanes share a queue: 205 instead of 224
+# pairs/s under torch.distributed.run.  Eight queues leave every lane its own.  Must be set before HIP initialises.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
 SIMDS = 256 * 4            # CUs x SIMDs per CU
 CLOCK_HZ = 2.4e9           # max shader clock

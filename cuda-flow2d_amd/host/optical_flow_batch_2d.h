@@ -10,9 +10,10 @@
 // synchronised until Synchronize().  Every pair's flow is bit-identical to OpticalFlow2D::ComputeFlowDevice on that
 // pair alone: the lanes share nothing but the device.
 //
-// Create the batch object BEFORE any other stream of the process: the HIP runtime deals streams onto its (four)
-// hardware queues in creation order, and a lane that shares a queue with another lane waits behind it (measured:
-// 205 instead of 224 pairs/s at 4096^2 with one idle stream created ahead of four lanes).
+// Every lane needs a hardware queue of its own: the HIP runtime deals a process's streams onto GPU_MAX_HW_QUEUES
+// (default 4) queues, and a lane that shares a queue waits behind its neighbour (measured at 4096^2, four lanes:
+// 205 instead of 224 pairs/s when one more stream -- an idle one, or RCCL's -- exists in the process).  Either create
+// the batch object before any other stream, or start the process with GPU_MAX_HW_QUEUES=8 (bench.py does).
 #pragma once
 
 #include <cstddef>
