@@ -201,7 +201,7 @@ class Job:
         self.rank, self.world, self.local_rank = rank, world, local_rank
         w, h = cfg["w"], cfg["h"]
         self.single = cfg["pairs_per_rank"] == 1
-        self.n_lanes = max(1, min(4, cfg["pairs_per_rank"] * args.pipeline))
+        self.n_lanes = max(1, min(args.max_lanes, cfg["pairs_per_rank"] * args.pipeline))
         self.runner = flow2d.OpticalFlowBatch(w, h, cfg["constancy"], lanes=self.n_lanes, device=local_rank)
         self.ctx = flow2d.Context(local_rank)  # plane allocation, uploads, downloads (created after the lanes' streams)
         self.runner.use_graph(not args.no_graph)
@@ -378,6 +378,7 @@ def main():
     ap.add_argument("--pipeline", type=int, default=4,
                     help="independent pairs in flight per GPU when a step holds a single pair: consecutive steps go to "
                          "alternating streams so one pair's launch-bound coarse levels overlap the next pair's fine levels")
+    ap.add_argument("--max-lanes", type=int, default=4, help="upper bound on the lanes (streams) per GPU")
     args = ap.parse_args()
     cfg = WORKLOADS[args.workload]
 

@@ -1,15 +1,15 @@
 // One outer iteration of the variational solver on small LDS tiles: the kernel shape for the MID-SIZE and small
-// pyramid levels (64 x 33 ... about 1024 x 1024 pixels).
+// pyramid levels (64 x 33 ... 736 x 736 pixels).
 //
 // The fused strip kernel (solve_fused.hip) gives a wave a 64-column strip and lets it walk down the image; a wave
 // issues one instruction every ~4 cycles whatever it is, so a launch lasts (rows + halo) x ~1.1 us however few strips
 // there are -- at 256 x 256 twelve microseconds for work that would occupy the chip's vector ALUs for half a
 // microsecond.  Here the same outer iteration (compute_phi_ksi + `inner` Jacobi sweeps, solve_2d.cu:43-377) is cut into
-// tiles of 8 x 8 or 16 x 16 pixels, one workgroup each with ONE THREAD PER PIXEL of the tile and its (inner + 1)-pixel
-// halo (20 x 20 or 28 x 28 threads' worth), so that even a 64 x 64 level spreads over 64 compute units: the region
-// lives in LDS, a pixel's coefficients in its thread's registers, and a sweep is one pass between two workgroup
-// barriers.  The halo is recomputed by every tile (6x / 3x the pixels of the tile itself in the first stage, shrinking
-// by one ring per stage), which is why the large levels stay with the strips (1.3x).
+// tiles of 8 x 8, 16 x 16 or 32 x 32 pixels, one workgroup each with one thread per pixel (32 x 32: per two pixels) of
+// the tile and its (inner + 1)-pixel halo (20 x 20, 28 x 28 or 44 x 44 pixels), so that even a 64 x 64 level spreads over
+// 64 compute units: the region lives in LDS, a pixel's coefficients in its thread's registers, and a sweep is one pass
+// between two workgroup barriers.  The halo is recomputed by every tile (6x / 3x / 1.9x the pixels of the tile itself
+// in the first stage, shrinking by one ring per stage), which is why the large levels stay with the strips (1.3x).
 //
 // Arithmetic: the solver_math.hpp expressions in the reference's order, no FMA contraction -- the same bits as the
 // per-sweep, fused and single-workgroup kernels and as the oracle.
@@ -41,8 +41,10 @@ struct TileArgs {
 
 // GRAD: 0 brightness constancy (solve_2d), 1 gradient constancy with the reference's 16x8 block rule (solve_2d_grad),
 // 2 gradient constancy over true neighbours (FLOW2D_CONSTANCY_GRADIENT_UNTILED)
+// (two workgroups of up to 1024 threads per CU: at most 64 VGPRs, so that one tile's barriers and LDS round trips
+// hide behind the other's arithmetic)
 template <int TX, int TY, int GRAD, int kThreads>
-__global__ __launch_bounds__(kThreads) void tile_outer_kernel(TileArgs a)
+__global__ __launch_bounds__(kThreads, 8) void tile_outer_kernel(TileArgs a)
 {
     constexpr int kHalo = kMaxInner + 1;
     constexpr int RW = TX + 2 * kHalo, RH = TY + 2 * kHalo, RN = RW * RH;
@@ -274,22 +276,27 @@ int launch_tiled_outer(flow2d_context* ctx, int constancy, const float* f0, cons
     TileArgs a{f0, f1, u, v, du, dv, out_du, out_dv, (int)w, (int)h, (int)(pitch_bytes / 4), (int)inner,
                zero_increment ? 1 : 0, hx, hy, alpha, e_smooth, e_data};
     const int grad = constancy == FLOW2D_CONSTANCY_GRADIENT ? 1 : (constancy == FLOW2D_CONSTANCY_GRADIENT_UNTILED ? 2 : 0);
-    // Tile size by level size (measured on MI355X, level solve of 10 x 5, Grey / Gradient, fused strips for comparison):
-    //   64^2   8x8: 0.052 / 0.055 ms   16x16: 0.061 / 0.064   strips 0.110 / 0.120
-    //   128^2  8x8: 0.054 / 0.058      16x16: 0.061 / 0.065   strips 0.110 / 0.126
-    //   256^2  8x8: 0.097 / 0.106      16x16: 0.068 / 0.072   strips 0.132 / 0.149
-    //   512^2  16x16: 0.169 / 0.181    32x16: 0.169 / 0.178   strips 0.196 / 0.217
-    //   1024^2 16x16: 0.60 / 0.63                             strips 0.37 / 0.40   (-> AUTO keeps the strips there)
+    // Tile size by level size (measured on MI355X, level solve of 10 x 5, Grey / Gradient, ms; fused strips for comparison):
+    //            8x8            16x16          32x32          strips
+    //   64^2     0.052 / 0.055  0.061 / 0.064                 0.110 / 0.120
+    //   256^2    0.096 / 0.104  0.068 / 0.071  0.110 / 0.118  0.128 / 0.149
+    //   384^2    0.176 / 0.193  0.128 / 0.137  0.119 / 0.128  0.169 / 0.162
+    //   512^2    0.277 / 0.315  0.171 / 0.184  0.127 / 0.139  0.195 / 0.217
+    //   640^2    0.406 / 0.453  0.255 / 0.290  0.212 / 0.232  0.244 / 0.270
+    //   800^2                   0.361 / 0.406  0.292 / 0.317  0.284 / 0.312
+    //   1024^2                  0.558 / 0.627  0.384 / 0.419  0.372 / 0.405   (-> AUTO keeps the strips from 736^2 on)
     // 8 x 8 tiles (one pixel per thread over the 20 x 20 region, 6x the tile's pixels) while that still spreads the
-    // level thinly; 16 x 16 (3x) above.
+    // level thinly; 16 x 16 (28 x 28 region, 3x) up to 352^2; 32 x 32 (44 x 44 region, two pixels per thread, 1.9x)
+    // above: fewer, larger workgroups, two of them per CU (64 VGPRs), so one tile's barriers hide behind the other's
+    // arithmetic.
     static const int variant = std::getenv("FLOW2D_TILE_VARIANT") ? std::atoi(std::getenv("FLOW2D_TILE_VARIANT")) : 0;  // developer knob
-    const bool tiny = w * h <= 160 * 160;
+    const bool tiny = w * h <= 160 * 160, mid = w * h <= 352 * 352;
     if (variant == 1 || (variant == 0 && tiny))
         launch_tiles<8, 8, 512>(grad, dim3(div_up(w, 8), div_up(h, 8)), ctx->stream, a);
-    else if (variant == 3)
-        launch_tiles<32, 16, 1024>(grad, dim3(div_up(w, 32), div_up(h, 16)), ctx->stream, a);
-    else
+    else if (variant == 2 || (variant == 0 && mid))
         launch_tiles<16, 16, 1024>(grad, dim3(div_up(w, 16), div_up(h, 16)), ctx->stream, a);
+    else
+        launch_tiles<32, 32, 1024>(grad, dim3(div_up(w, 32), div_up(h, 32)), ctx->stream, a);
     FLOW2D_CHECK_LAUNCH();
     return FLOW2D_OK;
 }

@@ -211,7 +211,8 @@ def test_median_rejects_bad_window(ctx, flow2d, oracle):
 @pytest.mark.parametrize("algorithm", [1, 2, 4, 0])
 @pytest.mark.parametrize("constancy", [0, 1, 2])  # 2 = gradient term over true neighbours (not in the reference)
 @pytest.mark.parametrize("outer,inner", [(2, 3), (3, 2), (1, 5), (2, 1), (1, 4)])
-@pytest.mark.parametrize("w,h,cw,ch", SIZES[:4] + [(300, 150, 320, 160), (52, 64, 64, 64), (53, 65, 64, 80), (640, 520, 640, 520)])
+@pytest.mark.parametrize("w,h,cw,ch", SIZES[:4] + [(300, 150, 320, 160), (52, 64, 64, 64), (53, 65, 64, 80), (640, 520, 640, 520),
+                                     (401, 333, 416, 340)])
 def test_solve_level(ctx, oracle, w, h, cw, ch, outer, inner, constancy, algorithm):
     f0, f1, u, v, _, _ = level_fields(oracle, w, h, 7)
     hx, hy = np.float32(cw / w), np.float32(ch / h)
