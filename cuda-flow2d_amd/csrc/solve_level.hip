@@ -62,7 +62,7 @@ hipError_t mark(flow2d_context* ctx, flow2d_timing_slot* slot)
 // largest level (pixels) AUTO gives to the tiled kernel; FLOW2D_TILED_MAX_PIXELS overrides (developer knob)
 static const size_t kTiledMaxPixels = std::getenv("FLOW2D_TILED_MAX_PIXELS")
                                           ? static_cast<size_t>(std::atoll(std::getenv("FLOW2D_TILED_MAX_PIXELS")))
-                                          : static_cast<size_t>(736) * 736;
+                                          : static_cast<size_t>(896) * 896;
 
 extern "C" {
 
@@ -80,10 +80,10 @@ int flow2d_solver_algorithm_for(int requested, size_t width, size_t height, size
         // and above 512^2 it wins by 1.7-2.9x.  A single sweep per outer iteration leaves nothing to fuse, and a
         // plane of 4 GiB or more is beyond the fused kernel's 32-bit buffer offsets: both take the per-sweep kernels.
         if (flow2d::small_level_supports(width, height) && height <= 32) return FLOW2D_SOLVER_SINGLE_WORKGROUP;
-        // Up to kTiledMaxPixels (736 x 736) the outer iteration runs on small LDS tiles (solve_tile.hip): a strip wave
+        // Up to kTiledMaxPixels (896 x 896) the outer iteration runs on small LDS tiles (solve_tile.hip): a strip wave
         // needs (rows + halo) x ~1.1 us whatever the level size, tiles spread a small level over the whole chip
-        // (level solve 10 x 5 at 256^2: 0.07 against 0.13 ms, at 512^2 0.13 against 0.20, at 640^2 0.21 against 0.24;
-        // from 800^2 on the strips win).
+        // (level solve 10 x 5 at 256^2: 0.07 against 0.13 ms, at 512^2 0.12 against 0.20, at 800^2 0.27 against 0.29;
+        // at 1024^2 the strips win for the gradient term).
         if (inner >= 2 && width * height <= kTiledMaxPixels && flow2d::tiled_supports(data_constancy, inner))
             return FLOW2D_SOLVER_TILED;
         return (inner >= 2 && flow2d::fused_addressable(height, pitch_bytes)) ? FLOW2D_SOLVER_FUSED : FLOW2D_SOLVER_PER_SWEEP;

@@ -1,5 +1,5 @@
 // One outer iteration of the variational solver on small LDS tiles: the kernel shape for the MID-SIZE and small
-// pyramid levels (64 x 33 ... 736 x 736 pixels).
+// pyramid levels (64 x 33 ... 896 x 896 pixels).
 //
 // The fused strip kernel (solve_fused.hip) gives a wave a 64-column strip and lets it walk down the image; a wave
 // issues one instruction every ~4 cycles whatever it is, so a launch lasts (rows + halo) x ~1.1 us however few strips
@@ -13,6 +13,7 @@
 //
 // Arithmetic: the solver_math.hpp expressions in the reference's order, no FMA contraction -- the same bits as the
 // per-sweep, fused and single-workgroup kernels and as the oracle.
+#include <cmath>
 #include <cstdlib>
 
 #include "common.hpp"
@@ -43,7 +44,9 @@ struct TileArgs {
 // 2 gradient constancy over true neighbours (FLOW2D_CONSTANCY_GRADIENT_UNTILED)
 // (two workgroups of up to 1024 threads per CU: at most 64 VGPRs, so that one tile's barriers and LDS round trips
 // hide behind the other's arithmetic)
-template <int TX, int TY, int GRAD, int kThreads>
+// POW2: 2h and 4h are powers of two (every level of a 0.5 pyramid), so the six divisions by them in compute_phi_ksi
+// are exact multiplies by the reciprocal (solver_math.hpp, div_spacing).
+template <int TX, int TY, int GRAD, int kThreads, bool POW2>
 __global__ __launch_bounds__(kThreads, 8) void tile_outer_kernel(TileArgs a)
 {
     constexpr int kHalo = kMaxInner + 1;
@@ -126,13 +129,13 @@ __global__ __launch_bounds__(kThreads, 8) void tile_outer_kernel(TileArgs a)
         fx[j] = fy[j] = ft[j] = ksi[j] = 0.f;
         if (inside(j) && ring_of(j) >= 1) {
             const int p = slot(j), nl = left_of(j), nr = right_of(j), nu = up_of(j), nd = down_of(j);
-            const float dux = diff4(P_u[nr], P_u[nl], P_du[nr], P_du[nl], 2.f * a.hx);
-            const float duy = diff4(P_u[nd], P_u[nu], P_du[nd], P_du[nu], 2.f * a.hy);
-            const float dvx = diff4(P_v[nr], P_v[nl], P_dv[nr], P_dv[nl], 2.f * a.hx);
-            const float dvy = diff4(P_v[nd], P_v[nu], P_dv[nd], P_dv[nu], 2.f * a.hy);
+            const float dux = diff4s<POW2>(P_u[nr], P_u[nl], P_du[nr], P_du[nl], 2.f * a.hx, 1.f / (2.f * a.hx));
+            const float duy = diff4s<POW2>(P_u[nd], P_u[nu], P_du[nd], P_du[nu], 2.f * a.hy, 1.f / (2.f * a.hy));
+            const float dvx = diff4s<POW2>(P_v[nr], P_v[nl], P_dv[nr], P_dv[nl], 2.f * a.hx, 1.f / (2.f * a.hx));
+            const float dvy = diff4s<POW2>(P_v[nd], P_v[nu], P_dv[nd], P_dv[nu], 2.f * a.hy, 1.f / (2.f * a.hy));
             P_phi[p] = phi_value(dux, duy, dvx, dvy, a.e_smooth);
-            fx[j] = diff4(P_f0[nr], P_f0[nl], P_f1[nr], P_f1[nl], 4.f * a.hx);
-            fy[j] = diff4(P_f0[nd], P_f0[nu], P_f1[nd], P_f1[nu], 4.f * a.hy);
+            fx[j] = diff4s<POW2>(P_f0[nr], P_f0[nl], P_f1[nr], P_f1[nl], 4.f * a.hx, 1.f / (4.f * a.hx));
+            fy[j] = diff4s<POW2>(P_f0[nd], P_f0[nu], P_f1[nd], P_f1[nu], 4.f * a.hy, 1.f / (4.f * a.hy));
             ft[j] = P_f1[p] - P_f0[p];
             ksi[j] = ksi_value(fx[j], fy[j], ft[j], du0[j], dv_cur[j], a.e_data);
             if (GRAD) {
@@ -244,15 +247,31 @@ __global__ __launch_bounds__(kThreads, 8) void tile_outer_kernel(TileArgs a)
     }
 }
 
+template <int TX, int TY, int kThreads, bool POW2>
+void launch_tiles_pow2(int grad, dim3 grid, hipStream_t stream, const TileArgs& a)
+{
+    if (grad == 1)
+        tile_outer_kernel<TX, TY, 1, kThreads, POW2><<<grid, kThreads, 0, stream>>>(a);
+    else if (grad == 2)
+        tile_outer_kernel<TX, TY, 2, kThreads, POW2><<<grid, kThreads, 0, stream>>>(a);
+    else
+        tile_outer_kernel<TX, TY, 0, kThreads, POW2><<<grid, kThreads, 0, stream>>>(a);
+}
+
+// true when x is a normal power of two whose reciprocal (and 1/(2x), 1/(4x)) is exactly representable
+bool is_power_of_two(float x)
+{
+    int e = 0;
+    return x > 0.f && std::frexp(x, &e) == 0.5f && e > -100 && e < 100;
+}
+
 template <int TX, int TY, int kThreads>
 void launch_tiles(int grad, dim3 grid, hipStream_t stream, const TileArgs& a)
 {
-    if (grad == 1)
-        tile_outer_kernel<TX, TY, 1, kThreads><<<grid, kThreads, 0, stream>>>(a);
-    else if (grad == 2)
-        tile_outer_kernel<TX, TY, 2, kThreads><<<grid, kThreads, 0, stream>>>(a);
+    if (is_power_of_two(a.hx) && is_power_of_two(a.hy))
+        launch_tiles_pow2<TX, TY, kThreads, true>(grad, grid, stream, a);
     else
-        tile_outer_kernel<TX, TY, 0, kThreads><<<grid, kThreads, 0, stream>>>(a);
+        launch_tiles_pow2<TX, TY, kThreads, false>(grad, grid, stream, a);
 }
 
 }  // namespace
@@ -281,10 +300,12 @@ int launch_tiled_outer(flow2d_context* ctx, int constancy, const float* f0, cons
     //   64^2     0.052 / 0.055  0.061 / 0.064                 0.110 / 0.120
     //   256^2    0.096 / 0.104  0.068 / 0.071  0.110 / 0.118  0.128 / 0.149
     //   384^2    0.176 / 0.193  0.128 / 0.137  0.119 / 0.128  0.169 / 0.162
-    //   512^2    0.277 / 0.315  0.171 / 0.184  0.127 / 0.139  0.195 / 0.217
-    //   640^2    0.406 / 0.453  0.255 / 0.290  0.212 / 0.232  0.244 / 0.270
-    //   800^2                   0.361 / 0.406  0.292 / 0.317  0.284 / 0.312
-    //   1024^2                  0.558 / 0.627  0.384 / 0.419  0.372 / 0.405   (-> AUTO keeps the strips from 736^2 on)
+    //   512^2    0.268 / 0.297  0.167 / 0.180  0.120 / 0.132  0.199 / 0.217
+    //   640^2    0.392 / 0.451  0.247 / 0.273  0.198 / 0.223  0.246 / 0.270
+    //   800^2                   0.350 / 0.387  0.272 / 0.298  0.287 / 0.311
+    //   1024^2                  0.531 / 0.594  0.356 / 0.422  0.375 / 0.407   (-> AUTO keeps the strips from 896^2 on)
+    // (h = 1, i.e. the power-of-two spacing of a 0.5 pyramid; an interior-tile variant without the border facts was
+    // measured too: 32 x 32 +3 %, not kept)
     // 8 x 8 tiles (one pixel per thread over the 20 x 20 region, 6x the tile's pixels) while that still spreads the
     // level thinly; 16 x 16 (28 x 28 region, 3x) up to 352^2; 32 x 32 (44 x 44 region, two pixels per thread, 1.9x)
     // above: fewer, larger workgroups, two of them per CU (64 VGPRs), so one tile's barriers hide behind the other's

@@ -45,7 +45,7 @@ def test_c_abi_rejects_bad_arguments_without_a_device(flow2d):
 
 def test_solver_algorithm_selection_and_32bit_guard(flow2d):
     """flow2d_solve_level's choice of algorithm, checked without a device: AUTO = one workgroup up to 64 x 32, LDS tiles
-    up to 736 x 736, the fused strip kernel above (when there are >= 2 sweeps to fuse), per-sweep launches
+    up to 896 x 896, the fused strip kernel above (when there are >= 2 sweeps to fuse), per-sweep launches
     otherwise -- and whenever the plane reaches
     4 GiB, which the fused kernel's 32-bit buffer offsets cannot address (an explicit FUSED request is refused there
     instead of wrapping around)."""
@@ -55,7 +55,7 @@ def test_solver_algorithm_selection_and_32bit_guard(flow2d):
     pitch = lambda w: flow2d.hip_lib().flow2d_plane_pitch_bytes(w)
     assert pick(AUTO, 64, 32, pitch(64), 10, 5) == ONE and pick(AUTO, 64, 33, pitch(64), 10, 5) == TILED
     assert pick(AUTO, 512, 512, pitch(512), 10, 5) == TILED and pick(AUTO, 512, 512, pitch(512), 10, 7) == FUSED
-    assert pick(AUTO, 736, 736, pitch(736), 10, 5) == TILED and pick(AUTO, 737, 736, pitch(737), 10, 5) == FUSED
+    assert pick(AUTO, 896, 896, pitch(896), 10, 5) == TILED and pick(AUTO, 897, 896, pitch(897), 10, 5) == FUSED
     assert pick(AUTO, 1024, 1024, pitch(1024), 10, 5) == FUSED
     assert pick(AUTO, 512, 512, pitch(512), 10, 5, flow2d.LOG_DERIVATIVES) == FUSED  # no tiled Log kernel
     assert pick(TILED, 1024, 1024, pitch(1024), 10, 6) == -1 and pick(TILED, 4096, 4096, pitch(4096), 10, 5) == TILED
