@@ -73,19 +73,20 @@ int flow2d_solver_algorithm_for(int requested, size_t width, size_t height, size
 {
     if (requested < FLOW2D_SOLVER_AUTO || requested > FLOW2D_SOLVER_TILED) return -1;
     if (requested == FLOW2D_SOLVER_AUTO) {
-        // Up to 64 x 32 the whole level runs in one launch on one CU (solve_small.hip; measured 0.06-0.10 ms
-        // against 0.16-0.19 ms for 60 per-sweep launches; at 64 x 64 four pixels per thread spill and lose).
-        // Everything else goes through the fused kernel: since its strip start-up is peeled it also wins on the
-        // launch-bound levels (10 launches of ~15 us instead of 60 of ~4 us: 0.15 against 0.21 ms at 64^2 .. 256^2),
-        // and above 512^2 it wins by 1.7-2.9x.  A single sweep per outer iteration leaves nothing to fuse, and a
-        // plane of 4 GiB or more is beyond the fused kernel's 32-bit buffer offsets: both take the per-sweep kernels.
-        if (flow2d::small_level_supports(width, height) && height <= 32) return FLOW2D_SOLVER_SINGLE_WORKGROUP;
         // Up to kTiledMaxPixels (896 x 896) the outer iteration runs on small LDS tiles (solve_tile.hip): a strip wave
         // needs (rows + halo) x ~1.1 us whatever the level size, tiles spread a small level over the whole chip
         // (level solve 10 x 5 at 256^2: 0.07 against 0.13 ms, at 512^2 0.12 against 0.20, at 800^2 0.27 against 0.29;
-        // at 1024^2 the strips win for the gradient term).
+        // at 1024^2 the strips win for the gradient term).  That includes the coarsest levels: ten launches of a few
+        // 8 x 8 tiles take 0.05 ms at 16 x 16 ... 64 x 32, the single-workgroup kernel 0.06 ... 0.11 ms.
         if (inner >= 2 && width * height <= kTiledMaxPixels && flow2d::tiled_supports(data_constancy, inner))
             return FLOW2D_SOLVER_TILED;
+        // Where the tiled kernel does not apply (solve_2d_log, a single sweep per outer iteration), levels up to 64 x 32
+        // run whole in one launch on one CU (solve_small.hip; 0.06-0.10 ms against 0.16-0.19 ms for 60 per-sweep launches;
+        // at 64 x 64 four pixels per thread spill and lose).
+        if (flow2d::small_level_supports(width, height) && height <= 32) return FLOW2D_SOLVER_SINGLE_WORKGROUP;
+        // Everything else goes through the fused strip kernel (above 512^2 it wins over per-sweep launches by 1.7-2.9x).
+        // A single sweep per outer iteration leaves nothing to fuse, and a plane of 4 GiB or more is beyond the fused
+        // kernel's 32-bit buffer offsets: both take the per-sweep kernels.
         return (inner >= 2 && flow2d::fused_addressable(height, pitch_bytes)) ? FLOW2D_SOLVER_FUSED : FLOW2D_SOLVER_PER_SWEEP;
     }
     if (requested == FLOW2D_SOLVER_TILED && !flow2d::tiled_supports(data_constancy, inner)) return -1;

@@ -225,7 +225,7 @@ def test_solve_level(ctx, oracle, w, h, cw, ch, outer, inner, constancy, algorit
     assert np.array_equal(rdv.download(w, h), odv)
     # which pair holds the result: per-sweep = the reference's swap parity (cuda_operation_solve_2d.cpp:288-289),
     # fused = one swap per outer iteration; either way the library reports it
-    single = algorithm == 0 and w <= 64 and h <= 32
+    single = algorithm == 0 and w <= 64 and h <= 32 and inner < 2  # AUTO: tiles whenever there are sweeps to fuse
     fused = algorithm in (2, 4) or (algorithm == 0 and not single and inner >= 2)  # one launch per outer iteration
     launches = 0 if single else (outer if fused else outer * inner)
     assert (rdu is tdu) == (launches % 2 == 1)

@@ -44,8 +44,8 @@ def test_c_abi_rejects_bad_arguments_without_a_device(flow2d):
 
 
 def test_solver_algorithm_selection_and_32bit_guard(flow2d):
-    """flow2d_solve_level's choice of algorithm, checked without a device: AUTO = one workgroup up to 64 x 32, LDS tiles
-    up to 896 x 896, the fused strip kernel above (when there are >= 2 sweeps to fuse), per-sweep launches
+    """flow2d_solve_level's choice of algorithm, checked without a device: AUTO = LDS tiles up to 896 x 896 (one workgroup
+    up to 64 x 32 where the tiled kernel does not apply), the fused strip kernel above (when there are >= 2 sweeps to fuse), per-sweep launches
     otherwise -- and whenever the plane reaches
     4 GiB, which the fused kernel's 32-bit buffer offsets cannot address (an explicit FUSED request is refused there
     instead of wrapping around)."""
@@ -53,7 +53,8 @@ def test_solver_algorithm_selection_and_32bit_guard(flow2d):
     pick = lambda req, w, h, pitch_bytes, outer, inner, constancy=0: raw(req, w, h, pitch_bytes, outer, inner, constancy)
     AUTO, SWEEP, FUSED, ONE, TILED = 0, 1, 2, 3, 4
     pitch = lambda w: flow2d.hip_lib().flow2d_plane_pitch_bytes(w)
-    assert pick(AUTO, 64, 32, pitch(64), 10, 5) == ONE and pick(AUTO, 64, 33, pitch(64), 10, 5) == TILED
+    assert pick(AUTO, 64, 32, pitch(64), 10, 5) == TILED and pick(AUTO, 64, 33, pitch(64), 10, 5) == TILED
+    assert pick(AUTO, 64, 32, pitch(64), 10, 5, flow2d.LOG_DERIVATIVES) == ONE and pick(AUTO, 64, 32, pitch(64), 10, 1) == ONE
     assert pick(AUTO, 512, 512, pitch(512), 10, 5) == TILED and pick(AUTO, 512, 512, pitch(512), 10, 7) == FUSED
     assert pick(AUTO, 896, 896, pitch(896), 10, 5) == TILED and pick(AUTO, 897, 896, pitch(897), 10, 5) == FUSED
     assert pick(AUTO, 1024, 1024, pitch(1024), 10, 5) == FUSED

@@ -36,5 +36,14 @@ print('$wl', 'value', d['value'], 'pairs/s', d['pairs_per_s'], 'ms/step', d['ms_
             rm -rf "$OUT/trace_$wl"
             head -4 "$OUT/r02_${wl}_by_grid.txt"
         done ;;
+    trace_default)  # the default bench command itself under the profiler (four lanes, graph replay)
+        export TMPDIR=/tmp
+        rm -rf "$OUT/trace_default"
+        (cd /tmp && timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_default" -- \
+            python3 "$R/bench.py" > "$OUT/r02_default_command_bench_line_under_rocprof.json" 2> "$OUT/trace_default.err") || { tail -5 "$OUT/trace_default.err"; exit 1; }
+        python3 tools/summarize_trace.py "$OUT"/trace_default/*/*kernel_trace.csv 30 > "$OUT/r02_default_command_by_grid.txt"
+        cp "$OUT"/trace_default/*/*kernel_stats.csv "$OUT/r02_default_command_kernel_stats.csv"
+        rm -rf "$OUT/trace_default"
+        head -5 "$OUT/r02_default_command_by_grid.txt" ;;
     esac
 done
