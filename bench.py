@@ -69,6 +69,11 @@ WORKLOADS = {
     "cfg5_8192_grey": dict(w=8192, h=8192, dx=12.0, dy=-7.0, seed=5, constancy=0, levels=12, scale=0.5, outer=10,
                            inner=5, median=5, sigma=1.5, alpha=35.0, pairs_per_rank=1),
 }
+# developer what-if (not a BASELINE config): 4 / 8 pairs of config 4 stacked into one tall frame, i.e. the kernel sizes a
+# lock-step batch of pairs would launch
+WORKLOADS["x_stack4_1080p"] = dict(WORKLOADS["cfg4_1080p_batch"], h=4320, pairs_per_rank=2)
+WORKLOADS["x_stack8_1080p"] = dict(WORKLOADS["cfg4_1080p_batch"], h=8640, pairs_per_rank=1)
+WORKLOADS["x_stack4_1024"] = dict(WORKLOADS["cfg2_1024_grey"], h=4096, pairs_per_rank=1)
 DEFAULT_WORKLOAD = "cfg3_4096_gradient"
 BATCH_WORKLOAD = "cfg4_1080p_batch"
 CONSTANCY_NAME = {0: "grey", 1: "gradient", 2: "gradient-untiled", 3: "log-derivatives"}
@@ -191,18 +196,23 @@ def sha(a):
 
 class Job:
     """One workload on this rank, run through the C++ batch entry (OpticalFlowBatch2D, host/optical_flow_batch_2d.cpp):
-    lanes = independent (stream, OpticalFlow2D, plane pool) triples.  A rank with several pairs per step hands them all
-    to one ComputeFlowBatchDevice call (pair k -> lane k mod lanes), so the launch-bound coarse levels of one pair
-    overlap another pair's work; with one pair per step, consecutive steps rotate over the lanes (every lane has its own
-    copy of the pair's planes)."""
+    lanes = independent (stream, OpticalFlow2D, plane pool) triples, every lane with its own copy of the planes it works
+    on; consecutive steps rotate over the lanes, so one step's launch-bound coarse levels overlap another step's fine
+    levels.  A step of a single-pair workload is that pair; a step of a batched workload is ONE lock-step group of all
+    the rank's pairs (--batch-mode groups: the pairs one below the other in tall containers, every kernel launched
+    once for the group) or, with --batch-mode lanes, the pairs spread one by one over the lanes."""
 
     def __init__(self, flow2d, batch, workload, cfg, args, rank, local_rank, world, out_tensor=None):
         self.flow2d, self.batch, self.workload, self.cfg, self.args = flow2d, batch, workload, cfg, args
         self.rank, self.world, self.local_rank = rank, world, local_rank
         w, h = cfg["w"], cfg["h"]
         self.single = cfg["pairs_per_rank"] == 1
-        self.n_lanes = max(1, min(args.max_lanes, cfg["pairs_per_rank"] * args.pipeline))
-        self.runner = flow2d.OpticalFlowBatch(w, h, cfg["constancy"], lanes=self.n_lanes, device=local_rank)
+        self.grouped = not self.single and args.batch_mode == "groups"
+        self.group = cfg["pairs_per_rank"] if self.grouped else 1
+        self.rotate = self.single or self.grouped  # a step is one entry; steps rotate over the lanes
+        self.n_lanes = max(1, min(args.max_lanes, args.pipeline if self.rotate else cfg["pairs_per_rank"] * args.pipeline))
+        self.runner = flow2d.OpticalFlowBatch(w, h, cfg["constancy"], lanes=self.n_lanes, device=local_rank,
+                                              group_size=self.group)
         self.ctx = flow2d.Context(local_rank)  # plane allocation, uploads, downloads (created after the lanes' streams)
         self.runner.use_graph(not args.no_graph)
         # rank 0's parameter block on every rank (RCCL broadcast; SURVEY 8e), then the same solve everywhere
@@ -212,22 +222,30 @@ class Job:
                                          block[6], int(block[7]), block[8], int(block[9]))
         # this rank's pairs, resident in HBM before any timed region; pair k -> rank k mod world
         self.owned = batch.pairs_of_rank(cfg["pairs_per_rank"] * world, rank, world)
-        self.first_pair = None
-        self.sets = []  # (frame 0, frame 1, u, v, global pair index); single-pair workloads: one copy per lane
-        c = self.ctx
-        for n, gk in enumerate(self.owned):
-            dx, dy = pair_shift(workload, cfg, gk)
-            f0, f1 = synthetic_pair(w, h, dx, dy)
-            if self.first_pair is None:
-                self.first_pair = (f0, f1)
-            for _ in range(self.n_lanes if self.single else 1):
-                if out_tensor is not None:  # flow fields written straight into the gather buffer
+        frames = [synthetic_pair(w, h, *pair_shift(workload, cfg, gk)) for gk in self.owned]
+        self.first_pair = frames[0]
+        c, G = self.ctx, self.group
+        # entries: (frame 0, frame 1, u, v, [global pair indices]); planes are G containers tall
+        self.sets = []
+        if self.rotate:
+            stacked = (np.vstack([f[0] for f in frames]), np.vstack([f[1] for f in frames]))
+            for lane in range(self.n_lanes):
+                if out_tensor is not None and lane == 0:  # lane 0 writes straight into the gather buffer [2, G, h, pitch]
                     assert out_tensor.shape[-1] * 4 == self.runner.pitch
-                    pu = _Borrowed(c, out_tensor[n, 0].data_ptr(), self.runner.pitch, w, h)
-                    pv = _Borrowed(c, out_tensor[n, 1].data_ptr(), self.runner.pitch, w, h)
+                    pu = _Borrowed(c, out_tensor[0].data_ptr(), self.runner.pitch, w, h * G)
+                    pv = _Borrowed(c, out_tensor[1].data_ptr(), self.runner.pitch, w, h * G)
+                else:
+                    pu, pv = c.plane(w, h * G), c.plane(w, h * G)
+                self.sets.append((c.plane(w, h * G, stacked[0]), c.plane(w, h * G, stacked[1]), pu, pv, list(self.owned)))
+        else:
+            for n, gk in enumerate(self.owned):
+                if out_tensor is not None:
+                    assert out_tensor.shape[-1] * 4 == self.runner.pitch
+                    pu = _Borrowed(c, out_tensor[0, n].data_ptr(), self.runner.pitch, w, h)
+                    pv = _Borrowed(c, out_tensor[1, n].data_ptr(), self.runner.pitch, w, h)
                 else:
                     pu, pv = c.plane(w, h), c.plane(w, h)
-                self.sets.append((c.plane(w, h, f0), c.plane(w, h, f1), pu, pv, gk))
+                self.sets.append((c.plane(w, h, frames[n][0]), c.plane(w, h, frames[n][1]), pu, pv, [gk]))
         c.synchronize()
 
     def sync(self):
@@ -240,7 +258,7 @@ class Job:
 
     def step(self, index):
         """One pass over this rank's pairs: ONE call into the C++ batch entry (replayed HIP graphs unless --no-graph)."""
-        if self.single:
+        if self.rotate:
             lane = index % self.n_lanes
             self._queue([self.sets[lane]], lane)
         else:
@@ -256,7 +274,13 @@ class Job:
     def digests(self):
         """{(set index, pair index): (sha(u), sha(v))} of what is in HBM now."""
         self.sync()
-        return {(si, gk): (sha(pu.download()), sha(pv.download())) for si, (_, _, pu, pv, gk) in enumerate(self.sets)}
+        h = self.cfg["h"]
+        out = {}
+        for si, (_, _, pu, pv, gks) in enumerate(self.sets):
+            u, v = pu.download(), pv.download()
+            for k, gk in enumerate(gks):
+                out[(si, gk)] = (sha(u[k * h:(k + 1) * h]), sha(v[k * h:(k + 1) * h]))
+        return out
 
     def close(self):
         self.runner.close()
@@ -279,7 +303,7 @@ def timed_region(job, batch, torch, steps, warmup):
         job.sync()
         torch.cuda.synchronize()
 
-    for k in range(max(warmup, 1) * (job.n_lanes if job.single else 1)):
+    for k in range(max(warmup, 1) * (job.n_lanes if job.rotate else 1)):
         job.step(k)  # also records the graphs of every lane
     barrier()
     t0 = time.perf_counter()
@@ -295,12 +319,15 @@ def output_check(job):
     job.eager_pass()
     eager = job.digests()
     lanes_identical = True
-    if job.single:
-        lanes_identical = len({v for v in replayed.values()}) == 1
+    if job.rotate:  # every lane holds a copy of the same pairs: pair by pair the lanes must agree
+        by_pair = {}
+        for (si, gk), d in replayed.items():
+            by_pair.setdefault(gk, set()).add(d)
+        lanes_identical = all(len(ds) == 1 for ds in by_pair.values())
     return {
         "ok": bool(replayed == eager and lanes_identical),
         "graph_replay_equals_eager": bool(replayed == eager),
-        "streams_identical": bool(lanes_identical) if job.single else None,
+        "streams_identical": bool(lanes_identical) if job.rotate else None,
         "fields_hashed": 2 * len(replayed),
         "sha256_u_v_first_pair": list(replayed[min(replayed)]),
     }
@@ -333,12 +360,13 @@ def batch_leg(flow2d, batch, torch, args, rank, local_rank, world):
     w, h = cfg["w"], cfg["h"]
     pitch_floats = flow2d.hip_lib().flow2d_plane_pitch_bytes(w) // 4
     n_local = cfg["pairs_per_rank"]
-    local = torch.zeros((n_local, 2, h, pitch_floats), dtype=torch.float32, device=torch.device("cuda", local_rank))
+    # u planes of the rank's pairs, then their v planes: [2, pairs, H, pitch] (a lock-step group's tall containers)
+    local = torch.zeros((2, n_local, h, pitch_floats), dtype=torch.float32, device=torch.device("cuda", local_rank))
     job = Job(flow2d, batch, BATCH_WORKLOAD, cfg, args, rank, local_rank, world, out_tensor=local)
     steps = max(3, min(args.steps, 20))
     elapsed = timed_region(job, batch, torch, steps, 1)
     check = output_check(job)
-    # gather: every rank's [8, 2, H, pitch] block -> [world, 8, 2, H, pitch] on every rank; pair k = [k % world, k // world]
+    # gather: every rank's [2, 8, H, pitch] block -> [world, 2, 8, H, pitch] on every rank; pair k = [k % world, :, k // world]
     torch.cuda.synchronize()
     gathered = batch.all_gather_fields(local)
     batch.barrier()
@@ -347,8 +375,8 @@ def batch_leg(flow2d, batch, torch, args, rank, local_rank, world):
     gathered = batch.all_gather_fields(local, out=gathered)
     torch.cuda.synchronize()
     gather_s = batch.max_over_ranks(time.perf_counter() - t0)
-    mine_ok = all(bool(torch.equal(gathered[rank, n], local[n])) for n in range(n_local))
-    nonzero = bool((gathered.abs().amax(dim=(2, 3, 4)) > 0).all().item())
+    mine_ok = bool(torch.equal(gathered[rank], local))
+    nonzero = bool((gathered.abs().amax(dim=(3, 4)) > 0).all().item())
     job.close()
     pairs = steps * n_local * world
     px_iters = float(w) * h * cfg["outer"] * cfg["inner"]
@@ -356,7 +384,8 @@ def batch_leg(flow2d, batch, torch, args, rank, local_rank, world):
         "workload": BATCH_WORKLOAD, "pairs_per_gpu": n_local, "pairs_total_per_step": n_local * world, "steps": steps,
         "value": round(px_iters * pairs / elapsed / 1e6, 1), "unit": "Mpixel*iters/s",
         "pairs_per_s": round(pairs / elapsed, 2), "ms_per_step": round(elapsed / steps * 1e3, 3),
-        "streams_per_gpu": job.n_lanes,
+        "streams_per_gpu": job.n_lanes, "batch_mode": "lock-step group of %d pairs per launch" % job.group if job.grouped
+        else "pairs spread over the lanes",
         "gather": {"collective": "all_gather_into_tensor (RCCL)" if world > 1 else "none (one process)",
                    "bytes_per_rank": int(local.numel() * 4), "ms": round(gather_s * 1e3, 3),
                    "own_block_intact": mine_ok, "every_pair_present": nonzero},
@@ -379,6 +408,9 @@ def main():
                     help="independent pairs in flight per GPU when a step holds a single pair: consecutive steps go to "
                          "alternating streams so one pair's launch-bound coarse levels overlap the next pair's fine levels")
     ap.add_argument("--max-lanes", type=int, default=4, help="upper bound on the lanes (streams) per GPU")
+    ap.add_argument("--batch-mode", choices=["groups", "lanes"], default="groups",
+                    help="batched workloads: all pairs of a step as one lock-step group (every kernel launched once for "
+                         "the group) or spread one by one over the lanes")
     args = ap.parse_args()
     cfg = WORKLOADS[args.workload]
 
@@ -488,6 +520,7 @@ def main():
                 "parallelism": "independent pairs, one process per GPU, no data-path collective",
                 "host_path": "OpticalFlowBatch2D::ComputeFlowBatchDevice (C++): one call per step",
                 "streams_per_gpu": n_lanes, "hip_graph_replay": not args.no_graph,
+                "batch_mode": ("lock-step group" if args.batch_mode == "groups" else "lanes") if cfg["pairs_per_rank"] > 1 else None,
                 "timed_region": "graph-replayed steps only; output check, roofline sample, batch leg and baselines follow it",
             },
             "pairs_per_s": round(pairs_total / elapsed, 3),

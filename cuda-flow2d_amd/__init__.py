@@ -431,7 +431,9 @@ def host_lib():
         L.flow2d_host_operator_execute.argtypes = [vp, C.POINTER(C.c_char_p), C.POINTER(vp), sz]
         L.flow2d_host_operator_destroy.argtypes = [vp]
         L.flow2d_host_batch_create.restype = vp
-        L.flow2d_host_batch_create.argtypes = [sz, sz, i, sz, i]
+        L.flow2d_host_batch_create.argtypes = [sz, sz, i, sz, i, sz]
+        L.flow2d_host_batch_group_stride.restype = sz
+        L.flow2d_host_batch_group_stride.argtypes = [vp]
         L.flow2d_host_batch_destroy.argtypes = [vp]
         L.flow2d_host_batch_pitch.restype = sz
         L.flow2d_host_batch_pitch.argtypes = [vp]
@@ -544,14 +546,17 @@ class OpticalFlowBatch:
     pool each) on one GPU; pair k of a call runs on lane (first_lane + k) mod lanes.  The scheduling is C++; this
     class only marshals device addresses."""
 
-    def __init__(self, width, height, constancy=GREY, lanes=4, device=0):
+    def __init__(self, width, height, constancy=GREY, lanes=4, device=0, group_size=1):
         L = host_lib()
-        self.width, self.height = width, height
-        self.handle = L.flow2d_host_batch_create(width, height, _HOST_CONSTANCY[constancy], lanes, device)
+        self.width, self.height, self.group_size = width, height, group_size
+        self.handle = L.flow2d_host_batch_create(width, height, _HOST_CONSTANCY[constancy], lanes, device, group_size)
         if not self.handle:
             raise Flow2DError(1, "OpticalFlowBatch2D::Initialize")
         self.pitch = L.flow2d_host_batch_pitch(self.handle)
         self.lanes = L.flow2d_host_batch_lanes(self.handle)
+        # group_size > 1: every plane handed to compute_flow_batch_device is a tall container, pair g of the group
+        # group_stride bytes * g behind its address (= pitch * height: the pairs' containers one below the other)
+        self.group_stride = L.flow2d_host_batch_group_stride(self.handle)
 
     params = staticmethod(OpticalFlow.params)
 

@@ -25,6 +25,17 @@ struct flow2d_context {
     std::vector<hipEvent_t> event_pool;          // recycled timing events
     std::vector<flow2d_timing_slot> timings;
     int num_cus = 256;
+    // flow2d_context_set_batch: every launch runs `batch_count` instances, instance b on plane pointers + b * stride
+    unsigned batch_count = 1;
+    size_t batch_stride_floats = 0;
+};
+
+// How a kernel finds its instance of a batched launch: grid.z = planes x batch_count, plane = z % planes (the
+// u / v or frame 0 / frame 1 choice of the two-plane launches), instance = z / planes.
+struct BatchArg {
+    unsigned planes;
+    unsigned reserved;
+    unsigned long long stride;  // floats between consecutive instances of every plane
 };
 
 namespace flow2d {
@@ -47,6 +58,12 @@ inline bool plane_args_ok(const void* p, size_t w, size_t h, size_t pitch_bytes)
 
 inline unsigned div_up(size_t a, size_t b) { return static_cast<unsigned>((a + b - 1) / b); }
 
+inline BatchArg batch_arg(const flow2d_context* ctx, unsigned planes)
+{
+    return BatchArg{planes, 0u, static_cast<unsigned long long>(ctx->batch_stride_floats)};
+}
+inline unsigned batch_z(const flow2d_context* ctx, unsigned planes) { return planes * ctx->batch_count; }
+
 }  // namespace flow2d
 
 #define FLOW2D_HIP_TRY(expr)                              \
@@ -67,6 +84,12 @@ inline unsigned div_up(size_t a, size_t b) { return static_cast<unsigned>((a + b
     (void)hipGetLastError()
 
 #define FLOW2D_CHECK_LAUNCH() FLOW2D_HIP_TRY(hipGetLastError())
+
+__device__ __forceinline__ unsigned batch_plane(const BatchArg& b) { return blockIdx.z % b.planes; }
+__device__ __forceinline__ size_t batch_offset(const BatchArg& b)
+{
+    return static_cast<size_t>(blockIdx.z / b.planes) * static_cast<size_t>(b.stride);
+}
 
 // Reflect-without-repeat index of the solver / median halos: -k -> k, n-1+k -> n-1-k.
 __device__ __forceinline__ int mirror_index(int i, int n)

@@ -192,7 +192,9 @@ int flow2d_memset_2d(flow2d_context* ctx, void* dev_ptr, size_t pitch_bytes, int
     FLOW2D_ENTER(ctx);
     if (!dev_ptr || width_bytes > pitch_bytes) return FLOW2D_ERR_INVALID_ARGUMENT;
     if (width_bytes == 0 || height == 0) return FLOW2D_OK;
-    FLOW2D_HIP_TRY(hipMemset2DAsync(dev_ptr, pitch_bytes, byte_value, width_bytes, height, ctx->stream));
+    for (unsigned b = 0; b < ctx->batch_count; ++b)
+        FLOW2D_HIP_TRY(hipMemset2DAsync(static_cast<char*>(dev_ptr) + b * ctx->batch_stride_floats * sizeof(float),
+                                        pitch_bytes, byte_value, width_bytes, height, ctx->stream));
     return FLOW2D_OK;
 }
 
@@ -223,7 +225,20 @@ int flow2d_copy_d2d(flow2d_context* ctx, void* dst_dev, const void* src_dev, siz
     FLOW2D_ENTER(ctx);
     if (!dst_dev || !src_dev) return FLOW2D_ERR_INVALID_ARGUMENT;
     if (bytes == 0) return FLOW2D_OK;
-    FLOW2D_HIP_TRY(hipMemcpyAsync(dst_dev, src_dev, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+    for (unsigned b = 0; b < ctx->batch_count; ++b) {
+        const size_t off = b * ctx->batch_stride_floats * sizeof(float);
+        FLOW2D_HIP_TRY(hipMemcpyAsync(static_cast<char*>(dst_dev) + off, static_cast<const char*>(src_dev) + off, bytes,
+                                      hipMemcpyDeviceToDevice, ctx->stream));
+    }
+    return FLOW2D_OK;
+}
+
+int flow2d_context_set_batch(flow2d_context* ctx, size_t count, size_t stride_bytes)
+{
+    if (!ctx || count == 0 || count > 65535 || (count > 1 && (stride_bytes == 0 || stride_bytes % 16 != 0)))
+        return FLOW2D_ERR_INVALID_ARGUMENT;
+    ctx->batch_count = static_cast<unsigned>(count);
+    ctx->batch_stride_floats = count > 1 ? stride_bytes / sizeof(float) : 0;
     return FLOW2D_OK;
 }
 

@@ -133,10 +133,10 @@ __device__ __noinline__ float exact_median(const float* __restrict__ in, int x, 
 template <int R>
 __global__ __launch_bounds__(256) void median_kernel(const float* __restrict__ in_a, const float* __restrict__ in_b, int w,
                                                      int h, int pitch, float* __restrict__ out_a,
-                                                     float* __restrict__ out_b)
+                                                     float* __restrict__ out_b, BatchArg batch)
 {
-    const float* __restrict__ in = blockIdx.z ? in_b : in_a;
-    float* __restrict__ out = blockIdx.z ? out_b : out_a;
+    const float* __restrict__ in = (batch_plane(batch) ? in_b : in_a) + batch_offset(batch);
+    float* __restrict__ out = (batch_plane(batch) ? out_b : out_a) + batch_offset(batch);
     constexpr int R2 = R / 2;
     constexpr int N = R * R;
     const int x = blockIdx.x * kBlockX + threadIdx.x;
@@ -325,10 +325,10 @@ __device__ __forceinline__ void median5_strip(const float* __restrict__ in, floa
 __global__ __launch_bounds__(256) void median5_stream_kernel(const float* __restrict__ in_a,
                                                              const float* __restrict__ in_b, int w, int h, int pitch,
                                                              int rows_per_strip, float* __restrict__ out_a,
-                                                             float* __restrict__ out_b)
+                                                             float* __restrict__ out_b, BatchArg batch)
 {
-    const float* __restrict__ in = blockIdx.z ? in_b : in_a;
-    float* __restrict__ out = blockIdx.z ? out_b : out_a;
+    const float* __restrict__ in = (batch_plane(batch) ? in_b : in_a) + batch_offset(batch);
+    float* __restrict__ out = (batch_plane(batch) ? out_b : out_a) + batch_offset(batch);
     const int lane = threadIdx.x & 63;
     const int strip = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int x_first = strip * kStreamValid - 2;
@@ -352,7 +352,7 @@ int median5_rows_per_strip(const flow2d_context* ctx, size_t w, size_t h)
     const long strips_x = flow2d::div_up(w, kStreamValid);
     const long want_waves = (ctx->num_cus > 0 ? ctx->num_cus : 256) * 4 * 4;  // four waves per SIMD
     long rows = 64;
-    while (rows > 8 && strips_x * (long)flow2d::div_up(h, rows) < want_waves) rows /= 2;
+    while (rows > 8 && strips_x * (long)flow2d::div_up(h, rows) * (long)ctx->batch_count < want_waves) rows /= 2;
     return (int)rows;
 }
 
@@ -373,21 +373,23 @@ static int launch_median(flow2d_context* ctx, const float* input, const float* i
     if (window != 3 && window != 5 && window != 7) return FLOW2D_ERR_UNSUPPORTED;
     // the mirror rule needs every reflected index inside the image
     if (width <= window / 2 || height <= window / 2) return FLOW2D_ERR_UNSUPPORTED;
-    const unsigned z = pair ? 2 : 1;
+    const unsigned planes = pair ? 2 : 1;
+    const unsigned z = flow2d::batch_z(ctx, planes);
+    const BatchArg batch = flow2d::batch_arg(ctx, planes);
     const dim3 grid(flow2d::div_up(width, kBlockX), flow2d::div_up(height, kBlockY), z);
     const dim3 block(kBlockX, kBlockY);
     const int w = (int)width, h = (int)height, pitch = (int)(pitch_bytes / 4);
     if (window == 5 && width >= 8 && height >= 8) {  // mirrored rows/columns up to 3 beyond the border stay inside
         const int rows = median5_rows_per_strip(ctx, width, height);
         const dim3 sgrid(flow2d::div_up(flow2d::div_up(width, kStreamValid), 4), flow2d::div_up(height, rows), z);
-        median5_stream_kernel<<<sgrid, 256, 0, ctx->stream>>>(input, input_b, w, h, pitch, rows, output, output_b);
+        median5_stream_kernel<<<sgrid, 256, 0, ctx->stream>>>(input, input_b, w, h, pitch, rows, output, output_b, batch);
         FLOW2D_CHECK_LAUNCH();
         return FLOW2D_OK;
     }
     switch (window) {
-        case 3: median_kernel<3><<<grid, block, 0, ctx->stream>>>(input, input_b, w, h, pitch, output, output_b); break;
-        case 5: median_kernel<5><<<grid, block, 0, ctx->stream>>>(input, input_b, w, h, pitch, output, output_b); break;
-        default: median_kernel<7><<<grid, block, 0, ctx->stream>>>(input, input_b, w, h, pitch, output, output_b); break;
+        case 3: median_kernel<3><<<grid, block, 0, ctx->stream>>>(input, input_b, w, h, pitch, output, output_b, batch); break;
+        case 5: median_kernel<5><<<grid, block, 0, ctx->stream>>>(input, input_b, w, h, pitch, output, output_b, batch); break;
+        default: median_kernel<7><<<grid, block, 0, ctx->stream>>>(input, input_b, w, h, pitch, output, output_b, batch); break;
     }
     FLOW2D_CHECK_LAUNCH();
     return FLOW2D_OK;

@@ -23,10 +23,10 @@ inline dim3 grid_for(size_t w, size_t h) { return dim3(flow2d::div_up(w, kBlockX
 // level, ... come in pairs, and on the small levels a launch costs more than its work.
 __global__ __launch_bounds__(256) void add_2d_kernel(float* __restrict__ op0_a, const float* __restrict__ op1_a,
                                                      float* __restrict__ op0_b, const float* __restrict__ op1_b, int w,
-                                                     int h, int pitch)
+                                                     int h, int pitch, BatchArg batch)
 {
-    float* __restrict__ op0 = blockIdx.z ? op0_b : op0_a;
-    const float* __restrict__ op1 = blockIdx.z ? op1_b : op1_a;
+    float* __restrict__ op0 = (batch_plane(batch) ? op0_b : op0_a) + batch_offset(batch);
+    const float* __restrict__ op1 = (batch_plane(batch) ? op1_b : op1_a) + batch_offset(batch);
     const int x4 = (blockIdx.x * kBlockX + threadIdx.x) * 4;
     const int y = blockIdx.y * kBlockY + threadIdx.y;
     if (y >= h || x4 >= w) return;
@@ -183,8 +183,11 @@ __device__ __forceinline__ void blur_steps(float (&ring)[2 * R + 1], float& next
 
 template <int R>
 __global__ __launch_bounds__(256) void gauss_stream_kernel(float* __restrict__ dst, const float* __restrict__ src, int w,
-                                                           int h, int pitch, int rows_per_strip, GaussTaps taps)
+                                                           int h, int pitch, int rows_per_strip, GaussTaps taps,
+                                                           BatchArg batch)
 {
+    dst += batch_offset(batch);
+    src += batch_offset(batch);
     constexpr int N = 2 * R + 1, kValid = 64 - 2 * R;
     const int lane = threadIdx.x & 63;
     const int strip = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -217,20 +220,20 @@ void launch_gauss_stream(flow2d_context* ctx, float* dst, const float* src, size
     const long strips = flow2d::div_up(width, 64 - 2 * R);
     const long want_waves = (ctx->num_cus > 0 ? ctx->num_cus : 256) * 4 * 4;  // four waves per SIMD
     long rows = 128;
-    while (rows > 16 && strips * (long)flow2d::div_up(height, rows) < want_waves) rows /= 2;
-    const dim3 grid(flow2d::div_up(strips, 4), flow2d::div_up(height, rows));
+    while (rows > 16 && strips * (long)flow2d::div_up(height, rows) * (long)ctx->batch_count < want_waves) rows /= 2;
+    const dim3 grid(flow2d::div_up(strips, 4), flow2d::div_up(height, rows), flow2d::batch_z(ctx, 1));
     gauss_stream_kernel<R><<<grid, 256, 0, ctx->stream>>>(dst, src, (int)width, (int)height, (int)(pitch_bytes / 4),
-                                                          (int)rows, t);
+                                                          (int)rows, t, flow2d::batch_arg(ctx, 1));
 }
 
 // ---- area-weighted resampling: src/kernels/resample_2d.cu:34-75 (x), :77-118 (y) ----------------
 template <bool kAlongX>
 __global__ __launch_bounds__(256) void resample_kernel(const float* __restrict__ in_a, float* __restrict__ out_a,
                                                        const float* __restrict__ in_b, float* __restrict__ out_b,
-                                                       int out_w, int out_h, int in_n, int pitch)
+                                                       int out_w, int out_h, int in_n, int pitch, BatchArg batch)
 {
-    const float* __restrict__ in = blockIdx.z ? in_b : in_a;
-    float* __restrict__ out = blockIdx.z ? out_b : out_a;
+    const float* __restrict__ in = (batch_plane(batch) ? in_b : in_a) + batch_offset(batch);
+    float* __restrict__ out = (batch_plane(batch) ? out_b : out_a) + batch_offset(batch);
     const int x = blockIdx.x * kBlockX + threadIdx.x;
     const int y = blockIdx.y * kBlockY + threadIdx.y;
     if (x >= out_w || y >= out_h) return;
@@ -281,10 +284,10 @@ constexpr int kResampleLdsPerWave = kResampleChunk + kResampleChunk / 32;  // on
 
 __global__ __launch_bounds__(256) void resample_x_lds_kernel(const float* __restrict__ in_a, float* __restrict__ out_a,
                                                              const float* __restrict__ in_b, float* __restrict__ out_b,
-                                                             int out_w, int out_h, int in_w, int pitch)
+                                                             int out_w, int out_h, int in_w, int pitch, BatchArg batch)
 {
-    const float* __restrict__ in = blockIdx.z ? in_b : in_a;
-    float* __restrict__ out = blockIdx.z ? out_b : out_a;
+    const float* __restrict__ in = (batch_plane(batch) ? in_b : in_a) + batch_offset(batch);
+    float* __restrict__ out = (batch_plane(batch) ? out_b : out_a) + batch_offset(batch);
     __shared__ float lds[4][kResampleLdsPerWave];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int x = blockIdx.x * 64 + lane;
@@ -383,11 +386,11 @@ __device__ __forceinline__ float resample_x_output_lds(const float* __restrict__
 
 __global__ __launch_bounds__(256) void resample_x_levels_kernel(const float* __restrict__ in_a, float* __restrict__ out_a,
                                                                 const float* __restrict__ in_b, float* __restrict__ out_b,
-                                                                int in_w, int pitch, ResampleLevels lv)
+                                                                int in_w, int pitch, ResampleLevels lv, BatchArg batch)
 {
     extern __shared__ float row[];
-    const float* __restrict__ in = blockIdx.z ? in_b : in_a;
-    float* __restrict__ out = blockIdx.z ? out_b : out_a;
+    const float* __restrict__ in = (batch_plane(batch) ? in_b : in_a) + batch_offset(batch);
+    float* __restrict__ out = (batch_plane(batch) ? out_b : out_a) + batch_offset(batch);
     const size_t line = static_cast<size_t>(blockIdx.x) * pitch;
     for (int i = threadIdx.x; i < in_w; i += 256) row[i + (i >> 5)] = in[line + i];
     __syncthreads();
@@ -426,8 +429,13 @@ __global__ __launch_bounds__(256) void resample_x_levels_kernel(const float* __r
 __global__ __launch_bounds__(256) void registration_kernel(const float* __restrict__ f0, const float* __restrict__ f1,
                                                            const float* __restrict__ u, const float* __restrict__ v,
                                                            int w, int h, int pitch, float hx, float hy,
-                                                           float* __restrict__ out)
+                                                           float* __restrict__ out, BatchArg batch)
 {
+    f0 += batch_offset(batch);
+    f1 += batch_offset(batch);
+    u += batch_offset(batch);
+    v += batch_offset(batch);
+    out += batch_offset(batch);
     const int gx = blockIdx.x * kBlockX + threadIdx.x;
     const int gy = blockIdx.y * kBlockY + threadIdx.y;
     if (gx >= w || gy >= h) return;
@@ -469,9 +477,11 @@ static int launch_add(flow2d_context* ctx, float* operand_0, const float* operan
                  !flow2d::plane_args_ok(operand_1_b, width, height, pitch_bytes) || operand_0_b == operand_0 ||
                  operand_0_b == operand_1 || operand_0 == operand_1_b))
         return FLOW2D_ERR_INVALID_ARGUMENT;
-    dim3 grid(flow2d::div_up(width, kBlockX * 4), flow2d::div_up(height, kBlockY), pair ? 2 : 1);
+    const unsigned planes = pair ? 2 : 1;
+    dim3 grid(flow2d::div_up(width, kBlockX * 4), flow2d::div_up(height, kBlockY), flow2d::batch_z(ctx, planes));
     add_2d_kernel<<<grid, dim3(kBlockX, kBlockY), 0, ctx->stream>>>(operand_0, operand_1, operand_0_b, operand_1_b,
-                                                                   (int)width, (int)height, (int)(pitch_bytes / 4));
+                                                                   (int)width, (int)height, (int)(pitch_bytes / 4),
+                                                                   flow2d::batch_arg(ctx, planes));
     FLOW2D_CHECK_LAUNCH();
     return FLOW2D_OK;
 }
@@ -520,12 +530,15 @@ static int launch_gauss(flow2d_context* ctx, bool rows, float* dst, const float*
     if (radius < 0 || 2 * radius + 1 > 51) return FLOW2D_ERR_UNSUPPORTED;
     GaussTaps t;
     for (int i = 0; i < 51; ++i) t.t[i] = i < 2 * radius + 1 ? taps[i] : 0.f;
-    if (rows)
-        gauss_kernel<true><<<grid_for(width, height), dim3(kBlockX, kBlockY), 0, ctx->stream>>>(
-            dst, src, (int)width, (int)height, (int)(pitch_bytes / 4), radius, t);
-    else
-        gauss_kernel<false><<<grid_for(width, height), dim3(kBlockX, kBlockY), 0, ctx->stream>>>(
-            dst, src, (int)width, (int)height, (int)(pitch_bytes / 4), radius, t);
+    for (unsigned b = 0; b < ctx->batch_count; ++b) {  // (not on the pyramid's path: one launch per batch instance)
+        const size_t off = b * ctx->batch_stride_floats;
+        if (rows)
+            gauss_kernel<true><<<grid_for(width, height), dim3(kBlockX, kBlockY), 0, ctx->stream>>>(
+                dst + off, src + off, (int)width, (int)height, (int)(pitch_bytes / 4), radius, t);
+        else
+            gauss_kernel<false><<<grid_for(width, height), dim3(kBlockX, kBlockY), 0, ctx->stream>>>(
+                dst + off, src + off, (int)width, (int)height, (int)(pitch_bytes / 4), radius, t);
+    }
     FLOW2D_CHECK_LAUNCH();
     return FLOW2D_OK;
 }
@@ -562,8 +575,10 @@ int flow2d_gaussian_blur(flow2d_context* ctx, float* dst, const float* src, size
         case 6: launch_gauss_stream<6>(ctx, dst, src, width, height, pitch_bytes, t); break;
         default: {
             const dim3 grid(flow2d::div_up(width, kBlockX), flow2d::div_up(height, kBlurTile));
-            gauss_fused_kernel<<<grid, dim3(kBlockX, kBlockY), 0, ctx->stream>>>(dst, src, (int)width, (int)height,
-                                                                                (int)(pitch_bytes / 4), radius, t);
+            for (unsigned b = 0; b < ctx->batch_count; ++b)  // (large radii only: one launch per batch instance)
+                gauss_fused_kernel<<<grid, dim3(kBlockX, kBlockY), 0, ctx->stream>>>(
+                    dst + b * ctx->batch_stride_floats, src + b * ctx->batch_stride_floats, (int)width, (int)height,
+                    (int)(pitch_bytes / 4), radius, t);
         }
     }
     FLOW2D_CHECK_LAUNCH();
@@ -584,20 +599,24 @@ static int launch_resample(flow2d_context* ctx, bool along_x, const float* input
                  !flow2d::plane_args_ok(output_b, out_width, out_height, pitch_bytes) || input_b == output_b ||
                  output_b == output || output_b == input || output == input_b))
         return FLOW2D_ERR_INVALID_ARGUMENT;
-    const unsigned z = pair ? 2 : 1;
+    const unsigned planes = pair ? 2 : 1;
+    const unsigned z = flow2d::batch_z(ctx, planes);
+    const BatchArg batch = flow2d::batch_arg(ctx, planes);
     if (along_x && in_extent >= 2 * out_width)  // strong down-sampling: coalesced staging through LDS
         resample_x_lds_kernel<<<dim3(flow2d::div_up(out_width, 64), flow2d::div_up(out_height, 4), z), 256, 0,
                                 ctx->stream>>>(input, output, input_b, output_b, (int)out_width, (int)out_height,
-                                               (int)in_extent, (int)(pitch_bytes / 4));
+                                               (int)in_extent, (int)(pitch_bytes / 4), batch);
     else {
         dim3 grid = grid_for(out_width, out_height);
         grid.z = z;
         if (along_x)
             resample_kernel<true><<<grid, dim3(kBlockX, kBlockY), 0, ctx->stream>>>(
-                input, output, input_b, output_b, (int)out_width, (int)out_height, (int)in_extent, (int)(pitch_bytes / 4));
+                input, output, input_b, output_b, (int)out_width, (int)out_height, (int)in_extent, (int)(pitch_bytes / 4),
+                batch);
         else
             resample_kernel<false><<<grid, dim3(kBlockX, kBlockY), 0, ctx->stream>>>(
-                input, output, input_b, output_b, (int)out_width, (int)out_height, (int)in_extent, (int)(pitch_bytes / 4));
+                input, output, input_b, output_b, (int)out_width, (int)out_height, (int)in_extent, (int)(pitch_bytes / 4),
+                batch);
     }
     FLOW2D_CHECK_LAUNCH();
     return FLOW2D_OK;
@@ -632,8 +651,10 @@ int flow2d_resample_x_levels(flow2d_context* ctx, const float* input_a, float* p
         lv.col[l] = static_cast<int>(column_offsets[l]);
     }
     const size_t lds_bytes = (in_width + in_width / 32 + 1) * sizeof(float);
-    resample_x_levels_kernel<<<dim3(static_cast<unsigned>(height), 1, pair ? 2 : 1), 256, lds_bytes, ctx->stream>>>(
-        input_a, packed_a, input_b, packed_b, static_cast<int>(in_width), static_cast<int>(pitch), lv);
+    const unsigned planes = pair ? 2 : 1;
+    resample_x_levels_kernel<<<dim3(static_cast<unsigned>(height), 1, flow2d::batch_z(ctx, planes)), 256, lds_bytes,
+                               ctx->stream>>>(input_a, packed_a, input_b, packed_b, static_cast<int>(in_width),
+                                              static_cast<int>(pitch), lv, flow2d::batch_arg(ctx, planes));
     FLOW2D_CHECK_LAUNCH();
     return FLOW2D_OK;
 }
@@ -677,8 +698,11 @@ int flow2d_registration_2d(flow2d_context* ctx, const float* frame_0, const floa
         !flow2d::plane_args_ok(output, width, height, pitch_bytes) || output == frame_1 || output == frame_0 ||
         !(hx > 0.f) || !(hy > 0.f))
         return FLOW2D_ERR_INVALID_ARGUMENT;
-    registration_kernel<<<grid_for(width, height), dim3(kBlockX, kBlockY), 0, ctx->stream>>>(
-        frame_0, frame_1, flow_u, flow_v, (int)width, (int)height, (int)(pitch_bytes / 4), hx, hy, output);
+    dim3 grid = grid_for(width, height);
+    grid.z = flow2d::batch_z(ctx, 1);
+    registration_kernel<<<grid, dim3(kBlockX, kBlockY), 0, ctx->stream>>>(
+        frame_0, frame_1, flow_u, flow_v, (int)width, (int)height, (int)(pitch_bytes / 4), hx, hy, output,
+        flow2d::batch_arg(ctx, 1));
     FLOW2D_CHECK_LAUNCH();
     return FLOW2D_OK;
 }

@@ -376,6 +376,17 @@ int launch_phi_ksi(flow2d_context* ctx, const float* f0, const float* f1, const 
                    const float* du, const float* dv, size_t w, size_t h, size_t pitch_bytes, float hx, float hy,
                    float e_smooth, float e_data, float* phi, float* ksi)
 {
+    if (ctx->batch_count > 1) {  // the per-sweep kernels are not batched: one launch per instance
+        const unsigned n = ctx->batch_count;
+        const size_t s = ctx->batch_stride_floats;
+        ctx->batch_count = 1;
+        int st = FLOW2D_OK;
+        for (unsigned b = 0; b < n && st == FLOW2D_OK; ++b)
+            st = launch_phi_ksi(ctx, f0 + b * s, f1 + b * s, u + b * s, v + b * s, du + b * s, dv + b * s, w, h,
+                                pitch_bytes, hx, hy, e_smooth, e_data, phi + b * s, ksi + b * s);
+        ctx->batch_count = n;
+        return st;
+    }
     const dim3 grid(div_up(w, kBlockX), div_up(h, kBlockY));
     phi_ksi_kernel<<<grid, dim3(kBlockX, kBlockY), 0, ctx->stream>>>(f0, f1, u, v, du, dv, (int)w, (int)h,
                                                                      (int)(pitch_bytes / 4), hx, hy, e_smooth, e_data,
@@ -388,6 +399,17 @@ int launch_sweep(flow2d_context* ctx, int constancy, const float* f0, const floa
                  const float* du, const float* dv, const float* phi, const float* ksi, size_t w, size_t h,
                  size_t pitch_bytes, float hx, float hy, float alpha, float* tdu, float* tdv)
 {
+    if (ctx->batch_count > 1) {
+        const unsigned n = ctx->batch_count;
+        const size_t s = ctx->batch_stride_floats;
+        ctx->batch_count = 1;
+        int st = FLOW2D_OK;
+        for (unsigned b = 0; b < n && st == FLOW2D_OK; ++b)
+            st = launch_sweep(ctx, constancy, f0 + b * s, f1 + b * s, u + b * s, v + b * s, du + b * s, dv + b * s,
+                              phi + b * s, ksi + b * s, w, h, pitch_bytes, hx, hy, alpha, tdu + b * s, tdv + b * s);
+        ctx->batch_count = n;
+        return st;
+    }
     if (constancy == FLOW2D_CONSTANCY_GRADIENT) {
         const dim3 grid(div_up(w, kBlockX), div_up(h, kGradTileY));
         sweep_grad_kernel<<<grid, dim3(kBlockX, kGradTileY), 0, ctx->stream>>>(
@@ -414,6 +436,17 @@ int launch_sor_iteration(flow2d_context* ctx, int constancy, const float* f0, co
                          const float* v, float* du, float* dv, const float* phi, const float* ksi, size_t w, size_t h,
                          size_t pitch_bytes, float hx, float hy, float alpha, float omega)
 {
+    if (ctx->batch_count > 1) {
+        const unsigned n = ctx->batch_count;
+        const size_t s = ctx->batch_stride_floats;
+        ctx->batch_count = 1;
+        int st = FLOW2D_OK;
+        for (unsigned b = 0; b < n && st == FLOW2D_OK; ++b)
+            st = launch_sor_iteration(ctx, constancy, f0 + b * s, f1 + b * s, u + b * s, v + b * s, du + b * s, dv + b * s,
+                                      phi + b * s, ksi + b * s, w, h, pitch_bytes, hx, hy, alpha, omega);
+        ctx->batch_count = n;
+        return st;
+    }
     for (int colour = 0; colour < 2; ++colour) {
         if (constancy == FLOW2D_CONSTANCY_GRADIENT) {
             const dim3 grid(div_up(w, kBlockX), div_up(h, kGradTileY));

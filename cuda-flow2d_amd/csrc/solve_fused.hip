@@ -54,6 +54,7 @@ struct FusedArgs {
     const float* start_dv;
     int continue_sweeps;
     float hx, hy, alpha, e_smooth, e_data;
+    unsigned long long batch_stride;  // floats between the instances of a batched launch (blockIdx.z)
     // developer diagnostics (FLOW2D_FUSED_STAMPS=1): per wave {start, end} in 100 MHz ticks, hardware id, xcc id
     unsigned long long* stamps;
 };
@@ -394,6 +395,11 @@ __global__ __launch_bounds__(256, 2) void fused_outer_kernel(FusedArgs a)
     const int lane = threadIdx.x & 63;
     const int strip_x = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (strip_x * S::kValid >= a.w) return;  // whole wave leaves; waves never synchronise with each other
+    {  // instance of a batched launch
+        const size_t off = static_cast<size_t>(blockIdx.z) * static_cast<size_t>(a.batch_stride);
+        a.f0 += off, a.f1 += off, a.u += off, a.v += off, a.du += off, a.dv += off, a.out_du += off, a.out_dv += off;
+        if (CONT) a.start_du += off, a.start_dv += off;
+    }
     const unsigned long long t_start = a.stamps ? __builtin_amdgcn_s_memrealtime() : 0ull;
     const int x = strip_x * S::kValid - S::kHalo + lane;
     const int xc = min(max(x, 0), a.w - 1);
@@ -553,7 +559,7 @@ int fused_rows_per_strip(const flow2d_context* ctx, size_t w, size_t h, size_t i
         if (rows < 1) break;
         if ((long)((h + rows - 1) / rows) != ny) continue;  // same ny reachable with fewer rows: skip duplicates
         const double steps = (double)(rows + 2 * (long)inner + 3) - saved_steps;  // the last ring turn is partial
-        const long blocks = blocks_x * ny;
+        const long blocks = blocks_x * ny * (long)ctx->batch_count;  // the instances of a batched launch share the chip
         const long full = blocks / cap, rem = blocks % cap;
         const double cost = full * 2.0 * steps + (rem == 0 ? 0.0 : (rem <= cus ? 1.3 * steps : 2.0 * steps));
         if (cost < best - 1e-9) {
@@ -574,10 +580,10 @@ int launch_fused_outer(flow2d_context* ctx, int constancy, const float* f0, cons
     if (!fused_supports(inner) || !fused_addressable(h, pitch_bytes)) return FLOW2D_ERR_UNSUPPORTED;
     FusedArgs a{f0, f1, u, v, du, dv, out_du, out_dv, (int)w, (int)h, (int)(pitch_bytes / 4), rows_per_strip,
                 zero_increment ? 1 : 0, start_du, start_dv, (start_du && start_dv) ? 1 : 0, hx, hy, alpha, e_smooth,
-                e_data, nullptr};
+                e_data, static_cast<unsigned long long>(ctx->batch_stride_floats), nullptr};
     const int valid = 64 - 2 * ((int)inner + 1);
     const unsigned strips_x = div_up(w, valid);
-    const dim3 grid(div_up(strips_x, 4), div_up(h, rows_per_strip));
+    const dim3 grid(div_up(strips_x, 4), div_up(h, rows_per_strip), ctx->batch_count);
     const bool pow2 = is_power_of_two(hx) && is_power_of_two(hy);
     if (g_stamps_enabled) {
         const size_t need = static_cast<size_t>(grid.x) * grid.y * 4 * 4 * sizeof(unsigned long long);

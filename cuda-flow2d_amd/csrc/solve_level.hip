@@ -142,10 +142,12 @@ int flow2d_solve_level(flow2d_context* ctx, const float* frame_0, const float* f
     // starts its first outer iteration from zero increments without reading the planes, so it needs no memset.
     const bool one_per_outer = algorithm == FLOW2D_SOLVER_FUSED || algorithm == FLOW2D_SOLVER_TILED;
     if (algorithm == FLOW2D_SOLVER_PER_SWEEP || (one_per_outer && p->outer_iterations_count == 0)) {
-        FLOW2D_HIP_TRY(hipMemset2DAsync(flow_du, p->pitch_bytes, 0, p->width * sizeof(float), p->container_height,
-                                        ctx->stream));
-        FLOW2D_HIP_TRY(hipMemset2DAsync(flow_dv, p->pitch_bytes, 0, p->width * sizeof(float), p->container_height,
-                                        ctx->stream));
+        for (unsigned b = 0; b < ctx->batch_count; ++b) {
+            FLOW2D_HIP_TRY(hipMemset2DAsync(flow_du + b * ctx->batch_stride_floats, p->pitch_bytes, 0,
+                                            p->width * sizeof(float), p->container_height, ctx->stream));
+            FLOW2D_HIP_TRY(hipMemset2DAsync(flow_dv + b * ctx->batch_stride_floats, p->pitch_bytes, 0,
+                                            p->width * sizeof(float), p->container_height, ctx->stream));
+        }
     }
 
     const bool per_launch = slot && ctx->timing >= 2 && p->width >= ctx->timing_min_w && p->height >= ctx->timing_min_h;
@@ -208,10 +210,13 @@ int flow2d_solve_level(flow2d_context* ctx, const float* frame_0, const float* f
         ++launches;
     }
     if (algorithm == FLOW2D_SOLVER_FUSED && source == 2) {  // the caller only knows two pairs: hand the result over
-        FLOW2D_HIP_TRY(hipMemcpy2DAsync(flow_du, p->pitch_bytes, phi, p->pitch_bytes, p->width * sizeof(float), p->height,
-                                        hipMemcpyDeviceToDevice, ctx->stream));
-        FLOW2D_HIP_TRY(hipMemcpy2DAsync(flow_dv, p->pitch_bytes, ksi, p->pitch_bytes, p->width * sizeof(float), p->height,
-                                        hipMemcpyDeviceToDevice, ctx->stream));
+        for (unsigned b = 0; b < ctx->batch_count; ++b) {
+            const size_t off = b * ctx->batch_stride_floats;
+            FLOW2D_HIP_TRY(hipMemcpy2DAsync(flow_du + off, p->pitch_bytes, phi + off, p->pitch_bytes,
+                                            p->width * sizeof(float), p->height, hipMemcpyDeviceToDevice, ctx->stream));
+            FLOW2D_HIP_TRY(hipMemcpy2DAsync(flow_dv + off, p->pitch_bytes, ksi + off, p->pitch_bytes,
+                                            p->width * sizeof(float), p->height, hipMemcpyDeviceToDevice, ctx->stream));
+        }
         source = 0;
     }
     if (one_per_outer && source == 1) {

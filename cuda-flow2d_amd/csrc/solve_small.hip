@@ -303,6 +303,17 @@ int launch_small_level(flow2d_context* ctx, int constancy, const float* f0, cons
                        float e_smooth, float e_data, size_t outer, size_t inner, float* out_du, float* out_dv)
 {
     if (!small_level_supports(w, h)) return FLOW2D_ERR_UNSUPPORTED;
+    if (ctx->batch_count > 1) {  // one workgroup per instance, one launch each
+        const unsigned n = ctx->batch_count;
+        const size_t s = ctx->batch_stride_floats;
+        ctx->batch_count = 1;
+        int st = FLOW2D_OK;
+        for (unsigned b = 0; b < n && st == FLOW2D_OK; ++b)
+            st = launch_small_level(ctx, constancy, f0 + b * s, f1 + b * s, u + b * s, v + b * s, w, h, pitch_bytes, hx, hy,
+                                    alpha, e_smooth, e_data, outer, inner, out_du + b * s, out_dv + b * s);
+        ctx->batch_count = n;
+        return st;
+    }
     SmallArgs a{f0, f1, u, v, out_du, out_dv, (int)w, (int)h, (int)(pitch_bytes / 4), (int)outer, (int)inner,
                 hx, hy, alpha, e_smooth, e_data, 0, 0};
     const dim3 block(kMaxSide, 1024 / kMaxSide);

@@ -38,6 +38,7 @@ struct TileArgs {
     int inner;
     int zero_increment;  // first outer iteration of a level: du = dv = 0, the planes are not read
     float hx, hy, alpha, e_smooth, e_data;
+    unsigned long long batch_stride;  // floats between the instances of a batched launch (blockIdx.z)
 };
 
 // GRAD: 0 brightness constancy (solve_2d), 1 gradient constancy with the reference's 16x8 block rule (solve_2d_grad),
@@ -54,6 +55,10 @@ __global__ __launch_bounds__(kThreads, 8) void tile_outer_kernel(TileArgs a)
     constexpr int PPT = (RN + kThreads - 1) / kThreads;  // pixels per thread
     constexpr int kPlanes = GRAD ? 10 : 7;
     __shared__ float lds[kPlanes * RN];
+    {
+        const size_t off = static_cast<size_t>(blockIdx.z) * static_cast<size_t>(a.batch_stride);
+        a.f0 += off, a.f1 += off, a.u += off, a.v += off, a.du += off, a.dv += off, a.out_du += off, a.out_dv += off;
+    }
     float* const P_u = lds + 0 * RN;   // later: ping (u + du^k)
     float* const P_v = lds + 1 * RN;   //        ping (v + dv^k)
     float* const P_du = lds + 2 * RN;  // later: pong
@@ -293,7 +298,8 @@ int launch_tiled_outer(flow2d_context* ctx, int constancy, const float* f0, cons
 {
     if (!tiled_supports(constancy, inner)) return FLOW2D_ERR_UNSUPPORTED;
     TileArgs a{f0, f1, u, v, du, dv, out_du, out_dv, (int)w, (int)h, (int)(pitch_bytes / 4), (int)inner,
-               zero_increment ? 1 : 0, hx, hy, alpha, e_smooth, e_data};
+               zero_increment ? 1 : 0, hx, hy, alpha, e_smooth, e_data,
+               static_cast<unsigned long long>(ctx->batch_stride_floats)};
     const int grad = constancy == FLOW2D_CONSTANCY_GRADIENT ? 1 : (constancy == FLOW2D_CONSTANCY_GRADIENT_UNTILED ? 2 : 0);
     // Tile size by level size (measured on MI355X, level solve of 10 x 5, Grey / Gradient, ms; fused strips for comparison):
     //            8x8            16x16          32x32          strips
@@ -313,11 +319,11 @@ int launch_tiled_outer(flow2d_context* ctx, int constancy, const float* f0, cons
     static const int variant = std::getenv("FLOW2D_TILE_VARIANT") ? std::atoi(std::getenv("FLOW2D_TILE_VARIANT")) : 0;  // developer knob
     const bool tiny = w * h <= 160 * 160, mid = w * h <= 352 * 352;
     if (variant == 1 || (variant == 0 && tiny))
-        launch_tiles<8, 8, 512>(grad, dim3(div_up(w, 8), div_up(h, 8)), ctx->stream, a);
+        launch_tiles<8, 8, 512>(grad, dim3(div_up(w, 8), div_up(h, 8), ctx->batch_count), ctx->stream, a);
     else if (variant == 2 || (variant == 0 && mid))
-        launch_tiles<16, 16, 1024>(grad, dim3(div_up(w, 16), div_up(h, 16)), ctx->stream, a);
+        launch_tiles<16, 16, 1024>(grad, dim3(div_up(w, 16), div_up(h, 16), ctx->batch_count), ctx->stream, a);
     else
-        launch_tiles<32, 32, 1024>(grad, dim3(div_up(w, 32), div_up(h, 32)), ctx->stream, a);
+        launch_tiles<32, 32, 1024>(grad, dim3(div_up(w, 32), div_up(h, 32), ctx->batch_count), ctx->stream, a);
     FLOW2D_CHECK_LAUNCH();
     return FLOW2D_OK;
 }

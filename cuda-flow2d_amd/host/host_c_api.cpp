@@ -154,12 +154,13 @@ struct flow2d_host_batch {
     OpticalFlowBatch2D batch;
 };
 
-HOST_API flow2d_host_batch* flow2d_host_batch_create(size_t width, size_t height, int constancy, size_t lanes, int device)
+HOST_API flow2d_host_batch* flow2d_host_batch_create(size_t width, size_t height, int constancy, size_t lanes, int device,
+                                                     size_t group_size)
 {
     flow2d_host_batch* h = new (std::nothrow) flow2d_host_batch();
     if (!h) return nullptr;
     DataSize3 size = {width, height, 1};
-    if (!h->batch.Initialize(size, static_cast<DataConstancy>(constancy), lanes, device)) {
+    if (!h->batch.Initialize(size, static_cast<DataConstancy>(constancy), lanes, device, group_size)) {
         delete h;
         return nullptr;
     }
@@ -175,6 +176,7 @@ HOST_API void flow2d_host_batch_destroy(flow2d_host_batch* h)
 
 HOST_API size_t flow2d_host_batch_pitch(flow2d_host_batch* h) { return h ? h->batch.ContainerSize().pitch : 0; }
 HOST_API size_t flow2d_host_batch_lanes(flow2d_host_batch* h) { return h ? h->batch.Lanes() : 0; }
+HOST_API size_t flow2d_host_batch_group_stride(flow2d_host_batch* h) { return h ? h->batch.GroupStrideBytes() : 0; }
 HOST_API flow2d_context* flow2d_host_batch_lane_context(flow2d_host_batch* h, size_t lane)
 {
     return h ? h->batch.LaneContext(lane) : nullptr;

@@ -54,6 +54,11 @@ bool OpticalFlow2D::Initialize(const DataSize3& data_size, DataConstancy data_co
         std::printf("Error: '%s': frames must be at least 4 x 4.\n", GetName());
         return false;
     }
+    if (group_size == 0 || group_size > 64) {
+        std::printf("Error: '%s': group size %zu (1..64).\n", GetName(), group_size);
+        return false;
+    }
+    group_ = group_size;
     dev_container_size_ = data_size;
     dev_container_size_.pitch = 0;
     data_constancy_ = data_constancy;
@@ -68,7 +73,8 @@ bool OpticalFlow2D::InitMemory()
     size_t free_bytes = 0, total_bytes = 0;
     if (CheckFlow2DError(flow2d_mem_info(context_, &free_bytes, &total_bytes), "flow2d_mem_info")) return false;
     const size_t pitch = flow2d_plane_pitch_bytes(dev_container_size_.width);
-    const size_t needed = pitch * dev_container_size_.height * (kContainersCount + 2);  // + the two packed x-pass planes
+    // (+ the two packed x-pass planes; a lock-step group holds every plane group_ containers tall)
+    const size_t needed = pitch * dev_container_size_.height * group_ * (kContainersCount + 2);
     if (!silent)
         std::printf("Available\t:\t%.0fMB / %.0fMB\nNeeded\t\t:\t%.0fMB\n", free_bytes / 1048576.f,
                     total_bytes / 1048576.f, needed / 1048576.f);
@@ -76,7 +82,7 @@ bool OpticalFlow2D::InitMemory()
     for (size_t i = 0; i < kContainersCount; ++i) {
         void* plane = nullptr;
         size_t got_pitch = 0;
-        if (CheckFlow2DError(flow2d_plane_alloc(context_, dev_container_size_.width, dev_container_size_.height,
+        if (CheckFlow2DError(flow2d_plane_alloc(context_, dev_container_size_.width, dev_container_size_.height * group_,
                                                 &plane, &got_pitch),
                              "flow2d_plane_alloc") ||
             got_pitch != pitch) {
@@ -89,8 +95,8 @@ bool OpticalFlow2D::InitMemory()
     for (DevicePtr& packed : packed_frames_) {  // outside the pool: they hold one pair's x-resampled rows of all levels
         void* plane = nullptr;
         size_t got_pitch = 0;
-        if (CheckFlow2DError(flow2d_plane_alloc(context_, dev_container_size_.width, dev_container_size_.height, &plane,
-                                                &got_pitch),
+        if (CheckFlow2DError(flow2d_plane_alloc(context_, dev_container_size_.width, dev_container_size_.height * group_,
+                                                &plane, &got_pitch),
                              "flow2d_plane_alloc") ||
             got_pitch != pitch) {
             std::printf("Error during device memory allocation.");
@@ -198,6 +204,10 @@ bool OpticalFlow2D::ComputeFlowSequenceDevice(const DevicePtr* dev_frames, size_
                                               const DevicePtr* dev_flows_v, OperationParameters& params)
 {
     if (!IsInitialized() || !dev_frames || !dev_flows_u || !dev_flows_v || frame_count < 2) return false;
+    if (group_ > 1) {
+        std::printf("Error: '%s': sequences and lock-step groups do not combine.\n", GetName());
+        return false;
+    }
     for (size_t k = 0; k < frame_count; ++k)
         if (!dev_frames[k] || (k + 1 < frame_count && (!dev_flows_u[k] || !dev_flows_v[k]))) return false;
     float gaussian_sigma = 0.f;
@@ -266,6 +276,10 @@ void OpticalFlow2D::ComputeFlow(Data2D& frame_0, Data2D& frame_1, Data2D& flow_u
 {
     last_run_ok_ = false;
     if (!IsInitialized()) return;
+    if (group_ > 1) {
+        std::printf("Error: '%s': ComputeFlow takes one pair; lock-step groups go through ComputeFlowDevice.\n", GetName());
+        return;
+    }
     const size_t W = dev_container_size_.width, H = dev_container_size_.height;
     if (frame_0.Width() != W || frame_0.Height() != H || frame_1.Width() != W || frame_1.Height() != H ||
         flow_u.Width() != W || flow_u.Height() != H || flow_v.Width() != W || flow_v.Height() != H) {
@@ -375,6 +389,10 @@ bool OpticalFlow2D::QueuePair(DevicePtr dev_frame_0, DevicePtr dev_frame_1, Devi
                               DevicePtr dev_flow_v, OperationParameters& params)
 {
     const size_t bytes = dev_container_size_.pitch * dev_container_size_.height;
+    // a lock-step group: from here to the end of the run every launch, memset and device copy of this context acts on
+    // all group_ pairs (instance g of every plane, pool and caller alike, GroupStrideBytes() * g behind its pointer)
+    if (group_ > 1 && CheckFlow2DError(flow2d_context_set_batch(context_, group_, GroupStrideBytes()), "flow2d_context_set_batch"))
+        return false;
     dev_frame_0_ = Acquire();
     dev_frame_1_ = Acquire();
     dev_flow_u_ = Acquire();
@@ -401,6 +419,7 @@ bool OpticalFlow2D::QueuePair(DevicePtr dev_frame_0, DevicePtr dev_frame_1, Devi
     Release(dev_frame_1_);
     Release(dev_flow_u_);
     Release(dev_flow_v_);
+    if (group_ > 1) flow2d_context_set_batch(context_, 1, 0);
     return ok;
 }
 

@@ -86,6 +86,15 @@ public:
     // several hundred launches.  Ignored while timing_mode != 0 (events are not captured).
     bool use_graph = false;
 
+    // Lock-step groups of independent pairs (set BEFORE Initialize; 1 = off).  Every plane of the pool becomes
+    // `group_size` containers tall and ComputeFlowDevice computes group_size pairs at once: pair g of each of the four
+    // caller planes lives GroupStrideBytes() * g behind the pointer passed (tall containers, pairs one below the other).
+    // Every launch then holds the work of the whole group (flow2d_context_set_batch), so a level of a mid-size frame
+    // fills the chip and the launch-bound coarse levels cost one launch per group instead of one per pair; each pair's
+    // flow is bit-identical to its own ComputeFlowDevice.  Not available for ComputeFlow (host images) and sequences.
+    size_t group_size = 1;
+    size_t GroupStrideBytes() const { return dev_container_size_.pitch * dev_container_size_.height; }
+
     const DataSize3& ContainerSize() const { return dev_container_size_; }
     // Device time of the last ComputeFlow (events around upload..download), milliseconds.
     float LastTotalMs() const { return last_total_ms_; }
@@ -112,6 +121,7 @@ private:
 
     static constexpr size_t kContainersCount = 12;  // optical_flow_2d.h:45 of the reference
     DataSize3 dev_container_size_{0, 0, 0};
+    size_t group_ = 1;  // group_size as it was at Initialize
     std::vector<DevicePtr> all_planes_;
     std::vector<DevicePtr> free_planes_;
     DevicePtr dev_frame_0_ = 0, dev_frame_1_ = 0, dev_flow_u_ = 0, dev_flow_v_ = 0;  // valid inside a run

@@ -8,9 +8,11 @@ OpticalFlowBatch2D::OpticalFlowBatch2D() = default;
 
 OpticalFlowBatch2D::~OpticalFlowBatch2D() { Destroy(); }
 
-bool OpticalFlowBatch2D::Initialize(const DataSize3& data_size, DataConstancy data_constancy, size_t lanes, int device)
+bool OpticalFlowBatch2D::Initialize(const DataSize3& data_size, DataConstancy data_constancy, size_t lanes, int device,
+                                    size_t group_size)
 {
     Destroy();
+    group_size_ = group_size;
     if (lanes == 0 || lanes > 64) {
         std::printf("Error: OpticalFlowBatch2D: %zu lanes (1..64).\n", lanes);
         return false;
@@ -27,6 +29,7 @@ bool OpticalFlowBatch2D::Initialize(const DataSize3& data_size, DataConstancy da
         {
             ScopedDeviceContext current(lane->context);
             lane->flow.silent = silent;
+            lane->flow.group_size = group_size;
             ok = lane->flow.Initialize(data_size, data_constancy);
             if (!ok) lane->flow.Destroy();
         }
@@ -74,6 +77,11 @@ void OpticalFlowBatch2D::Destroy()
 DataSize3 OpticalFlowBatch2D::ContainerSize() const
 {
     return lanes_.empty() ? DataSize3{0, 0, 0} : lanes_.front()->flow.ContainerSize();
+}
+
+size_t OpticalFlowBatch2D::GroupStrideBytes() const
+{
+    return lanes_.empty() ? 0 : lanes_.front()->flow.GroupStrideBytes();
 }
 
 flow2d_context* OpticalFlowBatch2D::LaneContext(size_t lane) const

@@ -29,7 +29,11 @@ public:
 
     // `lanes` contexts (one stream each) on `device`, each with an OpticalFlow2D of `data_size` and its plane pool
     // (12 + 2 planes per lane).  false when the device, a stream or the memory is not to be had.
-    bool Initialize(const DataSize3& data_size, DataConstancy data_constancy, size_t lanes, int device = 0);
+    // group_size > 1: every lane computes lock-step groups of that many pairs (OpticalFlow2D::group_size): an entry of
+    // ComputeFlowBatchDevice is then a group, its four planes tall containers with pair g GroupStrideBytes() * g behind
+    // the pointer.  Mid-size frames (1080p, 1024^2) gain a third in throughput: one launch per level holds the group.
+    bool Initialize(const DataSize3& data_size, DataConstancy data_constancy, size_t lanes, int device = 0,
+                    size_t group_size = 1);
 
     // `count` pairs already in pitched device containers of ContainerSize() (any allocation of this device):
     // dev_frames_*[k] are read, dev_flows_*[k] written.  Queued, not synchronised.  false on a bad argument or when
@@ -46,6 +50,8 @@ public:
 
     size_t Lanes() const { return lanes_.size(); }
     DataSize3 ContainerSize() const;
+    size_t GroupSize() const { return group_size_; }
+    size_t GroupStrideBytes() const;
     flow2d_context* LaneContext(size_t lane) const;
 
 private:
@@ -54,4 +60,5 @@ private:
         OpticalFlow2D flow;
     };
     std::vector<std::unique_ptr<Lane>> lanes_;
+    size_t group_size_ = 1;
 };

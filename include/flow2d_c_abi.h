@@ -76,6 +76,13 @@ FLOW2D_API int flow2d_context_destroy(flow2d_context* ctx);
 FLOW2D_API int flow2d_context_device(const flow2d_context* ctx, int* device_ordinal);
 FLOW2D_API int flow2d_context_stream(const flow2d_context* ctx, void** hip_stream);
 FLOW2D_API int flow2d_synchronize(flow2d_context* ctx); /* cuStreamSynchronize(NULL), cuda_operation_solve_2d.cpp:291 */
+/* Lock-step batches of independent pairs (no reference counterpart): after flow2d_context_set_batch(ctx, count,
+ * stride_bytes) every launcher, memset and device copy of this context acts on `count` instances of its planes,
+ * instance b at plane pointer + b * stride_bytes (pairs stored one below the other in tall containers; stride a
+ * multiple of 16).  One launch then holds the work of all instances (grid.z), so a level of a mid-size frame fills the
+ * chip and the launch-bound coarse levels cost one launch per batch instead of one per pair.  count = 1 switches it
+ * off (the default).  Results per instance are those of the unbatched call. */
+FLOW2D_API int flow2d_context_set_batch(flow2d_context* ctx, size_t count, size_t stride_bytes);
 /* cuMemGetInfo, optical_flow_2d.cpp:91 */
 FLOW2D_API int flow2d_mem_info(flow2d_context* ctx, size_t* free_bytes, size_t* total_bytes);
 FLOW2D_API int flow2d_device_name(flow2d_context* ctx, char* buf, size_t buf_len);
