@@ -57,9 +57,10 @@ def broadcast_params(values, device=None):
 
 
 def all_gather_fields(local, out=None):
-    """ONE collective for the flow fields of a batch: every rank contributes its block `local` (a tensor
-    [pairs_per_rank, 2, H, W], on the GPU for RCCL) and receives [world, pairs_per_rank, 2, H, W]; with the shard rule
-    of pairs_of_rank, pair k is out[k % world, k // world].  all_gather moves each byte once per receiving rank
+    """ONE collective for the flow fields of a batch: every rank contributes its block `local` (a tensor of any one
+    shape on all ranks -- bench.py: [2, pairs_per_rank, H, W], the u planes then the v planes of the rank's lock-step
+    group; on the GPU for RCCL) and receives [world, *local.shape]; with the shard rule of pairs_of_rank, pair k is
+    rank k % world's entry k // world.  all_gather moves each byte once per receiving rank
     (a ring all-gather over xGMI), unlike a sum-reduction of a dense zero-padded array."""
     import torch
     import torch.distributed as dist
