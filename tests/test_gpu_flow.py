@@ -308,13 +308,13 @@ def test_batch_entry_uneven_pairs_and_lane_offsets(flow2d, oracle, constancy):
         c.close()
 
 
+@pytest.mark.parametrize("w,h,G", [(208, 144, 3), (101, 75, 5)])
 @pytest.mark.parametrize("constancy,sigma,median", [(0, 1.5, 5), (1, 1.5, 5), (0, 0.0, 3), (3, 1.5, 5)])
-def test_lock_step_groups_match_single_pairs(flow2d, oracle, constancy, sigma, median):
+def test_lock_step_groups_match_single_pairs(flow2d, oracle, constancy, sigma, median, w, h, G):
     """OpticalFlow2D::group_size (flow2d_context_set_batch): groups of 3 pairs stored one below the other in tall
     containers, every kernel launched once per group (grid.z); two groups on two lanes, eager and graph-replayed.
     Every pair of every group is bit-identical to the oracle's flow of that pair alone -- Grey, Gradient,
     LogDerivatives (per-instance launches of the single-workgroup kernel), with and without the pre-blur."""
-    w, h, G = 208, 144, 3
     p = (4, 0.5, 3, 5, 35.0, 0.001, 0.001, median, sigma)
     pairs = [oracle.synthetic_pair(w, h, 1.5 * np.cos(k), -1.0 + 0.5 * k, seed=k, noise=True) for k in range(2 * G)]
     if constancy == 3:  # log(I + 1): the CPU libm and the device library differ in the last place; compare with the
