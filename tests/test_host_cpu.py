@@ -318,3 +318,15 @@ def test_ref_host_colour_wheel_ppm_and_magnitude(flow2d, ref_host_golden, tmp_pa
     flow2d.write_outputs(g["flow_u"], g["flow_v"], ppm, amp, 10.0)
     assert open(ppm, "rb").read() == g["ppm_bytes"].tobytes()
     assert np.array_equal(np.fromfile(amp, np.float32).reshape(g["amp"].shape).view(np.uint32), g["amp"].view(np.uint32))
+
+
+def test_host_library_exports_the_batch_entry(flow2d):
+    """The C++ host layer carries the batched path (OpticalFlowBatch2D) and the C-ABI the lock-step batch switch;
+    a batch of zero lanes is refused without touching a device."""
+    host = flow2d.host_lib()
+    for name in ("flow2d_host_batch_create", "flow2d_host_batch_compute", "flow2d_host_batch_synchronize",
+                 "flow2d_host_batch_destroy", "flow2d_host_batch_group_stride", "flow2d_host_batch_use_graph"):
+        assert hasattr(host, name), name
+    assert hasattr(flow2d.hip_lib(), "flow2d_context_set_batch")
+    assert flow2d.hip_lib().flow2d_context_set_batch(None, 2, 4096) == 1  # no context: invalid argument
+    assert not host.flow2d_host_batch_create(64, 64, 0, 0, 0, 1)         # zero lanes
