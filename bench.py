@@ -180,6 +180,30 @@ def reference_gpu_baseline(cfg, f0, f1):
     }
 
 
+def measured_copy_peak(flow2d, local_rank):
+    """Device-to-device copy of 512 MiB (hipMemcpyAsync D2D, read + write counted) on a stream of its own, best of 5:
+    the HBM rate this box reaches on a plain stream, next to the 8 TB/s nominal peak."""
+    c = flow2d.Context(local_rank)
+    try:
+        n = 8192
+        a, b = c.plane(n, 2 * n).fill_bytes(1), c.plane(n, 2 * n)
+        nbytes = a.pitch * 2 * n
+        best = None
+        for _ in range(6):
+            e0, e1 = c.event(), c.event()
+            c.record(e0)
+            if flow2d.hip_lib().flow2d_copy_d2d(c.handle, b.ptr, a.ptr, nbytes) != 0:
+                return None
+            c.record(e1)
+            ms = c.elapsed_ms(e0, e1)
+            best = ms if best is None or ms < best else best
+        return round(2.0 * nbytes / (best * 1e-3) / 1e9, 1)
+    except Exception:  # noqa: BLE001 - informational figure only
+        return None
+    finally:
+        c.close()
+
+
 def load_pmc(workload, algorithm):
     """Per-launch PMC figures of the dominant kernel from the committed rocprofv3 --pmc passes
     (profiles/traffic.json, written by tools/pmc_traffic.py); {} if not measured for this workload."""
@@ -445,6 +469,7 @@ def main():
     elapsed = timed_region(job, batch, torch, args.steps, args.warmup)   # <- the number
     check = output_check(job)
     finest = roofline_sample(job)
+    copy_gbs = measured_copy_peak(flow2d, local_rank) if rank == 0 else None
     first_pair = job.first_pair
     n_lanes = job.n_lanes
     levels_run = int(min(cfg["levels"], flow2d.host_lib().flow2d_host_max_warp_level_static(w, h, cfg["scale"])))
@@ -475,6 +500,7 @@ def main():
             {0: "solve_2d", 1: "solve_2d_grad", 3: "solve_2d_log"}.get(cfg["constancy"], "gradient-untiled"),
             "achieved": round(achieved, 1),
             "peak": HBM_PEAK_GBS,
+            "measured_copy_gbs": copy_gbs,  # a 512 MiB device-to-device copy on this box (read + write), for scale
             "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4),
             "traffic": phys,
