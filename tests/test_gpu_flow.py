@@ -98,6 +98,34 @@ def test_synthetic_pairs_parity(flow2d, oracle, make_flow, w, h, levels, scale, 
     assert np.array_equal(u, ou) and np.array_equal(v, ov)
 
 
+def _random_cases(count, seed):
+    """Deterministic spread of pipeline configurations: odd sizes, every scale from shallow to deep pyramids, 1-7 sweeps
+    (beyond 5: chunked fused launches), the three median widths, with and without the pre-blur, alpha over two decades."""
+    rng = np.random.default_rng(seed)
+    cases = []
+    for _ in range(count):
+        w, h = int(rng.integers(9, 420)), int(rng.integers(9, 300))
+        constancy = int(rng.choice([0, 0, 1, 2]))
+        cases.append((w, h, int(rng.integers(1, 12)), float(np.float32(rng.uniform(0.35, 0.95))), int(rng.integers(1, 4)),
+                      int(rng.integers(1, 8)), int(rng.choice([3, 5, 7])), float(rng.choice([0.0, 0.45, 1.0, 1.5, 2.2])),
+                      constancy, float(np.float32(10.0 ** rng.uniform(0.0, 2.0))), int(rng.integers(0, 1 << 30))))
+    return cases
+
+
+@pytest.mark.parametrize("w,h,levels,scale,outer,inner,median,sigma,constancy,alpha,seed", _random_cases(28, 20261003))
+def test_randomized_pipelines_match_the_oracle(flow2d, oracle, make_flow, w, h, levels, scale, outer, inner, median, sigma,
+                                               constancy, alpha, seed):
+    """Whole ComputeFlow runs on configurations nobody hand-picked (AUTO therefore mixes the tiled, fused, chunked-fused,
+    per-sweep and single-workgroup kernels across the levels of one run): bit-identical to the oracle.  Gradient cases
+    are compared on whatever level sizes come out -- the oracle defines the reference's unwritten shared-memory slot
+    the same way the product does."""
+    f0, f1 = oracle.synthetic_pair(w, h, 1.0 + (seed % 7) * 0.3, -1.0 + (seed % 5) * 0.4, seed=seed, noise=True)
+    flow = make_flow(w, h, constancy)
+    u, v, _ = flow.compute_flow(f0, f1, flow.params(levels, scale, outer, inner, alpha, 0.001, 0.001, median, sigma))
+    ou, ov, _ = oracle.compute_flow(f0, f1, levels, scale, outer, inner, alpha, 0.001, 0.001, median, sigma, constancy)
+    assert np.array_equal(u, ou, equal_nan=True) and np.array_equal(v, ov, equal_nan=True)
+
+
 def test_device_resident_entry_matches_host_entry(flow2d, oracle, make_flow, ctx):
     w, h = 200, 120
     f0, f1 = oracle.synthetic_pair(w, h, 2.0, 1.0, seed=3, noise=True)
