@@ -143,6 +143,13 @@ FLOWS = [
     ("syn1024x1024", (5, 0.5, 10, 5, 35.0, 0.001, 0.001, 5, 1.5), 0),  # config 2 at full size
     ("syn1024x512", (4, 0.5, 5, 5, 35.0, 0.001, 0.001, 5, 1.5), 1),
     ("syn100x70", (6, 0.8, 2, 3, 3.5, 0.001, 0.001, 3, 0.45), 0),
+    # odd sizes and parameters nobody tuned (Grey: any size; the block-rule data terms on 16x8 multiples at every level)
+    ("syn333x207", (7, 0.75, 2, 4, 12.0, 0.001, 0.001, 7, 1.0), 0),
+    ("syn61x149", (9, 0.6, 6, 2, 8.0, 0.001, 0.001, 3, 0.0), 0),
+    ("syn417x95", (5, 0.9, 2, 6, 5.0, 0.002, 0.0005, 5, 2.2), 0),
+    ("syn800x720", (5, 0.5, 3, 5, 35.0, 0.001, 0.001, 5, 1.5), 0),     # 800x720 runs the 32x32 tiles, 400x360 too
+    ("syn768x512", (3, 0.5, 3, 5, 35.0, 0.001, 0.001, 5, 1.5), 1),
+    ("syn384x256", (3, 0.5, 3, 3, 0.0005, 0.001, 0.001, 3, 0.45), 3),
 ]
 
 
