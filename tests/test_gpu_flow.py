@@ -389,6 +389,38 @@ def test_lock_step_groups_match_single_pairs(flow2d, oracle, constancy, sigma, m
         c.close()
 
 
+@pytest.mark.parametrize("what", ["sor", "per-sweep", "seven sweeps"])
+def test_lock_step_groups_on_the_unbatched_kernels(flow2d, oracle, what):
+    """The solver paths that have no batched kernel run once per instance of a group (red-black SOR, the per-sweep
+    kernels) or carry their continuation planes along (more than five sweeps: chunked fused launches on the larger
+    level): each pair of a group of three still equals the oracle."""
+    w, h, G = 672, 240, 3  # 672 x 240 and 336 x 120: the finest level goes to the strips when there are > 5 sweeps
+    inner, kw, okw = 4, {}, {}
+    if what == "sor":
+        kw, okw = {"sor_omega": 1.4}, {"sor_omega": 1.4}
+    elif what == "per-sweep":
+        kw = {"algorithm": flow2d.SOLVER_PER_SWEEP}
+    else:
+        inner = 7
+    p = (2, 0.5, 2, inner, 35.0, 0.001, 0.001, 5, 1.5)
+    pairs = [oracle.synthetic_pair(w, h, 1.0 + 0.5 * k, -0.5 * k, seed=40 + k, noise=True) for k in range(G)]
+    c = flow2d.Context(0)
+    batch = flow2d.OpticalFlowBatch(w, h, flow2d.GREY, lanes=1, group_size=G)
+    try:
+        planes = [c.plane(w, h * G, np.vstack([q[0] for q in pairs])), c.plane(w, h * G, np.vstack([q[1] for q in pairs])),
+                  c.plane(w, h * G), c.plane(w, h * G)]
+        batch.use_graph(False)
+        batch.compute_flow_batch_device(*[[q.ptr] for q in planes], batch.params(*p, **kw))
+        batch.synchronize()
+        u, v = planes[2].download(), planes[3].download()
+        for k, (f0, f1) in enumerate(pairs):
+            ou, ov, _ = oracle.compute_flow(f0, f1, *p, flow2d.GREY, **okw)
+            assert np.array_equal(u[k * h:(k + 1) * h], ou) and np.array_equal(v[k * h:(k + 1) * h], ov), k
+    finally:
+        batch.close()
+        c.close()
+
+
 def test_config5_full_size_parity(flow2d, oracle, make_flow):
     """Config 5 as specified (8192^2, (12, -7) px shift, all 12 levels, 10 x 5 sweeps, median 5): every pixel of the flow
     bit-identical to the oracle (OpenMP on the box's cores: about half a minute and 3 GB of host memory)."""
