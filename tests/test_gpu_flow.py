@@ -421,6 +421,30 @@ def test_lock_step_groups_on_the_unbatched_kernels(flow2d, oracle, what):
         c.close()
 
 
+def test_sequence_as_a_lock_step_group(flow2d, oracle):
+    """An image sequence stored as one tall container needs no entry of its own in group mode: the group's frame-1 plane
+    is its frame-0 plane one container further down, so the G flows of G + 1 consecutive frames are one
+    ComputeFlowDevice call (frames are only read).  Each flow equals the oracle's flow of that pair."""
+    w, h, G = 240, 136, 4
+    p = (4, 0.5, 3, 5, 35.0, 0.001, 0.001, 5, 1.5)
+    frames = [oracle.synthetic_pair(w, h, 0.8 * t, -0.4 * t, seed=9, noise=False)[1] for t in range(G + 1)]
+    c = flow2d.Context(0)
+    batch = flow2d.OpticalFlowBatch(w, h, flow2d.GREY, lanes=1, group_size=G)
+    try:
+        tall = c.plane(w, h * (G + 1), np.vstack(frames))
+        pu, pv = c.plane(w, h * G), c.plane(w, h * G)
+        batch.compute_flow_batch_device([tall.ptr], [tall.ptr + batch.group_stride], [pu.ptr], [pv.ptr], batch.params(*p))
+        batch.synchronize()
+        u, v = pu.download(), pv.download()
+        assert np.array_equal(tall.download(), np.vstack(frames))  # the sequence is left untouched
+        for k in range(G):
+            ou, ov, _ = oracle.compute_flow(frames[k], frames[k + 1], *p)
+            assert np.array_equal(u[k * h:(k + 1) * h], ou) and np.array_equal(v[k * h:(k + 1) * h], ov), k
+    finally:
+        batch.close()
+        c.close()
+
+
 def test_config5_full_size_parity(flow2d, oracle, make_flow):
     """Config 5 as specified (8192^2, (12, -7) px shift, all 12 levels, 10 x 5 sweeps, median 5): every pixel of the flow
     bit-identical to the oracle (OpenMP on the box's cores: about half a minute and 3 GB of host memory)."""
