@@ -192,9 +192,14 @@ int flow2d_memset_2d(flow2d_context* ctx, void* dev_ptr, size_t pitch_bytes, int
     FLOW2D_ENTER(ctx);
     if (!dev_ptr || width_bytes > pitch_bytes) return FLOW2D_ERR_INVALID_ARGUMENT;
     if (width_bytes == 0 || height == 0) return FLOW2D_OK;
+    const size_t stride_bytes = ctx->batch_stride_floats * sizeof(float);
+    if (ctx->batch_count > 1 && stride_bytes == pitch_bytes * height) {  // whole containers, one below the other: one call
+        FLOW2D_HIP_TRY(hipMemset2DAsync(dev_ptr, pitch_bytes, byte_value, width_bytes, height * ctx->batch_count, ctx->stream));
+        return FLOW2D_OK;
+    }
     for (unsigned b = 0; b < ctx->batch_count; ++b)
-        FLOW2D_HIP_TRY(hipMemset2DAsync(static_cast<char*>(dev_ptr) + b * ctx->batch_stride_floats * sizeof(float),
-                                        pitch_bytes, byte_value, width_bytes, height, ctx->stream));
+        FLOW2D_HIP_TRY(hipMemset2DAsync(static_cast<char*>(dev_ptr) + b * stride_bytes, pitch_bytes, byte_value, width_bytes,
+                                        height, ctx->stream));
     return FLOW2D_OK;
 }
 
