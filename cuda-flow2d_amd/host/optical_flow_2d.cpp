@@ -354,7 +354,7 @@ std::vector<unsigned char> GraphKey(DevicePtr a, DevicePtr b, DevicePtr c, Devic
 void OpticalFlow2D::DropGraphs()
 {
     for (auto& kv : graphs_)
-        if (kv.second && context_) flow2d_graph_destroy(context_, kv.second);
+        if (kv.second.exec && context_) flow2d_graph_destroy(context_, kv.second.exec);
     graphs_.clear();
 }
 
@@ -368,9 +368,14 @@ bool OpticalFlow2D::ComputeFlowDevice(DevicePtr dev_frame_0, DevicePtr dev_frame
     auto it = graphs_.find(key);
     if (it == graphs_.end()) {
         if (graphs_.size() >= kMaxGraphs) {
-            // the recorded graphs may still be running on the stream (replays are not synchronised by contract)
+            // full: the least recently replayed graph goes.  It may still be running on the stream (replays are not
+            // synchronised by contract), so the stream is drained first.
             flow2d_synchronize(context_);
-            DropGraphs();
+            auto oldest = graphs_.begin();
+            for (auto g = graphs_.begin(); g != graphs_.end(); ++g)
+                if (g->second.last_use < oldest->second.last_use) oldest = g;
+            if (oldest->second.exec) flow2d_graph_destroy(context_, oldest->second.exec);
+            graphs_.erase(oldest);
         }
         if (CheckFlow2DError(flow2d_capture_begin(context_), "flow2d_capture_begin")) return false;
         const bool queued = QueuePair(dev_frame_0, dev_frame_1, dev_flow_u, dev_flow_v, params);
@@ -380,9 +385,10 @@ bool OpticalFlow2D::ComputeFlowDevice(DevicePtr dev_frame_0, DevicePtr dev_frame
             if (exec) flow2d_graph_destroy(context_, exec);
             return false;
         }
-        it = graphs_.emplace(std::move(key), exec).first;
+        it = graphs_.emplace(std::move(key), RecordedGraph{exec, 0}).first;
     }
-    return !CheckFlow2DError(flow2d_graph_launch(context_, it->second), "flow2d_graph_launch");
+    it->second.last_use = ++graph_clock_;
+    return !CheckFlow2DError(flow2d_graph_launch(context_, it->second.exec), "flow2d_graph_launch");
 }
 
 bool OpticalFlow2D::QueuePair(DevicePtr dev_frame_0, DevicePtr dev_frame_1, DevicePtr dev_flow_u,

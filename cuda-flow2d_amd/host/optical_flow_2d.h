@@ -148,7 +148,12 @@ private:
     float last_total_ms_ = 0.f;
     bool last_run_ok_ = false;
     // recorded pyramids, keyed by the caller buffers and parameters they were recorded for
-    std::map<std::vector<unsigned char>, void*> graphs_;
+    struct RecordedGraph {
+        void* exec = nullptr;
+        unsigned long long last_use = 0;
+    };
+    std::map<std::vector<unsigned char>, RecordedGraph> graphs_;
+    unsigned long long graph_clock_ = 0;
     static constexpr size_t kMaxGraphs = 32;
 
     CudaOperationAdd2D cuop_add_;

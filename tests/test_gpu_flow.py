@@ -544,6 +544,31 @@ def test_graph_replay_matches_eager(flow2d, oracle, ctx):
         flow.close()
 
 
+def test_graph_cache_evicts_the_least_recently_used(flow2d, oracle, ctx):
+    """More (buffers, parameters) combinations than the cache of recorded pyramids holds (32): the least recently replayed
+    graph goes, one at a time, and whatever is replayed or re-recorded afterwards still computes the right flow."""
+    w, h = 64, 48
+    flow = flow2d.OpticalFlow(w, h, 0, ctx=ctx)
+    try:
+        f0, f1 = oracle.synthetic_pair(w, h, 1.0, 0.5, seed=2, noise=True)
+        planes = [ctx.plane(w, h, f0), ctx.plane(w, h, f1), ctx.plane(w, h), ctx.plane(w, h)]
+        ptrs = [pl.ptr for pl in planes]
+        flow.use_graph(True)
+        want = {}
+        for rnd in range(2):
+            for k in range(36):  # 36 parameter sets through a cache of 32, twice
+                alpha = 5.0 + k
+                if k not in want:
+                    want[k] = oracle.compute_flow(f0, f1, 3, 0.5, 1, 2, alpha, 0.001, 0.001, 3, 0.45)[:2]
+                planes[2].fill_bytes(0x55)
+                planes[3].fill_bytes(0x55)
+                flow.compute_flow_device(*ptrs, flow.params(3, 0.5, 1, 2, alpha, 0.001, 0.001, 3, 0.45))
+                ctx.synchronize()
+                assert np.array_equal(planes[2].download(), want[k][0]) and np.array_equal(planes[3].download(), want[k][1]), (rnd, k)
+    finally:
+        flow.close()
+
+
 def test_graph_replay_with_chunked_fused_solver(flow2d, oracle, ctx):
     """7 sweeps per outer iteration at a fused-kernel level: two launches per outer iteration and, with one outer
     iteration, the hand-over copy out of the third plane pair -- all inside a recorded graph."""
