@@ -372,7 +372,19 @@ def roofline_sample(job, passes=3):
         for _ in range(passes):
             flow.compute_flow_device(f0.ptr, f1.ptr, u.ptr, v.ptr, job.params, 2)
         c.synchronize()
-        return [r for r in flow.level_timings() if (r[0], r[1]) == (w, h)]
+        finest = [r for r in flow.level_timings() if (r[0], r[1]) == (w, h)]
+        # one pair alone on the GPU, launch to done, replayed from its graph (no timing events inside): the latency
+        # a single pair sees, as opposed to the pipelined rate of the timed region
+        flow.use_graph(True)
+        latency = None
+        for _ in range(4):  # the first call records
+            e0, e1 = c.event(), c.event()
+            c.record(e0)
+            flow.compute_flow_device(f0.ptr, f1.ptr, u.ptr, v.ptr, job.params, 0)
+            c.record(e1)
+            ms = c.elapsed_ms(e0, e1)
+            latency = ms if latency is None or ms < latency else latency
+        return finest, latency
     finally:
         flow.close()
         c.close()
@@ -468,7 +480,7 @@ def main():
     free_b, total_b = job.ctx.mem_info()
     elapsed = timed_region(job, batch, torch, args.steps, args.warmup)   # <- the number
     check = output_check(job)
-    finest = roofline_sample(job)
+    finest, pair_latency_ms = roofline_sample(job)
     copy_gbs = measured_copy_peak(flow2d, local_rank) if rank == 0 else None
     first_pair = job.first_pair
     n_lanes = job.n_lanes
@@ -550,6 +562,7 @@ def main():
                 "timed_region": "graph-replayed steps only; output check, roofline sample, batch leg and baselines follow it",
             },
             "pairs_per_s": round(pairs_total / elapsed, 3),
+            "single_pair_latency_ms": round(pair_latency_ms, 3),  # one pair alone on the GPU, graph replay, launch to done
             "finest_level": {
                 "solve_ms": round(solve_ms, 4),
                 "mpix_iters_per_s": round(px_iters / (solve_ms * 1e-3) / 1e6, 1),
