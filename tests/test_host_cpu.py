@@ -330,3 +330,15 @@ def test_host_library_exports_the_batch_entry(flow2d):
     assert hasattr(flow2d.hip_lib(), "flow2d_context_set_batch")
     assert flow2d.hip_lib().flow2d_context_set_batch(None, 2, 4096) == 1  # no context: invalid argument
     assert not host.flow2d_host_batch_create(64, 64, 0, 0, 0, 1)         # zero lanes
+
+
+def test_plain_c_client_links_and_runs_without_a_device(flow2d, tmp_path):
+    """tests/c/abi_link.c: a C99 program against include/flow2d_c_abi.h and libflow2d_hip.so (no C++ in between)."""
+    exe = tmp_path / "abi_link"
+    csrc = os.path.join(ROOT, "cuda-flow2d_amd", "csrc")
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "c", "abi_link.c"), "-L", csrc, "-lflow2d_hip",
+                           "-Wl,-rpath," + csrc, "-o", str(exe)])
+    out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, (out.returncode, out.stdout, out.stderr)
+    assert "flow2d C-ABI v1" in out.stdout
