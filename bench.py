@@ -402,17 +402,24 @@ def batch_leg(flow2d, batch, torch, args, rank, local_rank, world):
     steps = max(3, min(args.steps, 20))
     elapsed = timed_region(job, batch, torch, steps, 1)
     check = output_check(job)
-    # gather: every rank's [2, 8, H, pitch] block -> [world, 2, 8, H, pitch] on every rank; pair k = [k % world, :, k // world]
-    torch.cuda.synchronize()
-    gathered = batch.all_gather_fields(local)
-    batch.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    gathered = batch.all_gather_fields(local, out=gathered)
-    torch.cuda.synchronize()
-    gather_s = batch.max_over_ranks(time.perf_counter() - t0)
+    # gather: every rank's [2, 8, H, pitch] block -> [world, 2, 8, H, pitch]; pair k = [k % world, :, k // world].  Two forms,
+    # each run once untimed and once timed: to every rank (all_gather) and to rank 0 only (gather: what BASELINE.json asks)
+    def timed(collective, out):
+        torch.cuda.synchronize()
+        batch.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        out = collective(local, out=out)
+        torch.cuda.synchronize()
+        return out, batch.max_over_ranks(time.perf_counter() - t0)
+
+    gathered, _ = timed(batch.all_gather_fields, None)
+    gathered, all_gather_s = timed(batch.all_gather_fields, gathered)
+    at_root, _ = timed(batch.gather_fields_to_root, None)
+    at_root, gather_s = timed(batch.gather_fields_to_root, at_root)
     mine_ok = bool(torch.equal(gathered[rank], local))
     nonzero = bool((gathered.abs().amax(dim=(3, 4)) > 0).all().item())
+    root_ok = bool(torch.equal(at_root, gathered)) if rank == 0 else at_root is None
     job.close()
     pairs = steps * n_local * world
     px_iters = float(w) * h * cfg["outer"] * cfg["inner"]
@@ -422,11 +429,71 @@ def batch_leg(flow2d, batch, torch, args, rank, local_rank, world):
         "pairs_per_s": round(pairs / elapsed, 2), "ms_per_step": round(elapsed / steps * 1e3, 3),
         "streams_per_gpu": job.n_lanes, "batch_mode": "lock-step group of %d pairs per launch" % job.group if job.grouped
         else "pairs spread over the lanes",
-        "gather": {"collective": "all_gather_into_tensor (RCCL)" if world > 1 else "none (one process)",
+        "gather": {"collective": "gather to rank 0 (RCCL grouped send/recv)" if world > 1 else "none (one process)",
                    "bytes_per_rank": int(local.numel() * 4), "ms": round(gather_s * 1e3, 3),
-                   "own_block_intact": mine_ok, "every_pair_present": nonzero},
+                   "all_gather_into_tensor_ms": round(all_gather_s * 1e3, 3),
+                   "own_block_intact": mine_ok, "every_pair_present": nonzero, "root_equals_all_gather": root_ok},
         "output_check": check,
     }
+
+
+def spawn_ranks(args):
+    """`python bench.py --gpus N` from a plain shell (no WORLD_SIZE in the environment): start the N ranks as FRESH child
+    processes -- `python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py <same arguments>` -- before
+    this process has made any HIP / torch.cuda call, let rank 0's JSON line through (the children inherit stdout) and
+    exit with the launcher's status.  Nothing is exec'd and nothing is re-launched after GPU initialisation."""
+    import socket
+    import subprocess
+
+    if not args.plumbing_check:
+        import torch  # device_count() alone does not initialise the GPU on this image
+        visible = torch.cuda.device_count()
+        if visible < args.gpus:
+            sys.exit("bench.py --gpus %d: %d HIP device(s) visible; the flow2d path has no CPU fallback" %
+                     (args.gpus, visible))
+    with socket.socket() as s:  # a free rendezvous port on the loopback interface
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL's intra-node transport on this host driver
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // args.gpus)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.exit(subprocess.run(cmd, env=env).returncode)
+
+
+def plumbing_check(batch, args):
+    """--plumbing-check: the rank plumbing of a multi-GPU run WITHOUT the flow computation, on the gloo backend and host
+    tensors, so that it runs on a box without GPUs (tests/test_batch_gloo.py runs `bench.py --gpus 2 --plumbing-check`
+    from a plain shell): launcher -> process group -> parameter broadcast -> barriers around a timed region -> max
+    over ranks -> all_gather and gather-to-root of a stand-in field block.  Prints a line that carries no metric: it
+    says that the ranks started and talked, nothing about the product."""
+    import torch
+
+    rank, _, world = batch.init(backend="gloo")
+    cfg = WORKLOADS[args.workload]
+    block = batch.broadcast_params([cfg["levels"], cfg["scale"], cfg["outer"], cfg["inner"], cfg["alpha"]] if rank == 0
+                                   else [0, 0, 0, 0, 0])
+    owned = batch.pairs_of_rank(cfg["pairs_per_rank"] * world, rank, world)
+    batch.barrier()
+    t0 = time.perf_counter()
+    time.sleep(0.01 * (rank + 1))
+    batch.barrier()
+    slowest = batch.max_over_ranks(time.perf_counter() - t0)
+    local = torch.full((2, len(owned), 4, 8), float(rank + 1))  # the shape of a rank's flow block: [2, pairs, H, pitch]
+    everywhere = batch.all_gather_fields(local)
+    at_root = batch.gather_fields_to_root(local)
+    expect = torch.arange(1, world + 1, dtype=torch.float32).view(world, 1, 1, 1, 1).expand(world, *local.shape)
+    ok = bool(torch.equal(everywhere, expect)) and (rank != 0 or bool(torch.equal(at_root, expect))) and \
+        (rank == 0 or at_root is None)
+    oks = batch.gather_digests({rank: float(ok)}, world)
+    if rank == 0:
+        print(json.dumps({"plumbing_check": True, "n_gpus": world, "backend": "gloo", "params": block,
+                          "pairs_of_rank_0": owned, "slowest_rank_s": round(slowest, 4),
+                          "collectives_ok": bool(all(v == 1.0 for v in oks))}))
+    batch.shutdown()
+    if not ok:
+        sys.exit("bench.py --plumbing-check: a collective delivered the wrong data on rank %d" % rank)
 
 
 def main():
@@ -447,11 +514,18 @@ def main():
     ap.add_argument("--batch-mode", choices=["groups", "lanes"], default="groups",
                     help="batched workloads: all pairs of a step as one lock-step group (every kernel launched once for "
                          "the group) or spread one by one over the lanes")
+    ap.add_argument("--plumbing-check", action="store_true",
+                    help="rank plumbing only (launcher, process group on gloo, broadcast, barriers, gathers) without the "
+                         "flow computation; needs no GPU and prints no metric")
     args = ap.parse_args()
     cfg = WORKLOADS[args.workload]
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        spawn_ranks(args)  # does not return
 
-    flow2d = importlib.import_module("cuda-flow2d_amd")
     batch = importlib.import_module("cuda-flow2d_amd.batch")
+    if args.plumbing_check:
+        return plumbing_check(batch, args)
+    flow2d = importlib.import_module("cuda-flow2d_amd")
     if not (os.path.exists(flow2d.HIP_LIB_PATH) and os.path.exists(flow2d.HOST_LIB_PATH)):
         if int(os.environ.get("LOCAL_RANK", "0")) == 0:
             flow2d.build()  # checkout without the in-tree libraries (normally built by __graft_entry__.build())
@@ -462,11 +536,7 @@ def main():
                 time.sleep(0.5)
             time.sleep(1.0)
     rank, local_rank, world = batch.world_info()
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run (WORLD_SIZE=%d)" %
-                     (args.gpus, world))
-        args.gpus = world
+    args.gpus = world  # launched by torch.distributed.run: the launcher's world size is the number of GPUs
 
     import torch  # device plumbing only: barrier, device-wide synchronise, max-over-ranks, the RCCL gather buffer
 

@@ -77,6 +77,7 @@ def hip_lib():
         L.flow2d_status_string.argtypes = [i]
         L.flow2d_last_error.restype = C.c_char_p
         L.flow2d_device_count.argtypes = [C.POINTER(i)]
+        L.flow2d_hw_queues.restype = i
         L.flow2d_context_create.argtypes = [i, C.POINTER(vp)]
         L.flow2d_context_create_on_stream.argtypes = [i, vp, C.POINTER(vp)]
         L.flow2d_context_destroy.argtypes = [vp]

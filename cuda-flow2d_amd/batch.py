@@ -74,6 +74,25 @@ def all_gather_fields(local, out=None):
     return out
 
 
+def gather_fields_to_root(local, out=None, root=0):
+    """The same blocks delivered to ONE rank (BASELINE.json: "broadcast/gather"): rank `root` receives
+    [world, *local.shape], every other rank sends its block once and gets None.  Each byte crosses xGMI once in total
+    (the root's seven links in parallel) instead of once per receiving rank as in all_gather_fields: 1/world of the
+    traffic when only the root consumes the fields.  RCCL runs it as grouped send/recv."""
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        return local.unsqueeze(0) if out is None else out.copy_(local.unsqueeze(0))
+    world, rank = dist.get_world_size(), dist.get_rank()
+    if rank != root:
+        dist.gather(local.contiguous(), dst=root)
+        return None
+    if out is None:
+        out = torch.empty((world,) + tuple(local.shape), dtype=local.dtype, device=local.device)
+    dist.gather(local.contiguous(), gather_list=list(out.unbind(0)), dst=root)
+    return out
+
+
 def gather_fields(local, total_pairs, height, width, device=None):
     """local: {global_pair_index: (u, v)} float32 arrays of this rank's pairs.  Returns on every rank a float32
     array [total_pairs, 2, height, width] with all flow fields (host-array front end of all_gather_fields; ranks

@@ -2,6 +2,7 @@
 // Replaces the CUDA driver calls of src/utils/cuda_utils.cpp:26-105 and
 // src/optical_flow/optical_flow_2d.cpp:84-140,309-312,574-577 of the reference.
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -10,6 +11,14 @@
 
 namespace {
 thread_local std::string g_last_error;
+
+// The HIP runtime deals a process's streams onto GPU_MAX_HW_QUEUES hardware queues (default 4) and reads the variable
+// once, when it initialises (the first HIP call of the process).  The batched host path keeps four lanes (streams) busy
+// next to whatever other stream the process owns (RCCL's, the caller's): with the default, two lanes share a queue and
+// wait behind each other (4096^2, four lanes: 205 instead of 224 pairs/s).  So the library asks for eight queues when
+// it is loaded, unless the caller has set the variable; a process that initialised HIP before loading the library keeps
+// what it had (flow2d_hw_queues() tells, OpticalFlowBatch2D warns).
+__attribute__((constructor)) void ask_for_hardware_queues() { setenv("GPU_MAX_HW_QUEUES", "8", 0); }
 }
 
 namespace flow2d {
@@ -53,6 +62,13 @@ const char* flow2d_status_string(int status)
 }
 
 const char* flow2d_last_error(void) { return g_last_error.c_str(); }
+
+int flow2d_hw_queues(void)
+{
+    const char* v = std::getenv("GPU_MAX_HW_QUEUES");
+    const int n = v ? std::atoi(v) : 0;
+    return n > 0 ? n : 4;
+}
 
 int flow2d_device_count(int* count)
 {

@@ -17,6 +17,9 @@ bool OpticalFlowBatch2D::Initialize(const DataSize3& data_size, DataConstancy da
         std::printf("Error: OpticalFlowBatch2D: %zu lanes (1..64).\n", lanes);
         return false;
     }
+    if (static_cast<size_t>(flow2d_hw_queues()) < lanes && !silent)
+        std::printf("Warning: OpticalFlowBatch2D: %zu lanes on %d hardware queues (GPU_MAX_HW_QUEUES): lanes will share queues.\n",
+                    lanes, flow2d_hw_queues());
     // OpticalFlow2D binds to the process's current context at Initialize (like the reference's operators bind to the
     // current CUDA context): each lane's own context is made current for its Initialize, the caller's is put back.
     bool ok = true;

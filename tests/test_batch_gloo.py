@@ -113,3 +113,65 @@ def test_shard_rule():
             assert sorted(sum(shards, [])) == list(range(total))
             assert max(len(s) for s in shards) - min(len(s) for s in shards) <= 1
     assert batch.pairs_of_rank(64, 3, 8) == [3, 11, 19, 27, 35, 43, 51, 59]  # config 4: 8 pairs per GPU
+
+
+def test_bench_launcher_path_from_a_plain_shell():
+    """`python bench.py --gpus 2` with no WORLD_SIZE in the environment starts its own ranks (fresh child processes under
+    torch.distributed.run) and relays rank 0's line; --plumbing-check runs the rank plumbing on gloo without the flow
+    computation, so the launcher path is covered on a box without GPUs."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--plumbing-check"], env=env,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=240)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [json.loads(x) for x in p.stdout.splitlines() if x.startswith("{")]
+    assert len(lines) == 1                                   # ONE line, from rank 0
+    line = lines[0]
+    assert line["plumbing_check"] is True and line["n_gpus"] == 2 and line["collectives_ok"] is True
+    assert line["params"][:4] == [8.0, 0.5, 10.0, 5.0]       # rank 0's block (the default workload) reached rank 1
+    assert "value" not in line and "metric" not in line      # not a measurement
+
+
+def test_bench_launcher_refuses_without_devices_before_spawning():
+    """On a box without GPUs `bench.py --gpus 2` stops at the device check (no CPU fallback), with a message and a
+    non-zero status, instead of demanding a launcher."""
+    import torch
+    if torch.cuda.device_count() >= 2:
+        import pytest
+        pytest.skip("two GPUs are visible: the launcher would run the real bench")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=env, stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, text=True, timeout=240)
+    assert p.returncode != 0 and "HIP device(s) visible" in p.stderr and p.stdout.strip() == ""
+
+
+def test_gather_to_root_matches_all_gather(tmp_path):
+    """gather_fields_to_root: rank 0 gets what all_gather_fields gives everyone, the other ranks get None."""
+    worker = textwrap.dedent("""
+        import importlib.util, json, os, sys
+        spec = importlib.util.spec_from_file_location("flow2d_batch", os.path.join(%r, "cuda-flow2d_amd", "batch.py"))
+        batch = importlib.util.module_from_spec(spec); spec.loader.exec_module(batch)
+        import torch
+        rank, _, world = batch.init(backend="gloo")
+        local = (torch.arange(2 * 3 * 4 * 8, dtype=torch.float32).view(2, 3, 4, 8) + 1000.0 * rank)
+        everywhere = batch.all_gather_fields(local)
+        at_root = batch.gather_fields_to_root(local)
+        again = batch.gather_fields_to_root(local, out=at_root)   # into a buffer that already exists
+        print(json.dumps({"rank": rank, "root_none": at_root is None,
+                          "equal": bool(at_root is not None and torch.equal(at_root, everywhere) and again is at_root),
+                          "own": bool(torch.equal(everywhere[rank], local))}))
+        batch.shutdown()
+    """) % ROOT
+    script = tmp_path / "worker.py"
+    script.write_text(worker)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29547", WORLD_SIZE="3")
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r), LOCAL_RANK=str(r)),
+                              stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in range(3)]
+    outs = []
+    for p in procs:
+        out, err = p.communicate(timeout=240)
+        assert p.returncode == 0, err[-2000:]
+        outs.append(__import__("json").loads(out.strip().splitlines()[-1]))
+    outs.sort(key=lambda o: o["rank"])
+    assert outs[0]["equal"] and not outs[0]["root_none"]
+    assert all(o["root_none"] for o in outs[1:]) and all(o["own"] for o in outs)

@@ -342,3 +342,17 @@ def test_plain_c_client_links_and_runs_without_a_device(flow2d, tmp_path):
     out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0, (out.returncode, out.stdout, out.stderr)
     assert "flow2d C-ABI v1" in out.stdout
+
+
+def test_library_asks_for_hardware_queues_at_load(flow2d):
+    """Loading libflow2d_hip.so sets GPU_MAX_HW_QUEUES=8 when the caller has not set it (the four lanes of the batched
+    host path need a hardware queue each, next to RCCL's stream), and leaves a caller's value alone."""
+    code = ("import ctypes, os; L = ctypes.CDLL(%r); print(os.environ.get('GPU_MAX_HW_QUEUES'), L.flow2d_hw_queues())"
+            % flow2d.HIP_LIB_PATH)
+    env = {k: v for k, v in os.environ.items() if k != "GPU_MAX_HW_QUEUES"}
+    out = subprocess.run([os.sys.executable, "-c", code], env=env, capture_output=True, text=True, check=True).stdout.split()
+    # (os.environ is Python's snapshot of the start-up environment: the library's setenv shows in the C environment)
+    assert out[1] == "8"
+    out = subprocess.run([os.sys.executable, "-c", code], env=dict(env, GPU_MAX_HW_QUEUES="2"), capture_output=True,
+                         text=True, check=True).stdout.split()
+    assert out == ["2", "2"]
