@@ -14,8 +14,10 @@ Order of a run
   2. TIMED REGION: exactly K steps, replayed from the recorded graphs, nothing else; barrier; max over ranks
   3. output check: the flow fields the timed steps left in HBM are hashed; an eager (un-graphed) recomputation
      must give the same bits, and for single-pair workloads all streams must agree
-  4. roofline sample: eager passes with HIP events on the launch stream around every finest-level solver launch
-  5. batch leg (BASELINE.json configs[3]): 8 pairs of 1920x1080 per GPU on 4 streams, timed the same way, then the
+  4. host-entry leg: the same pairs from HOST images to HOST flows (uploads and downloads inside the bracket, pipelined
+     against the pyramids by OpticalFlowBatch2D::ComputeFlowBatch): pairs_per_s_incl_h2d, SURVEY 8(d) metric 2 as defined
+  5. roofline sample: eager passes with HIP events on the launch stream around every finest-level solver launch;
+     batch leg (BASELINE.json configs[3]): 8 pairs of 1920x1080 per GPU on 4 streams, timed the same way, then the
      flow fields of all ranks are gathered with ONE RCCL all_gather (timed separately: gather_ms)
   6. baselines on rank 0 at N = 1: the CPU oracle on a bounded crop; the reference's own kernels (oracle/_ref,
      compiled from its sources for gfx950) with the reference's launch schedule on this GPU
@@ -357,6 +359,69 @@ def output_check(job):
     }
 
 
+def host_entry_leg(job, batch, torch, steps):
+    """SURVEY 8(d) metric 2 in the reference's own bracket (optical_flow_2d.cpp:173-179,214-215,544-554): host images in,
+    host flows out, uploads and downloads INSIDE the timed region.  OpticalFlowBatch2D::ComputeFlowBatch pipelines them:
+    an upload stream copies pair k + 1 while the lanes compute pair k and a download stream copies pair k - 1 out.  The
+    images are Data2D objects in page-locked memory (HostMemory::Pinned, the reference's ALLOCATE_PINNED_MEMORY option).
+    Every step takes the rank's pairs from the same host frames and delivers into its own flow images (2 x lanes sets,
+    reused round-robin).  Timed like the main region: barrier + synchronise on both sides, max over ranks."""
+    flow2d, cfg = job.flow2d, job.cfg
+    w, h, G = cfg["w"], cfg["h"], cfg["pairs_per_rank"]
+    frames = [synthetic_pair(w, h, *pair_shift(job.workload, cfg, gk)) for gk in job.owned]
+    f0s = [flow2d.HostImage(w, h, True, f[0]) for f in frames]
+    f1s = [flow2d.HostImage(w, h, True, f[1]) for f in frames]
+    n_sets = 2 * job.n_lanes
+    outs = [([flow2d.HostImage(w, h, True) for _ in range(G)], [flow2d.HostImage(w, h, True) for _ in range(G)])
+            for _ in range(n_sets)]
+    images = f0s + f1s + [q for us, vs in outs for q in us + vs]
+    pinned = all(q.pinned for q in images)
+    runner = job.runner
+    runner.use_graph(not job.args.no_graph)
+
+    def step(k):
+        us, vs = outs[k % n_sets]
+        if job.rotate:  # one entry (a pair, or one lock-step group of the rank's pairs) per step, steps rotate over the lanes
+            runner.compute_flow_batch(f0s, f1s, us, vs, job.params, first_lane=k % job.n_lanes)
+        else:
+            runner.compute_flow_batch(f0s, f1s, us, vs, job.params, first_lane=0)
+
+    def barrier():
+        batch.barrier()
+        runner.synchronize()
+        torch.cuda.synchronize()
+
+    try:
+        for k in range(n_sets):  # warm-up: allocates the staging planes, records the graphs of both slots of every lane
+            step(k)
+        barrier()
+        t0 = time.perf_counter()
+        for k in range(steps):
+            step(k)
+        barrier()
+        elapsed = batch.max_over_ranks(time.perf_counter() - t0)
+        # every delivered flow image against the device-resident result of the same pair (sha of the timed region's fields)
+        want = {gk: d for (si, gk), d in job.digests().items()}
+        same = all((sha(us[i].array), sha(vs[i].array)) == want[gk]
+                   for us, vs in outs[:min(n_sets, steps)] for i, gk in enumerate(job.owned))
+        pairs = steps * G * job.world
+        bytes_per_pair = 4 * w * h * 4
+        return {
+            "pairs_per_s": round(pairs / elapsed, 3), "ms_per_step": round(elapsed / steps * 1e3, 4), "steps": steps,
+            "bracket": "host Data2D frames in -> host Data2D flows out (upload, pyramid, download), as the reference's "
+                       "own timer brackets ComputeFlow",
+            "host_path": "OpticalFlowBatch2D::ComputeFlowBatch (C++): upload stream | %d lanes, graph replay | download "
+                         "stream, chained by events, two staging slots per lane" % job.n_lanes,
+            "host_memory": "page-locked Data2D" if pinned else "pageable Data2D (pinned allocation failed)",
+            "pcie_bytes_per_pair": bytes_per_pair,
+            "pcie_gbs_each_way": round(pairs / job.world * bytes_per_pair / 2 / elapsed / 1e9, 2),
+            "flows_bit_identical_to_device_resident_run": bool(same),
+        }
+    finally:
+        for q in images:
+            q.close()
+
+
 def roofline_sample(job, passes=3):
     """Eager passes of the first pair on a stream of its own, alone on the GPU, with HIP events on that stream around
     every level's solve and every finest-level solver launch (flow2d_timing_enable mode 2)."""
@@ -506,6 +571,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-reference-baseline", action="store_true")
     ap.add_argument("--no-batch-leg", action="store_true")
+    ap.add_argument("--no-host-entry-leg", action="store_true", help="skip the H<->D-inclusive leg (pairs_per_s_incl_h2d)")
     ap.add_argument("--no-graph", action="store_true", help="launch every step eagerly instead of replaying HIP graphs")
     ap.add_argument("--pipeline", type=int, default=4,
                     help="independent pairs in flight per GPU when a step holds a single pair: consecutive steps go to "
@@ -550,6 +616,9 @@ def main():
     free_b, total_b = job.ctx.mem_info()
     elapsed = timed_region(job, batch, torch, args.steps, args.warmup)   # <- the number
     check = output_check(job)
+    host_entry = host_entry_leg(job, batch, torch, max(5, min(args.steps, 50))) if not args.no_host_entry_leg else None
+    if host_entry is not None and not host_entry["flows_bit_identical_to_device_resident_run"]:
+        check["ok"] = False
     finest, pair_latency_ms = roofline_sample(job)
     copy_gbs = measured_copy_peak(flow2d, local_rank) if rank == 0 else None
     first_pair = job.first_pair
@@ -631,7 +700,10 @@ def main():
                 "batch_mode": ("lock-step group" if args.batch_mode == "groups" else "lanes") if cfg["pairs_per_rank"] > 1 else None,
                 "timed_region": "graph-replayed steps only; output check, roofline sample, batch leg and baselines follow it",
             },
-            "pairs_per_s": round(pairs_total / elapsed, 3),
+            "pairs_per_s": round(pairs_total / elapsed, 3),  # inputs and outputs resident in HBM (the bench contract)
+            # SURVEY 8(d) metric 2 as defined: host images in, host flows out, H<->D inside the bracket
+            "pairs_per_s_incl_h2d": host_entry["pairs_per_s"] if host_entry else None,
+            "host_entry": host_entry,
             "single_pair_latency_ms": round(pair_latency_ms, 3),  # one pair alone on the GPU, graph replay, launch to done
             "finest_level": {
                 "solve_ms": round(solve_ms, 4),
@@ -649,7 +721,9 @@ def main():
         else:
             out["cpu_baseline"] = None
         if world == 1 and not args.no_reference_baseline:
-            out["reference_gpu_baseline"] = reference_gpu_baseline(cfg, *first_pair)
+            ref = out["reference_gpu_baseline"] = reference_gpu_baseline(cfg, *first_pair)
+            if ref and ref.get("pairs_per_s") and host_entry:  # like for like: both brackets hold the H<->D copies
+                ref["product_incl_h2d_over_reference"] = round(host_entry["pairs_per_s"] / ref["pairs_per_s"], 2)
         else:
             out["reference_gpu_baseline"] = None
         print(json.dumps(out))

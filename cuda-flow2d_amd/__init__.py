@@ -99,6 +99,9 @@ def hip_lib():
         L.flow2d_event_synchronize.argtypes = [vp, vp]
         L.flow2d_event_elapsed_ms.argtypes = [vp, vp, vp, C.POINTER(f)]
         L.flow2d_event_destroy.argtypes = [vp, vp]
+        L.flow2d_stream_wait_event.argtypes = [vp, vp]
+        L.flow2d_host_alloc.argtypes = [vp, sz, C.POINTER(vp)]
+        L.flow2d_host_free.argtypes = [vp, vp]
         L.flow2d_add_2d.argtypes = [vp, vp, vp, sz, sz, sz]
         L.flow2d_gaussian_kernel.argtypes = [f, C.POINTER(f), C.POINTER(i)]
         L.flow2d_convolution_rows.argtypes = [vp, vp, vp, sz, sz, sz, C.POINTER(f), i]
@@ -446,6 +449,15 @@ def host_lib():
         L.flow2d_host_batch_compute.argtypes = [vp, sz, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp),
                                                 C.POINTER(HostParams), sz]
         L.flow2d_host_batch_synchronize.argtypes = [vp]
+        L.flow2d_host_data2d_create.restype = vp
+        L.flow2d_host_data2d_create.argtypes = [sz, sz, i]
+        L.flow2d_host_data2d_destroy.argtypes = [vp]
+        L.flow2d_host_use_pinned_memory.argtypes = [i]
+        L.flow2d_host_data2d_ptr.restype = vp
+        L.flow2d_host_data2d_ptr.argtypes = [vp]
+        L.flow2d_host_data2d_is_pinned.argtypes = [vp]
+        L.flow2d_host_batch_compute_host.argtypes = [vp, sz, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp),
+                                                     C.POINTER(HostParams), sz]
         _host = L
     return _host
 
@@ -574,6 +586,17 @@ class OpticalFlowBatch:
         if rc:
             raise Flow2DError(rc, "OpticalFlowBatch2D::ComputeFlowBatchDevice")
 
+    def compute_flow_batch(self, frames_0, frames_1, flows_u, flows_v, params, first_lane=0):
+        """OpticalFlowBatch2D::ComputeFlowBatch: HostImage objects in and out, uploads / downloads pipelined against the
+        lanes' pyramids.  Queued: read the flows after synchronize()."""
+        n = len(frames_0)
+        if not (len(frames_1) == len(flows_u) == len(flows_v) == n):
+            raise ValueError("one frame 0, frame 1, u and v image per pair")
+        arrays = [(C.c_void_p * n)(*[q.handle for q in a]) for a in (frames_0, frames_1, flows_u, flows_v)]
+        rc = host_lib().flow2d_host_batch_compute_host(self.handle, n, *arrays, C.byref(params), first_lane)
+        if rc:
+            raise Flow2DError(rc, "OpticalFlowBatch2D::ComputeFlowBatch")
+
     def synchronize(self):
         if host_lib().flow2d_host_batch_synchronize(self.handle) != 0:
             raise Flow2DError(2, "OpticalFlowBatch2D::Synchronize")
@@ -581,6 +604,29 @@ class OpticalFlowBatch:
     def close(self):
         if self.handle:
             host_lib().flow2d_host_batch_destroy(self.handle)
+            self.handle = None
+
+
+class HostImage:
+    """A Data2D of the host layer (tight row-major float32), in page-locked memory when pinned=True
+    (HostMemory::Pinned).  `array` is a numpy view of its pixels, valid until close()."""
+
+    def __init__(self, width, height, pinned=True, data=None):
+        L = host_lib()
+        self.handle = L.flow2d_host_data2d_create(width, height, int(pinned))
+        if not self.handle:
+            raise MemoryError("Data2D(%d, %d)" % (width, height))
+        self.width, self.height = width, height
+        self.pinned = bool(L.flow2d_host_data2d_is_pinned(self.handle))
+        buf = (C.c_float * (width * height)).from_address(L.flow2d_host_data2d_ptr(self.handle))
+        self.array = np.frombuffer(buf, np.float32).reshape(height, width)
+        if data is not None:
+            self.array[...] = data
+
+    def close(self):
+        if self.handle:
+            self.array = None
+            host_lib().flow2d_host_data2d_destroy(self.handle)
             self.handle = None
 
 

@@ -254,6 +254,30 @@ int flow2d_copy_d2d(flow2d_context* ctx, void* dst_dev, const void* src_dev, siz
     return FLOW2D_OK;
 }
 
+int flow2d_host_alloc(flow2d_context* ctx, size_t bytes, void** out_host_ptr)
+{
+    if (!out_host_ptr || bytes == 0) return FLOW2D_ERR_INVALID_ARGUMENT;
+    *out_host_ptr = nullptr;
+    if (ctx) {
+        flow2d::DeviceGuard guard(ctx);
+        if (!guard.ok()) return FLOW2D_ERR_DEVICE;
+    }
+    (void)hipGetLastError();
+    void* p = nullptr;
+    FLOW2D_HIP_TRY(hipHostMalloc(&p, bytes, hipHostMallocDefault));
+    *out_host_ptr = p;
+    return FLOW2D_OK;
+}
+
+int flow2d_host_free(flow2d_context* ctx, void* host_ptr)
+{
+    (void)ctx;
+    if (!host_ptr) return FLOW2D_OK;
+    (void)hipGetLastError();
+    FLOW2D_HIP_TRY(hipHostFree(host_ptr));
+    return FLOW2D_OK;
+}
+
 int flow2d_context_set_batch(flow2d_context* ctx, size_t count, size_t stride_bytes)
 {
     if (!ctx || count == 0 || count > 65535 || (count > 1 && (stride_bytes == 0 || stride_bytes % 16 != 0)))
@@ -340,6 +364,14 @@ int flow2d_event_elapsed_ms(flow2d_context* ctx, void* start_event, void* stop_e
     if (!start_event || !stop_event || !out_ms) return FLOW2D_ERR_INVALID_ARGUMENT;
     FLOW2D_HIP_TRY(hipEventElapsedTime(out_ms, static_cast<hipEvent_t>(start_event),
                                        static_cast<hipEvent_t>(stop_event)));
+    return FLOW2D_OK;
+}
+
+int flow2d_stream_wait_event(flow2d_context* ctx, void* event)
+{
+    FLOW2D_ENTER(ctx);
+    if (!event) return FLOW2D_ERR_INVALID_ARGUMENT;
+    FLOW2D_HIP_TRY(hipStreamWaitEvent(ctx->stream, static_cast<hipEvent_t>(event), 0));
     return FLOW2D_OK;
 }
 

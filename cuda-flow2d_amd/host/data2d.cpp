@@ -2,7 +2,12 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstring>
 #include <memory>
+#include <new>
+#include <vector>
+
+#include "flow2d_c_abi.h"
 
 namespace {
 struct FileCloser {
@@ -14,16 +19,86 @@ struct FileCloser {
 using File = std::unique_ptr<std::FILE, FileCloser>;
 }  // namespace
 
-Data2D::Data2D(size_t width, size_t height) : data_(width * height, 0.f), width_(width), height_(height) {}
+namespace {
+bool g_default_pinned = false;
+}
+
+void Data2D::UsePinnedMemory(bool on) { g_default_pinned = on; }
+
+Data2D::Data2D(size_t width, size_t height, HostMemory memory) { Allocate(width, height, memory); }
+
+Data2D::~Data2D() { Free(); }
+
+Data2D::Data2D(Data2D&& other) noexcept { *this = std::move(other); }
+
+Data2D& Data2D::operator=(Data2D&& other) noexcept
+{
+    if (this != &other) {
+        Free();
+        data_ = other.data_;
+        width_ = other.width_;
+        height_ = other.height_;
+        pinned_ = other.pinned_;
+        requested_ = other.requested_;
+        other.data_ = nullptr;
+        other.width_ = other.height_ = 0;
+        other.pinned_ = false;
+    }
+    return *this;
+}
+
+// AllocateMemory / FreeMemory of the reference (data2d.cpp:56-91), with the pinned branch chosen at run time.
+bool Data2D::Allocate(size_t width, size_t height, HostMemory memory)
+{
+    Free();
+    requested_ = memory;
+    const size_t count = width * height;
+    if (count == 0) return true;
+    const bool want_pinned = memory == HostMemory::Pinned || (memory == HostMemory::Default && g_default_pinned);
+    if (want_pinned) {
+        void* p = nullptr;
+        if (flow2d_host_alloc(nullptr, count * sizeof(float), &p) == FLOW2D_OK && p) {
+            data_ = static_cast<float*>(p);
+            pinned_ = true;
+        }
+    }
+    if (!data_) {
+        data_ = new (std::nothrow) float[count];
+        if (!data_) {
+            std::printf("Error. Cannot allocate memory on the host.\n");
+            return false;
+        }
+    }
+    std::memset(data_, 0, count * sizeof(float));
+    width_ = width;
+    height_ = height;
+    return true;
+}
+
+void Data2D::Free()
+{
+    if (data_) {
+        if (pinned_) flow2d_host_free(nullptr, data_);
+        else delete[] data_;
+    }
+    data_ = nullptr;
+    width_ = height_ = 0;
+    pinned_ = false;
+}
 
 void Data2D::Swap(Data2D& other)
 {
-    data_.swap(other.data_);
+    std::swap(data_, other.data_);
     std::swap(width_, other.width_);
     std::swap(height_, other.height_);
+    std::swap(pinned_, other.pinned_);
+    std::swap(requested_, other.requested_);
 }
 
-void Data2D::ZeroData() { std::fill(data_.begin(), data_.end(), 0.f); }
+void Data2D::ZeroData()
+{
+    if (data_) std::memset(data_, 0, width_ * height_ * sizeof(float));
+}
 
 // The file must hold exactly width*height samples: short files and files with trailing bytes are
 // rejected with the reference's "wrong dimensions" message (data2d.cpp:121-133,158-169).
@@ -46,13 +121,11 @@ bool Data2D::ReadRaw(const char* filename, size_t width, size_t height)
     if (ok && std::fread(&extra, 1, 1, file.get()) != 0) ok = false;
     if (!ok) {
         std::printf("Error reading RAW data from file '%s': wrong dimensions.", filename);
-        data_.clear();
-        width_ = height_ = 0;
+        Free();
         return false;
     }
-    data_.swap(pixels);
-    width_ = width;
-    height_ = height;
+    if (!Allocate(width, height, requested_)) return false;
+    if (!pixels.empty()) std::memcpy(data_, pixels.data(), pixels.size() * sizeof(float));
     return true;
 }
 
@@ -93,7 +166,7 @@ bool Data2D::WriteRAWToFileF32(const char* filename)
         return false;
     }
     const size_t count = width_ * height_;
-    if (count && std::fwrite(data_.data(), sizeof(float), count, file.get()) != count) {
+    if (count && std::fwrite(data_, sizeof(float), count, file.get()) != count) {
         std::printf("Error writing RAW data to file '%s'.", filename);
         return false;
     }

@@ -206,6 +206,35 @@ HOST_API int flow2d_host_batch_compute(flow2d_host_batch* h, size_t count, void*
     return h->batch.ComputeFlowBatchDevice(count, f0.data(), f1.data(), u.data(), v.data(), bag, first_lane) ? 0 : 2;
 }
 
+// Host images for the H<->D-inclusive entry: Data2D objects in pageable or page-locked memory (HostMemory::Pinned, the
+// reference's ALLOCATE_PINNED_MEMORY option as a run-time choice).  The caller fills / reads them through the pointer.
+HOST_API Data2D* flow2d_host_data2d_create(size_t width, size_t height, int pinned)
+{
+    Data2D* d = new (std::nothrow) Data2D(width, height, pinned ? HostMemory::Pinned : HostMemory::Pageable);
+    if (d && !d->DataPtr()) {
+        delete d;
+        d = nullptr;
+    }
+    return d;
+}
+HOST_API void flow2d_host_data2d_destroy(Data2D* d) { delete d; }
+HOST_API void flow2d_host_use_pinned_memory(int on) { Data2D::UsePinnedMemory(on != 0); }
+HOST_API float* flow2d_host_data2d_ptr(Data2D* d) { return d ? d->DataPtr() : nullptr; }
+HOST_API int flow2d_host_data2d_is_pinned(Data2D* d) { return d && d->IsPinned() ? 1 : 0; }
+
+// OpticalFlowBatch2D::ComputeFlowBatch: `count` pairs of host images in, host flows out, uploads and downloads
+// pipelined against the lanes' pyramids.  Queued: the flows are complete after flow2d_host_batch_synchronize.
+HOST_API int flow2d_host_batch_compute_host(flow2d_host_batch* h, size_t count, Data2D* const* frames_0,
+                                            Data2D* const* frames_1, Data2D* const* flows_u, Data2D* const* flows_v,
+                                            const flow2d_host_params* params, size_t first_lane)
+{
+    if (!h || !params) return 1;
+    flow2d_host_params p = *params;
+    OperationParameters bag;
+    FillBag(bag, p);
+    return h->batch.ComputeFlowBatch(count, frames_0, frames_1, flows_u, flows_v, bag, first_lane) ? 0 : 2;
+}
+
 HOST_API int flow2d_host_batch_synchronize(flow2d_host_batch* h) { return (h && h->batch.Synchronize()) ? 0 : 1; }
 
 // Per-level solve records of the last run (needs timing_mode >= 1 and a synchronised context).

@@ -60,6 +60,9 @@ int main(int argc, char** argv)
     const int nargs = static_cast<int>(args.size());
 
     if (!InitDeviceContext(device)) return 1;
+    // the reference's ALLOCATE_PINNED_MEMORY option (data2d.cpp:34), on: frames and flows live in page-locked memory
+    // and move by DMA (a failed pinned allocation falls back to pageable memory, same results)
+    Data2D::UsePinnedMemory(true);
 
     std::printf("//----------------------------------------------------------------------//\n");
     std::printf("//       2D optical flow, MI355X (gfx950) HIP path. flow2d 0.1          //\n");

@@ -109,6 +109,16 @@ FLOW2D_API int flow2d_copy_d2h_2d(flow2d_context* ctx, void* dst_host, size_t ds
                                   size_t src_pitch_bytes, size_t width_bytes, size_t height);
 FLOW2D_API int flow2d_copy_d2d(flow2d_context* ctx, void* dst_dev, const void* src_dev, size_t bytes);
 
+/* ---- page-locked host memory  (replaces cuMemAllocHost / cuMemFreeHost, the reference's ALLOCATE_PINNED_MEMORY
+ *      option: src/data_types/data2d.cpp:34,60-61,80-82) --------------------------------------------------------
+ * flow2d_copy_h2d_2d / flow2d_copy_d2h_2d are asynchronous on the context's stream; from and to pageable memory the
+ * runtime stages them through its own bounce buffers and the call returns when the bytes have left the caller's
+ * buffer (about 20 GB/s).  From and to memory allocated here the copy is one DMA transfer at the PCIe rate, returns at
+ * once and overlaps kernels of other streams: the host buffer must stay untouched until the stream has passed the
+ * copy (flow2d_synchronize, or an event recorded behind it).  ctx may be NULL (the calling thread's current device). */
+FLOW2D_API int flow2d_host_alloc(flow2d_context* ctx, size_t bytes, void** out_host_ptr);
+FLOW2D_API int flow2d_host_free(flow2d_context* ctx, void* host_ptr);
+
 /* ---- events  (replaces cuEventCreate/Record/Synchronize/ElapsedTime/Destroy,
  *      optical_flow_2d.cpp:173-179,548-557; cuda_operation_solve_2d.cpp:214-220,302-313) ------- */
 FLOW2D_API int flow2d_event_create(flow2d_context* ctx, void** out_event);
@@ -116,6 +126,11 @@ FLOW2D_API int flow2d_event_record(flow2d_context* ctx, void* event);
 FLOW2D_API int flow2d_event_synchronize(flow2d_context* ctx, void* event);
 FLOW2D_API int flow2d_event_elapsed_ms(flow2d_context* ctx, void* start_event, void* stop_event, float* out_ms);
 FLOW2D_API int flow2d_event_destroy(flow2d_context* ctx, void* event);
+/* Everything queued on `ctx` after this call waits until the work recorded into `event` (by flow2d_event_record on any
+ * context of the same device) has finished; the host does not wait.  An event never recorded counts as finished.  This
+ * is what chains an upload stream, the lanes' compute streams and a download stream into a pipeline (no reference
+ * counterpart: one NULL stream, host-synchronous copies, src/utils/cuda_utils.cpp:66-105). */
+FLOW2D_API int flow2d_stream_wait_event(flow2d_context* ctx, void* event);
 
 /* ---- stream capture (no counterpart in the reference, which launches eagerly and blocks after every
  *      sweep).  Everything queued on the context between begin and end is recorded into a HIP graph
