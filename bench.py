@@ -25,10 +25,12 @@ Order of a run
 metric  = Mpixel*solver-iterations/s at the finest level (BASELINE.json): finest-level pixel-iterations
           (W*H*outer*inner per pair) of all ranks / whole-pyramid wall time of the timed region (a whole-job
           rate; the pure finest-level solve rate is in "finest_level").  pairs_per_s: the metric's second half.
-roofline: the finest level's dominant solver kernel.  achieved/frac are the contract's ALGORITHMIC figures
-          (40 B per pixel-sweep, 32 B per pixel for phi/ksi, i.e. the reference's per-sweep schedule)
-          over the measured launch duration -- above 1 for the fused kernel because it does not move those bytes.
-          What the kernel is really bound by is reported next to it: physical HBM bytes (PMC) and VALU issue.
+roofline: the finest level's dominant solver kernel.  achieved/frac/traffic are PHYSICAL HBM bytes per launch (rocprofv3
+          --pmc passes of this very workload, run as child processes before the timed region) over the launch duration
+          measured with HIP events on the launch stream; effective_* are the contract's ALGORITHMIC figures (SURVEY 8d:
+          40 B per pixel-sweep, 32 B per pixel for phi/ksi, i.e. the reference's per-sweep schedule) over the same
+          duration -- above 1 for the fused kernel because it does not move those bytes.  bound says what limits the
+          kernel: "valu" (vector-instruction issue, valu_issue_frac) for the temporally blocked kernels, "hbm" otherwise.
 """
 import argparse
 import hashlib
@@ -204,6 +206,117 @@ def measured_copy_peak(flow2d, local_rank):
         return None
     finally:
         c.close()
+
+
+def pmc_child(flow2d, args, cfg):
+    """--pmc-child: what the rocprofv3 --pmc passes profile -- the workload's first pair, two eager pyramids on one stream
+    (same data, same parameters, same AUTO choice as the timed run), nothing else."""
+    w, h = cfg["w"], cfg["h"]
+    c = flow2d.Context(0)
+    flow = flow2d.OpticalFlow(w, h, cfg["constancy"], ctx=c)
+    try:
+        f0, f1 = (c.plane(w, h, a) for a in synthetic_pair(w, h, *pair_shift(args.workload, cfg, 0)))
+        u, v = c.plane(w, h), c.plane(w, h)
+        p = flow.params(cfg["levels"], cfg["scale"], cfg["outer"], cfg["inner"], cfg["alpha"], 0.001, 0.001,
+                        cfg["median"], cfg["sigma"], args.algorithm)
+        for _ in range(2):
+            flow.compute_flow_device(f0.ptr, f1.ptr, u.ptr, v.ptr, p, 0)
+        c.synchronize()
+    finally:
+        flow.close()
+        c.close()
+
+
+def pmc_passes(args, cfg):
+    """The HBM bytes and VALU instructions of the dominant kernel FOR THIS WORKLOAD, measured in this run: before this
+    process touches the GPU, three child processes `rocprofv3 --kernel-trace --pmc <counters> -- python3 bench.py
+    --pmc-child ...` (FETCH_SIZE and WRITE_SIZE do not fit one pass: MI355X_MICROARCH.md, rocprofv3 PMC slots; no other
+    trace domain is combined with --pmc).  Bytes = FETCH_SIZE x correction + WRITE_SIZE (KiB): on gfx950 FETCH_SIZE tallies
+    128-byte requests as 64 (same guide, HBM section), so the correction is 2; it is re-measured here on the pyramid's own
+    full-resolution add_2d launches, whose traffic is known exactly (4 planes read, 2 written).  Returns {} when
+    rocprofv3 is missing or a pass fails (the line then falls back to profiles/traffic.json and says so)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+
+    if not shutil.which("rocprofv3"):
+        return {}
+    out_root = tempfile.mkdtemp(prefix="flow2d_pmc_", dir="/tmp")
+    rows = {}
+    try:
+        for n, counters in enumerate((["FETCH_SIZE"], ["WRITE_SIZE"], ["SQ_INSTS_VALU", "SQ_WAVES"])):
+            d = os.path.join(out_root, "pass%d" % n)
+            cmd = ["rocprofv3", "--kernel-trace", "--output-format", "csv", "--pmc"] + counters + \
+                  ["-d", d, "--", sys.executable, os.path.abspath(__file__), "--pmc-child", "--workload", args.workload,
+                   "--algorithm", str(args.algorithm)]
+            r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.DEVNULL,
+                               stderr=subprocess.PIPE, text=True, timeout=240)
+            files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+            if r.returncode != 0 or not files:
+                return {"error": "rocprofv3 pass %d: rc %d %s" % (n, r.returncode, r.stderr[-200:])}
+            for f in files:
+                for row in csv.DictReader(open(f)):
+                    name = row["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0]
+                    rows.setdefault(row["Counter_Name"], []).append(
+                        (int(row["Dispatch_Id"]), name, int(row["Grid_Size"]), float(row["Counter_Value"])))
+    except (OSError, subprocess.SubprocessError, KeyError, ValueError) as e:
+        return {"error": str(e)[:200]}
+    finally:
+        shutil.rmtree(out_root, ignore_errors=True)
+    return {"rows": rows}
+
+
+def pmc_select(collected, cfg, algorithm_used):
+    """Per-launch figures of the finest level's solver kernel (the algorithm the timed run used there) out of the rows
+    pmc_passes collected."""
+    if "rows" not in collected:
+        return collected
+    rows = collected["rows"]
+    family = {1: "sweep_", 2: "fused_outer_kernel", 3: "small_level_kernel", 4: "tile_outer_kernel"}[algorithm_used]
+
+    per_solve = {1: cfg["outer"] * cfg["inner"], 2: cfg["outer"] * -(-cfg["inner"] // 5), 3: 1, 4: cfg["outer"]}[algorithm_used]
+    PYRAMIDS = 2  # pmc_child runs the pyramid twice
+
+    def launches(counter, prefix, per_pyramid):
+        """[value per launch, in dispatch order] of the FINEST level's launches of the kernels named prefix*: a pyramid
+        goes coarse to fine, so they are the last `per_pyramid` launches of that family in each pyramid (Grid_Size alone
+        cannot tell 5120 x 25 from 2560 x 50)."""
+        sel = sorted(r for r in rows.get(counter, []) if r[1].startswith(prefix))
+        n = len(sel) // PYRAMIDS
+        if n < per_pyramid or len(sel) != n * PYRAMIDS:
+            return None, []
+        picked = [r for k in range(PYRAMIDS) for r in sel[(k + 1) * n - per_pyramid:(k + 1) * n]]
+        return picked[-1][1], [r[3] for r in picked]
+
+    dominant, _ = launches("FETCH_SIZE", family, per_solve)
+    if dominant is None:
+        return {"error": "no %s* launches in the counter rows" % family}
+    plane = float(cfg["w"]) * cfg["h"] * 4
+    _, add_fetch = launches("FETCH_SIZE", "add_2d_kernel", 1)
+    _, add_write = launches("WRITE_SIZE", "add_2d_kernel", 1)
+    corr = 4 * plane / (np.mean(add_fetch) * 1024) if add_fetch else 2.0
+    wcorr = 2 * plane / (np.mean(add_write) * 1024) if add_write else 1.0
+    out = {"kernel": dominant, "fetch_size_correction": round(float(corr), 4), "write_size_correction": round(float(wcorr), 4),
+           "correction_from": "the pyramid's full-resolution add_2d launches (4 planes read, 2 written)" if add_fetch
+           else "MI355X_MICROARCH.md (FETCH_SIZE x 2)"}
+    split = {}
+    for counter in ("FETCH_SIZE", "WRITE_SIZE", "SQ_INSTS_VALU", "SQ_WAVES"):
+        _, vals = launches(counter, family, per_solve)
+        if not vals:
+            return {"error": "no %s rows for %s" % (counter, dominant)}
+        first = [x for i, x in enumerate(vals) if i % per_solve == 0]
+        steady = [x for i, x in enumerate(vals) if i % per_solve != 0] or first
+        split[counter] = (float(np.mean(first)), float(np.mean(steady)), len(vals))
+    out["launches_sampled"] = split["FETCH_SIZE"][2]
+    out["hbm_bytes_first_launch"] = round(split["FETCH_SIZE"][0] * 1024 * corr + split["WRITE_SIZE"][0] * 1024 * wcorr)
+    out["hbm_read_bytes_per_launch"] = round(split["FETCH_SIZE"][1] * 1024 * corr)
+    out["hbm_write_bytes_per_launch"] = round(split["WRITE_SIZE"][1] * 1024 * wcorr)
+    out["hbm_bytes_per_launch"] = out["hbm_read_bytes_per_launch"] + out["hbm_write_bytes_per_launch"]
+    out["valu_insts_per_launch"] = round(split["SQ_INSTS_VALU"][1])
+    out["waves_per_launch"] = round(split["SQ_WAVES"][1])
+    return out
 
 
 def load_pmc(workload, algorithm):
@@ -580,6 +693,10 @@ def main():
     ap.add_argument("--batch-mode", choices=["groups", "lanes"], default="groups",
                     help="batched workloads: all pairs of a step as one lock-step group (every kernel launched once for "
                          "the group) or spread one by one over the lanes")
+    ap.add_argument("--no-pmc", action="store_true",
+                    help="skip the rocprofv3 --pmc child passes that measure the dominant kernel's HBM bytes and VALU "
+                         "instructions for this run (N = 1 only); the line then quotes profiles/traffic.json")
+    ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--plumbing-check", action="store_true",
                     help="rank plumbing only (launcher, process group on gloo, broadcast, barriers, gathers) without the "
                          "flow computation; needs no GPU and prints no metric")
@@ -592,6 +709,8 @@ def main():
     if args.plumbing_check:
         return plumbing_check(batch, args)
     flow2d = importlib.import_module("cuda-flow2d_amd")
+    if args.pmc_child:
+        return pmc_child(flow2d, args, cfg)
     if not (os.path.exists(flow2d.HIP_LIB_PATH) and os.path.exists(flow2d.HOST_LIB_PATH)):
         if int(os.environ.get("LOCAL_RANK", "0")) == 0:
             flow2d.build()  # checkout without the in-tree libraries (normally built by __graft_entry__.build())
@@ -603,6 +722,8 @@ def main():
             time.sleep(1.0)
     rank, local_rank, world = batch.world_info()
     args.gpus = world  # launched by torch.distributed.run: the launcher's world size is the number of GPUs
+    # counters of THIS workload, collected by child processes before this one initialises the GPU
+    pmc_run = pmc_passes(args, cfg) if (world == 1 and not args.no_pmc) else {}
 
     import torch  # device plumbing only: barrier, device-wide synchronise, max-over-ranks, the RCCL gather buffer
 
@@ -639,40 +760,59 @@ def main():
         kernel_ms = float(np.mean(launch_ms))
         launches = finest[-1][4]
         bytes_per_launch = float(finest[-1][5])
-        algorithm_used = 2 if launches == cfg["outer"] and cfg["inner"] > 1 else 1
-        achieved = bytes_per_launch / (kernel_ms * 1e-3) / 1e9
-        pmc = load_pmc(args.workload, algorithm_used)
+        algorithm_used = int(finest[-1][6])  # from the timing record: what flow2d_solve_level actually ran
+        algorithmic = bytes_per_launch / (kernel_ms * 1e-3) / 1e9
+        pmc_run = pmc_select(pmc_run, cfg, algorithm_used)
+        if pmc_run.get("hbm_bytes_per_launch"):
+            pmc, pmc_source = pmc_run, ("this run: rocprofv3 --kernel-trace --pmc child passes of the same workload "
+                                        "(FETCH_SIZE | WRITE_SIZE | SQ_INSTS_VALU SQ_WAVES), before the timed region")
+        else:
+            pmc = load_pmc(args.workload, algorithm_used)
+            pmc_source = ("profiles/traffic.json (OFFLINE: measured by tools/pmc_passes.sh at commit %s, not in this run%s)"
+                          % (pmc.get("measured_at_commit", "9b4994d"),
+                             "; in-run passes failed: " + pmc_run["error"] if pmc_run.get("error") else "")) if pmc else None
         phys = pmc.get("hbm_bytes_per_launch")
         valu = pmc.get("valu_insts_per_launch")
+        phys_gbs = phys / (kernel_ms * 1e-3) / 1e9 if phys else None
+        valu_frac = valu * VALU_ISSUE_CYCLES / (SIMDS * CLOCK_HZ * kernel_ms * 1e-3) if valu else None
+        temporal = algorithm_used in (2, 3, 4)  # several sweeps per trip through HBM: not bound by the per-sweep bytes
+        kernel_name = {1: "Jacobi sweep kernel (%s)" % {0: "solve_2d", 1: "solve_2d_grad", 3: "solve_2d_log"}.get(
+                           cfg["constancy"], "gradient-untiled"),
+                       2: "fused outer-iteration strip kernel (phi/ksi + %d Jacobi sweeps per launch)" % min(cfg["inner"], 5),
+                       3: "single-workgroup level kernel", 4: "tiled outer-iteration kernel (LDS tiles)"}[algorithm_used]
         roof = {
-            "bound": "hbm",
-            "kernel": ("fused outer-iteration kernel (phi/ksi + %d Jacobi sweeps)" % cfg["inner"])
-            if algorithm_used == 2 else "Jacobi sweep kernel (%s)" %
-            {0: "solve_2d", 1: "solve_2d_grad", 3: "solve_2d_log"}.get(cfg["constancy"], "gradient-untiled"),
-            "achieved": round(achieved, 1),
+            # what bounds the kernel: vector-ALU instruction issue for the kernels that keep the sweeps of an outer
+            # iteration on chip, HBM for the per-sweep kernels.  achieved / frac = PHYSICAL HBM bytes (PMC) over the measured
+            # launch time against the 8 TB/s peak; effective_* = the contract's ALGORITHMIC bytes (the
+            # reference's per-sweep schedule, 32 + 40 x inner B per pixel and outer iteration) over the same time, which
+            # exceeds the peak for a temporally blocked kernel because it never moves those bytes.
+            "bound": "valu" if temporal else "hbm",
+            "kernel": kernel_name,
+            "achieved": round(phys_gbs, 1) if phys_gbs else None,
             "peak": HBM_PEAK_GBS,
             "measured_copy_gbs": copy_gbs,  # a 512 MiB device-to-device copy on this box (read + write), for scale
             "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBS, 4),
+            "frac": round(phys_gbs / HBM_PEAK_GBS, 4) if phys_gbs else None,
             "traffic": phys,
+            "effective_achieved": round(algorithmic, 1),
+            "effective_frac": round(algorithmic / HBM_PEAK_GBS, 4),
             "algorithmic_bytes_per_launch": bytes_per_launch,
+            "traffic_over_algorithmic": round(phys / bytes_per_launch, 4) if phys else None,
             "avg_launch_ms": round(kernel_ms, 5),
             "launch_samples": len(finest) * launches,
             "launches_per_level_solve": launches,
-            "note": "achieved/frac: algorithmic bytes of the reference's per-sweep schedule (SURVEY 8d) over the measured "
-                    "launch time; the fused kernel does not move them, hence frac > 1.  physical_* and valu_* say what "
-                    "the kernel is bound by.",
-            # what the launch physically moves through HBM (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, steady-state
-            # launches; the first launch of a level skips reading du, dv) and how busy it keeps the vector ALUs
-            "physical_bytes_per_launch": phys,
-            "physical_bytes_first_launch_of_level": pmc.get("hbm_bytes_first_launch"),
-            "physical_gbs": round(phys / (kernel_ms * 1e-3) / 1e9, 1) if phys else None,
-            "physical_frac": round(phys / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if phys else None,
+            "traffic_first_launch_of_level": pmc.get("hbm_bytes_first_launch"),
             "valu_instr_per_launch": valu,
-            "valu_issue_frac": round(valu * VALU_ISSUE_CYCLES / (SIMDS * CLOCK_HZ * kernel_ms * 1e-3), 4) if valu else None,
-            "bound_actual": ("vector-ALU issue latency at 2 waves/SIMD (256 VGPRs): neither HBM nor VALU throughput is "
-                             "saturated; see DESIGN.md section 3.1") if algorithm_used == 2 else "HBM",
-            "pmc_source": "profiles/traffic.json" if pmc else None,
+            "valu_issue_frac": round(valu_frac, 4) if valu_frac else None,  # of one wave64 instruction per 2 cycles per SIMD
+            "valu_peak_instr_per_s": SIMDS * CLOCK_HZ / VALU_ISSUE_CYCLES,
+            "pmc_source": pmc_source,
+            "pmc_detail": {k: pmc_run[k] for k in ("kernel", "fetch_size_correction", "write_size_correction",
+                                                    "correction_from", "launches_sampled", "waves_per_launch")
+                           if k in pmc_run} or None,
+            "note": ("frac = physical HBM fraction; effective_frac = algorithmic bytes of the reference's per-sweep schedule "
+                     "over the launch time (> 1: temporal blocking); the kernel is bound by VALU issue at 2 waves/SIMD "
+                     "(valu_issue_frac of the issue peak; DESIGN.md 3.1)") if temporal else
+                    "frac = physical HBM fraction; effective_frac = algorithmic bytes over the launch time",
         }
         out = {
             "metric": "Mpixels*SOR-iters/sec at finest level (whole-pyramid wall time); full-pyramid pairs/sec in pairs_per_s",

@@ -529,12 +529,13 @@ class OpticalFlow:
             raise Flow2DError(rc, "OpticalFlow2D::ComputeFlowSequenceDevice")
 
     def level_timings(self):
-        """[(width, height, solve_ms, kernel_ms, kernel_launches, algorithmic_bytes_per_launch)] per level."""
+        """[(width, height, solve_ms, kernel_ms, kernel_launches, algorithmic_bytes_per_launch, algorithm)] per level;
+        algorithm = the flow2d_solver_algorithm the level actually ran (never AUTO)."""
         cap = 8192
-        buf = np.zeros(6 * cap, np.float32)
+        buf = np.zeros(7 * cap, np.float32)
         n = host_lib().flow2d_host_level_timings(self.handle, _fptr(buf), cap)
-        return [(int(buf[6 * i]), int(buf[6 * i + 1]), float(buf[6 * i + 2]), float(buf[6 * i + 3]),
-                 int(buf[6 * i + 4]), float(buf[6 * i + 5])) for i in range(min(n, cap))]
+        return [(int(buf[7 * i]), int(buf[7 * i + 1]), float(buf[7 * i + 2]), float(buf[7 * i + 3]),
+                 int(buf[7 * i + 4]), float(buf[7 * i + 5]), int(buf[7 * i + 6])) for i in range(min(n, cap))]
 
     def use_graph(self, on=True):
         """Record the pyramid of a (buffers, parameters) combination once and replay it (HIP graph)."""

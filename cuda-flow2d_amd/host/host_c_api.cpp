@@ -238,19 +238,20 @@ HOST_API int flow2d_host_batch_compute_host(flow2d_host_batch* h, size_t count, 
 HOST_API int flow2d_host_batch_synchronize(flow2d_host_batch* h) { return (h && h->batch.Synchronize()) ? 0 : 1; }
 
 // Per-level solve records of the last run (needs timing_mode >= 1 and a synchronised context).
-// Writes up to `capacity` records of 6 floats (width, height, solve_ms, kernel_ms, kernel_launches,
-// algorithmic bytes per launch) and returns the number of levels.
-HOST_API size_t flow2d_host_level_timings(flow2d_host_flow* h, float* triples, size_t capacity)
+// Writes up to `capacity` records of 7 floats (width, height, solve_ms, kernel_ms, kernel_launches,
+// algorithmic bytes per launch, algorithm used) and returns the number of levels.
+HOST_API size_t flow2d_host_level_timings(flow2d_host_flow* h, float* records, size_t capacity)
 {
     if (!h) return 0;
     std::vector<FlowLevelTiming> t = h->flow.LastLevelTimings();
     for (size_t i = 0; i < t.size() && i < capacity; ++i) {
-        triples[6 * i + 0] = static_cast<float>(t[i].width);
-        triples[6 * i + 1] = static_cast<float>(t[i].height);
-        triples[6 * i + 2] = t[i].solve_ms;
-        triples[6 * i + 3] = t[i].kernel_ms;
-        triples[6 * i + 4] = static_cast<float>(t[i].kernel_launches);
-        triples[6 * i + 5] = static_cast<float>(t[i].bytes_per_launch);
+        records[7 * i + 0] = static_cast<float>(t[i].width);
+        records[7 * i + 1] = static_cast<float>(t[i].height);
+        records[7 * i + 2] = t[i].solve_ms;
+        records[7 * i + 3] = t[i].kernel_ms;
+        records[7 * i + 4] = static_cast<float>(t[i].kernel_launches);
+        records[7 * i + 5] = static_cast<float>(t[i].bytes_per_launch);
+        records[7 * i + 6] = static_cast<float>(t[i].algorithm);
     }
     return t.size();
 }

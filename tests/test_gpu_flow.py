@@ -143,6 +143,7 @@ def test_device_resident_entry_matches_host_entry(flow2d, oracle, make_flow, ctx
         assert [t[:2] for t in times] == [(25, 15), (50, 30), (100, 60), (200, 120)]
         # every level through the tiled kernel: one launch per outer iteration (3 here)
         assert all(t[2] > 0 for t in times) and [t[4] for t in times] == [3, 3, 3, 3]
+        assert all(t[6] == flow2d.SOLVER_TILED for t in times)  # the record names the algorithm that ran
         assert all(t[3] < 0 for t in times[:-1]) and 0 < times[-1][3] <= times[-1][2] * 1.05  # launches timed on the finest level only
         assert times[-1][5] == (32.0 + 40.0 * 5) * 200 * 120  # algorithmic bytes of a fused launch (inner 5)
         # input frames are left untouched

@@ -232,25 +232,31 @@ def test_cli_exit_codes_without_device(flow2d, tmp_path):
 
 
 def test_committed_bench_line_has_the_contract_fields():
-    """The bench line committed under profiles/ carries every field the bench contract names, and the roofline block
-    says both what the contract defines (algorithmic bytes over the launch time) and what the kernel is bound by."""
+    """The bench line committed under profiles/ carries every field the bench contract names.  The roofline block quotes
+    the PHYSICAL HBM fraction of the dominant kernel (PMC bytes over the launch time) as frac, the contract's algorithmic
+    figure as effective_frac, and names what the kernel is bound by."""
     import json
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    line = json.loads(open(os.path.join(root, "profiles", "r02_default_bench_line.json")).read())
+    line = json.loads(open(os.path.join(root, "profiles", "r03_default_bench_line.json")).read())
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
                 "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "output_check", "batch",
-                "reference_gpu_baseline"):
+                "reference_gpu_baseline", "pairs_per_s", "pairs_per_s_incl_h2d", "host_entry"):
         assert key in line, key
     assert line["config"]["workload"] == "cfg3_4096_gradient" and line["scaling"] == "weak" and line["dtype"] == "f32"
     assert line["output_check"]["ok"] and line["batch"]["output_check"]["ok"]
+    assert line["host_entry"]["flows_bit_identical_to_device_resident_run"]
+    assert 0 < line["pairs_per_s_incl_h2d"] <= line["pairs_per_s"]      # the H<->D-inclusive bracket cannot be faster
     roof = line["roofline"]
-    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic", "physical_bytes_per_launch", "physical_gbs",
-                "physical_frac", "valu_instr_per_launch", "valu_issue_frac", "bound_actual"):
+    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic", "effective_achieved", "effective_frac",
+                "algorithmic_bytes_per_launch", "valu_instr_per_launch", "valu_issue_frac", "pmc_source"):
         assert key in roof, key
-    assert roof["bound"] in ("hbm", "mfma") and roof["peak"] == 8000.0
+    assert roof["bound"] in ("hbm", "valu") and roof["peak"] == 8000.0
     assert abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-3
-    # the fused kernel moves a fraction of the algorithmic bytes: its physical HBM fraction is far below frac
-    assert roof["traffic"] == roof["physical_bytes_per_launch"] and 0.05 < roof["physical_frac"] < 0.6 < roof["frac"]
+    assert abs(roof["achieved"] - roof["traffic"] / (roof["avg_launch_ms"] * 1e-3) / 1e9) < 1.0
+    assert abs(roof["effective_frac"] - roof["algorithmic_bytes_per_launch"] / (roof["avg_launch_ms"] * 1e-3) / 1e9 / 8000.0) < 1e-3
+    # the fused kernel moves a fraction of the algorithmic bytes: physically far below the HBM peak, bound by VALU issue
+    assert roof["bound"] == "valu" and 0.05 < roof["frac"] < 0.6 < roof["effective_frac"]
+    assert roof["pmc_source"].startswith("this run")                    # counters measured in the run, not quoted
 
 
 # ---- the product's host layer against THE REFERENCE'S OWN host code ---------------------------------------
