@@ -16,7 +16,8 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(_HERE)
-HIP_LIB_PATH = os.path.join(_HERE, "csrc", "libflow2d_hip.so")
+# FLOW2D_HIP_LIB: an experimental build of the HIP library (ab/*.so, tools/ab_time.sh) instead of the in-tree one
+HIP_LIB_PATH = os.environ.get("FLOW2D_HIP_LIB") or os.path.join(_HERE, "csrc", "libflow2d_hip.so")
 HOST_LIB_PATH = os.path.join(_HERE, "host", "libflow2d_host.so")
 CLI_PATH = os.path.join(_HERE, "host", "flow2d")
 
@@ -125,6 +126,7 @@ def hip_lib():
         L.flow2d_solve_2d_sor.argtypes = [vp] * 9 + [sz, sz, sz, f, f, f, f, i]
         L.flow2d_solve_level.argtypes = [vp] * 11 + [C.POINTER(SolveParams), C.POINTER(i)]
         L.flow2d_timing_enable.argtypes = [vp, i]
+        L.flow2d_fused_fallbacks.argtypes = [vp, C.POINTER(C.c_ulonglong)]
         L.flow2d_timing_launch_filter.argtypes = [vp, sz, sz]
         L.flow2d_timing_count.argtypes = [vp, C.POINTER(sz)]
         L.flow2d_timing_get.argtypes = [vp, sz, C.POINTER(TimingRecord)]
@@ -220,6 +222,12 @@ class Context:
         a, b = C.c_size_t(), C.c_size_t()
         _check(hip_lib().flow2d_mem_info(self.handle, C.byref(a), C.byref(b)), "flow2d_mem_info")
         return a.value, b.value
+
+    def fused_fallbacks(self):
+        """Waves of the fused kernel that repeated their strip with the plain division (synchronises)."""
+        n = C.c_ulonglong()
+        _check(hip_lib().flow2d_fused_fallbacks(self.handle, C.byref(n)), "flow2d_fused_fallbacks")
+        return n.value
 
     def device_name(self):
         buf = C.create_string_buffer(256)

@@ -28,6 +28,8 @@ struct flow2d_context {
     // flow2d_context_set_batch: every launch runs `batch_count` instances, instance b on plane pointers + b * stride
     unsigned batch_count = 1;
     size_t batch_stride_floats = 0;
+    // device counter: waves of the fused kernel that repeated their strip with the plain division (flow2d_fused_fallbacks)
+    unsigned int* fused_fallbacks = nullptr;
 };
 
 // How a kernel finds its instance of a batched launch: grid.z = planes x batch_count, plane = z % planes (the

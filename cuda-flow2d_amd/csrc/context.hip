@@ -108,6 +108,13 @@ static int create_context(int device_ordinal, void* stream, bool adopt, flow2d_c
         }
         ctx->owns_stream = true;
     }
+    // (stream-ordered on the context's own stream: a call on the NULL stream here would bring the legacy default stream
+    //  to life, and with it the lanes of a batch lose their overlap -- measured: config 2 at half its rate)
+    if (hipMalloc(reinterpret_cast<void**>(&ctx->fused_fallbacks), sizeof(unsigned int)) != hipSuccess ||
+        hipMemsetAsync(ctx->fused_fallbacks, 0, sizeof(unsigned int), ctx->stream) != hipSuccess) {
+        (void)hipGetLastError();
+        ctx->fused_fallbacks = nullptr;  // diagnostics only: the kernels run without it
+    }
     int cus = 0;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device_ordinal) == hipSuccess && cus > 0)
         ctx->num_cus = cus;
@@ -133,6 +140,7 @@ int flow2d_context_destroy(flow2d_context* ctx)
     for (hipEvent_t ev : ctx->event_pool) (void)hipEventDestroy(ev);
     ctx->event_pool.clear();
     if (ctx->owns_stream) (void)hipStreamDestroy(ctx->stream);
+    if (ctx->fused_fallbacks) (void)hipFree(ctx->fused_fallbacks);
     delete ctx;
     return FLOW2D_OK;
 }
@@ -155,6 +163,19 @@ int flow2d_synchronize(flow2d_context* ctx)
 {
     FLOW2D_ENTER(ctx);
     FLOW2D_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return FLOW2D_OK;
+}
+
+int flow2d_fused_fallbacks(flow2d_context* ctx, unsigned long long* waves)
+{
+    FLOW2D_ENTER(ctx);
+    if (!waves) return FLOW2D_ERR_INVALID_ARGUMENT;
+    *waves = 0;
+    if (!ctx->fused_fallbacks) return FLOW2D_OK;
+    unsigned int n = 0;
+    FLOW2D_HIP_TRY(hipMemcpyAsync(&n, ctx->fused_fallbacks, sizeof(n), hipMemcpyDeviceToHost, ctx->stream));
+    FLOW2D_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    *waves = n;
     return FLOW2D_OK;
 }
 

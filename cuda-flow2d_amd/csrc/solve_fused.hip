@@ -20,9 +20,17 @@
 //  - Every pixel goes through exactly the expressions of solve_2d.cu (solver_math.hpp), in the same
 //    order, without FMA contraction: results are bit-identical to the per-sweep kernels and the oracle.
 //
-// Bound: fp32 VALU issue, not HBM: 368 VALU instructions per wave and row step at inner = 5 (interior strips), a
-// third of them the twelve correctly rounded divisions; measured breakdown and the per-instruction issue rates
-// are in DESIGN.md section 3.1.
+//  - The ten divisions of a row step (two per sweep, solve_2d.cu:363,367) are three instructions each: with
+//    y = RN(1 / den) taken once per pixel and outer iteration by a true division, q0 = n * y, r = fma(-q0, den, n),
+//    q = fma(r, y, q0) is RN(n / den) bit for bit -- for every pair of fp32 significands, checked exhaustively on the
+//    device (tools/ubench/markstein_exhaustive.hip, 7.0e13 pairs), and therefore for all operands that keep q0 and r
+//    inside the normal range.  The kernel checks exactly that as it goes (den within [2^-30, 2^40], no numerator in
+//    (0, 2^-80), no stored value infinite or NaN); a wave that sees anything else repeats its strip with the plain
+//    division, so the result never depends on the shortcut.
+//  - Border strips are shorter than interior ones (FusedPlan): a wave on an image border executes about a fifth more
+//    instructions per row, and a launch -- one round of waves -- lasts as long as its slowest wave.
+//
+// Bound: fp32 VALU issue, not HBM; measured breakdown and the per-instruction issue rates are in DESIGN.md section 3.1.
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
@@ -45,7 +53,17 @@ struct FusedArgs {
     float* out_du;
     float* out_dv;
     int w, h, pitch;
-    int rows_per_strip;
+    // Strip heights (FusedPlan): a wave whose strip touches an image border runs the EDGE body, about a fifth more
+    // instructions per row than an interior wave's, and a launch is one round of waves -- as long as its slowest wave.
+    // So border strips are shorter: the first and the last strip of every column of strips hold rows_edge rows, the ones
+    // between them rows_interior (strips_interior strips per column in all); the first and the last BLOCK in x (they
+    // hold the strips on the left / right border) are cut into strips of rows_edge throughout.  rows_interior ==
+    // rows_edge: uniform strips.
+    int rows_interior, rows_edge, strips_interior;
+    // The grid is one-dimensional over the blocks that have a strip (a two-dimensional grid would hold empty blocks,
+    // and with blocks dealt to the eight XCDs in turn the working ones would pile up on some of them): block id ->
+    // (block column, strip) by blocks_x, the block columns of the image.
+    int blocks_x;
     int zero_increment;  // first outer iteration: du = dv = 0, the planes are not read (and need no memset)
     // More sweeps per outer iteration than one launch holds: a later launch of the same outer iteration rebuilds
     // the coefficients from the same du/dv (identical arithmetic, identical values) and continues the sweeps
@@ -54,22 +72,29 @@ struct FusedArgs {
     const float* start_dv;
     int continue_sweeps;
     float hx, hy, alpha, e_smooth, e_data;
+    // Wave-uniform constants of the level, evaluated on the HOST in the reference's float / double arithmetic (the same
+    // IEEE operations the kernel would perform) so that they arrive as kernel arguments in scalar registers: computed in
+    // the kernel they are vector-ALU results, which the compiler broadcasts into vector register pairs, hoists out of the
+    // row loop and -- the register file being full -- spills, one scratch reload per use and row step.
+    float two_hx, two_hy, four_hx, four_hy;          // 2h, 4h (solve_2d.cu:141-171)
+    float inv_two_hx, inv_two_hy, inv_four_hx, inv_four_hy;  // their reciprocals (exact when h is a power of two)
+    float hx_1, hy_1;                                // float(1.0 / (2.0 * h)), solve_2d.cu:868-869
+    float hx_2, hy_2;                                // alpha / (h * h), solve_2d.cu:337-340
     unsigned long long batch_stride;  // floats between the instances of a batched launch (blockIdx.z)
-    // developer diagnostics (FLOW2D_FUSED_STAMPS=1): per wave {start, end} in 100 MHz ticks, hardware id, xcc id
-    unsigned long long* stamps;
+    unsigned int* fallback_count;     // waves that repeated their strip with the plain division (diagnostics; may be null)
 };
 
-// Plane rows are fetched with buffer loads: a 128-bit descriptor per plane in scalar registers, the row offset
-// as the scalar offset, the lane's column as a 32-bit vector offset.  Half the address payload of a global
-// load with per-lane 64-bit addresses, and no vector address arithmetic.
-using rsrc_t = __amdgpu_buffer_rsrc_t;
-__device__ __forceinline__ rsrc_t plane_rsrc(const float* plane, unsigned bytes)
+// A plane row is addressed as base pointer (a scalar register pair) + one 32-bit per-lane byte offset that all planes
+// share (global_load / global_store ... saddr): two scalar registers per plane.  (Buffer descriptors, four scalar
+// registers per plane, pushed the kernel past the scalar register file: the descriptors were spilled to vector-register
+// lanes and read back, 24 v_readlane per row step.)  Planes stay below 4 GiB (fused_addressable).
+__device__ __forceinline__ float plane_load(const float* plane, unsigned byte_offset)
 {
-    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(plane), 0, bytes, 0x00020000);
+    return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(plane) + static_cast<size_t>(byte_offset));
 }
-__device__ __forceinline__ float plane_load(rsrc_t r, unsigned col_bytes, unsigned row_bytes)
+__device__ __forceinline__ void plane_store(float* plane, unsigned byte_offset, float value)
 {
-    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, col_bytes, row_bytes, 0));
+    *reinterpret_cast<float*>(reinterpret_cast<char*>(plane) + static_cast<size_t>(byte_offset)) = value;
 }
 
 // lane i receives lane i-1 (wave_shr:1) / lane i+1 (wave_shl:1); the end lanes of the wave receive 0
@@ -87,11 +112,56 @@ __device__ __forceinline__ float from_right(float v)
 // static per-pixel coefficients of one outer iteration (what the sweeps need besides the moving flow)
 struct Coef {
     v2f wx, wy;    // (w_x+, w_x-), (w_y+, w_y-): face diffusivity * neighbour weight (solve_2d.cu:337-346)
+    v2f uvc;       // (u, v) of the pixel
     v2f den;       // (ksi * J11 + sumH, ksi * J22 + sumH) (solve_2d.cu:363,367)
+    v2f rden;      // (RN(1 / den.x), RN(1 / den.y)): three-step division only
     v2f J13_23;    // (J13, J23)
     float ksi, J12;
-    v2f uvc;       // (u, v) of the pixel
 };
+
+// n / d through the prepared reciprocal y = RN(1 / d): RN(n / d) exactly whenever q0 and r stay in the normal range
+// (see the header).
+__device__ __forceinline__ float div3(float n, float d, float y)
+{
+    const float q0 = n * y;
+    const float r = __builtin_fmaf(-q0, d, n);
+    return __builtin_fmaf(r, y, q0);
+}
+
+// What the proof does not cover is recorded per lane in three unsigned accumulators -- integer min / max on the operands'
+// bit patterns, vector ALU only (a comparison per division would go through the scalar unit: measured, it costs more than
+// the divisions it guards) -- and judged once, after the strip:
+//   tiny: min of (bits(n) << 1) - 1 over the numerators: the shift drops the sign, the decrement sends a zero (harmless:
+//         q0 = r = q = 0) to the top; a non-zero numerator below 2^-80 lands below kTinyLimit
+//   den : max of bits(den) - bits(2^-30): above kDenSpan for a denominator outside [2^-30, 2^40], negative or NaN
+//   out : max of bits(du, dv) << 1 over the stored results: above kOutLimit for an infinity or a NaN
+struct DivGuard {
+    unsigned tiny, den, out;
+};
+constexpr unsigned kTinyLimit = 2u * 0x17800000u - 1u;         // 2^-80 = 0x17800000
+constexpr unsigned kDenLow = 0x30800000u, kDenSpan = 0x53800000u - 0x30800000u;  // 2^-30, 2^40
+constexpr unsigned kOutLimit = 0xfefffffeu;                    // FLT_MAX << 1
+// (the empty asm pins each update where it is written: left alone, the compiler sinks all updates of a ring turn to the
+//  loop latch and keeps the sixty numerators of the turn alive until then)
+__device__ __forceinline__ void guard_numerators(DivGuard& g, float nu, float nv)
+{
+    g.tiny = min(g.tiny, min((__float_as_uint(nu) << 1) - 1u, (__float_as_uint(nv) << 1) - 1u));
+    asm volatile("" : "+v"(g.tiny));
+}
+__device__ __forceinline__ void guard_denominators(DivGuard& g, float du, float dv)
+{
+    g.den = max(g.den, max(__float_as_uint(du) - kDenLow, __float_as_uint(dv) - kDenLow));
+    asm volatile("" : "+v"(g.den));
+}
+__device__ __forceinline__ void guard_results(DivGuard& g, float du, float dv)
+{
+    g.out = max(g.out, max(__float_as_uint(du) << 1, __float_as_uint(dv) << 1));
+    asm volatile("" : "+v"(g.out));
+}
+__device__ __forceinline__ bool guard_tripped(const DivGuard& g)
+{
+    return g.tiny < kTinyLimit || g.den > kDenSpan || g.out > kOutLimit;
+}
 
 __device__ __forceinline__ v2f from_left2(v2f v) { return v2f{from_left(v.x), from_left(v.y)}; }
 __device__ __forceinline__ v2f from_right2(v2f v) { return v2f{from_right(v.x), from_right(v.y)}; }
@@ -119,12 +189,15 @@ struct Strip {
     Coef C[kRing];
     // brightness derivatives and ksi of the row stage W consumes next (produced by stage P one step earlier)
     float p_fx, p_fy, p_ft, p_ksi;
-    // prefetched input row
+    // two prefetched input rows in flight: row r+1 (n_*, fetched a step ago) and row r+2 (m_*, fetched in this step)
     float n_f0, n_f1;
     v2f n_uv, n_duv;
+    float m_f0, m_f1;
+    v2f m_uv, m_duv;
     // continue_sweeps only: the sweeps' starting increment of row r-2 (start_cur) and the row fetched for the
     // next step (n_start)
     v2f start_cur, n_start;
+    DivGuard guard;  // three-step division: operands outside the proven range leave their mark here
 };
 
 // EDGE = false: the strip touches no image border, so the reflect substitutions (a v_cndmask per
@@ -136,9 +209,10 @@ struct Strip {
 // stored row y needs sweep k on rows y-(INNER-k) .. y+(INNER-k) only, so during the first steps of a strip the later
 // stages would work on rows nothing depends on: stage P is first needed at step 2, stage W at step 3, sweep k at
 // step 3 + 2k.  The start-up steps are peeled off the row loop and compiled without those stages.
-template <int INNER, int GRAD, bool EDGE, bool POW2, bool CONT, int J, int T = -1>
+// FAST: the sweeps divide through the prepared reciprocal (div3); false = plain division (the fallback pass).
+template <int INNER, int GRAD, bool EDGE, bool POW2, bool CONT, bool FAST, int J, int T = -1>
 __device__ __forceinline__ void strip_step(Strip<INNER, GRAD>& s, const FusedArgs& a, int r, int x, int xc, bool at_l,
-                                           bool at_r, bool lane_stores, int y0, int y1, v2f xpm, float hx_2,
+                                           bool at_r, bool lane_stores, int y0, int y1, float hx_2,
                                            float hy_2)
 {
     using S = Strip<INNER, GRAD>;
@@ -154,10 +228,8 @@ __device__ __forceinline__ void strip_step(Strip<INNER, GRAD>& s, const FusedArg
     if (cont) {
         s.start_cur = s.n_start;  // row r-2
         const int rs = min(max(r - 1, 0), h - 1);
-        const unsigned row_bytes = static_cast<unsigned>(rs) * static_cast<unsigned>(a.pitch) * 4u;
-        const unsigned plane_bytes = static_cast<unsigned>(h) * static_cast<unsigned>(a.pitch) * 4u;
-        s.n_start = v2f{plane_load(plane_rsrc(a.start_du, plane_bytes), static_cast<unsigned>(xc) * 4u, row_bytes),
-                        plane_load(plane_rsrc(a.start_dv, plane_bytes), static_cast<unsigned>(xc) * 4u, row_bytes)};
+        const unsigned off = (static_cast<unsigned>(rs) * static_cast<unsigned>(a.pitch) + static_cast<unsigned>(xc)) * 4u;
+        s.n_start = v2f{plane_load(a.start_du, off), plane_load(a.start_dv, off)};
     }
     s.f0w[s0] = s.n_f0;
     s.f1w[s0] = s.n_f1;
@@ -167,18 +239,14 @@ __device__ __forceinline__ void strip_step(Strip<INNER, GRAD>& s, const FusedArg
         s.lf0w[s0] = log1p_frame(s.n_f0);
         s.lf1w[s0] = log1p_frame(s.n_f1);
     }
-    {  // prefetch row r+1 (clamped: rows outside the image are never used by a stored pixel)
-        const int rn = min(max(r + 1, 0), h - 1);
-        const unsigned row_bytes = static_cast<unsigned>(rn) * static_cast<unsigned>(a.pitch) * 4u;
-        const unsigned col_bytes = static_cast<unsigned>(xc) * 4u;
-        const unsigned plane_bytes = static_cast<unsigned>(h) * static_cast<unsigned>(a.pitch) * 4u;
-        s.n_f0 = plane_load(plane_rsrc(a.f0, plane_bytes), col_bytes, row_bytes);
-        s.n_f1 = plane_load(plane_rsrc(a.f1, plane_bytes), col_bytes, row_bytes);
-        s.n_uv = v2f{plane_load(plane_rsrc(a.u, plane_bytes), col_bytes, row_bytes),
-                     plane_load(plane_rsrc(a.v, plane_bytes), col_bytes, row_bytes)};
-        s.n_duv = a.zero_increment ? v2f{0.f, 0.f}
-                                   : v2f{plane_load(plane_rsrc(a.du, plane_bytes), col_bytes, row_bytes),
-                                         plane_load(plane_rsrc(a.dv, plane_bytes), col_bytes, row_bytes)};
+    {  // row r+1 arrived a step ago; fetch row r+2 (clamped: rows outside the image are never used by a stored pixel)
+        s.n_f0 = s.m_f0, s.n_f1 = s.m_f1, s.n_uv = s.m_uv, s.n_duv = s.m_duv;
+        const int rn = min(max(r + 2, 0), h - 1);
+        const unsigned off = (static_cast<unsigned>(rn) * static_cast<unsigned>(a.pitch) + static_cast<unsigned>(xc)) * 4u;
+        s.m_f0 = plane_load(a.f0, off);
+        s.m_f1 = plane_load(a.f1, off);
+        s.m_uv = v2f{plane_load(a.u, off), plane_load(a.v, off)};
+        s.m_duv = a.zero_increment ? v2f{0.f, 0.f} : v2f{plane_load(a.du, off), plane_load(a.dv, off)};
     }
 
     constexpr bool run_P = T < 0 || T >= 2, run_W = T < 0 || T >= 3;
@@ -200,11 +268,11 @@ __device__ __forceinline__ void strip_step(Strip<INNER, GRAD>& s, const FusedArg
         const v2f ynum = diff4_num2(uvD, uvU, duvD, duvU);  // numerators of (duy, dvy)
         v2f dx, dy;
         if (POW2) {
-            dx = xnum * (1.f / (2.f * a.hx));
-            dy = ynum * (1.f / (2.f * a.hy));
+            dx = xnum * a.inv_two_hx;
+            dy = ynum * a.inv_two_hy;
         } else {
-            dx = v2f{xnum.x / (2.f * a.hx), xnum.y / (2.f * a.hx)};
-            dy = v2f{ynum.x / (2.f * a.hy), ynum.y / (2.f * a.hy)};
+            dx = v2f{xnum.x / a.two_hx, xnum.y / a.two_hx};
+            dy = v2f{ynum.x / a.two_hy, ynum.y / a.two_hy};
         }
         s.phiw[s1] = phi_value(dx.x, dy.x, dx.y, dy.y, a.e_smooth);
 
@@ -214,8 +282,8 @@ __device__ __forceinline__ void strip_step(Strip<INNER, GRAD>& s, const FusedArg
         const float f1L = at_l ? f1r0 : f1l0, f1R = at_r ? f1l0 : f1r0;
         const float f0U = top ? s.f0w[s0] : s.f0w[s2], f0D = bot ? s.f0w[s2] : s.f0w[s0];
         const float f1U = top ? s.f1w[s0] : s.f1w[s2], f1D = bot ? s.f1w[s2] : s.f1w[s0];
-        fx = diff4s<POW2>(f0R, f0L, f1R, f1L, 4.f * a.hx, 1.f / (4.f * a.hx));
-        fy = diff4s<POW2>(f0D, f0U, f1D, f1U, 4.f * a.hy, 1.f / (4.f * a.hy));
+        fx = diff4s<POW2>(f0R, f0L, f1R, f1L, a.four_hx, a.inv_four_hx);
+        fy = diff4s<POW2>(f0D, f0U, f1D, f1U, a.four_hy, a.inv_four_hy);
         ft = f1c - f0c;
         ksi = ksi_value(fx, fy, ft, s.duvw[s1].x, s.duvw[s1].y, a.e_data);
         if (GRAD == 3) {
@@ -227,8 +295,8 @@ __device__ __forceinline__ void strip_step(Strip<INNER, GRAD>& s, const FusedArg
             const float l1L = x_lo ? l1c : l1l0, l1R = x_hi ? l1c : (at_r ? l1l0 : l1r0);
             const float l0U = y_lo ? l0c : s.lf0w[s2], l0D = y_hi ? l0c : (bot ? s.lf0w[s2] : s.lf0w[s0]);
             const float l1U = y_lo ? l1c : s.lf1w[s2], l1D = y_hi ? l1c : (bot ? s.lf1w[s2] : s.lf1w[s0]);
-            s.fxw[s1] = diff4s<POW2>(l0R, l0L, l1R, l1L, 4.f * a.hx, 1.f / (4.f * a.hx));
-            s.fyw[s1] = diff4s<POW2>(l0D, l0U, l1D, l1U, 4.f * a.hy, 1.f / (4.f * a.hy));
+            s.fxw[s1] = diff4s<POW2>(l0R, l0L, l1R, l1L, a.four_hx, a.inv_four_hx);
+            s.fyw[s1] = diff4s<POW2>(l0D, l0U, l1D, l1U, a.four_hy, a.inv_four_hy);
             s.ftw[s1] = l1c - l0c;
         } else if (GRAD) {
             s.fxw[s1] = fx;
@@ -259,17 +327,20 @@ __device__ __forceinline__ void strip_step(Strip<INNER, GRAD>& s, const FusedArg
         }
         const float yp = EDGE ? static_cast<float>(rw < h - 1) * hy_2 : hy_2;
         const float ym = EDGE ? static_cast<float>(rw > 0) * hy_2 : hy_2;
-        c.wx = (p_rl + pc) / 2.f * xpm;                                                  // face_phi * (xp, xm)
+        // face_phi * (xp, xm), solve_2d.cu:337-346: xp = [x < w-1] * alpha / hx^2, xm = [x > 0] * alpha / hx^2; an interior
+        // strip has no image border, so both are the uniform alpha / hx^2 there
+        c.wx = (p_rl + pc) / 2.f * (EDGE ? v2f{at_r ? 0.f : hx_2, at_l ? 0.f : hx_2} : v2f{hx_2, hx_2});
         c.wy = v2f{face_phi(pD, pc) * yp, face_phi(pU, pc) * ym};
         const float sumH = sum_weights(c.wx.x, c.wx.y, c.wy.x, c.wy.y);
-        c.ksi = s.p_ksi;
+        const float c_ksi = s.p_ksi;
         c.uvc = s.uvw[s2];
-        v2f J11_22;
+        v2f J11_22, c_J13_23;
+        float c_J12;
         if (!GRAD) {
             const v2f fxy = v2f{s.p_fx, s.p_fy};
             J11_22 = fxy * fxy;
-            c.J12 = s.p_fx * s.p_fy;
-            c.J13_23 = fxy * s.p_ft;
+            c_J12 = s.p_fx * s.p_fy;
+            c_J13_23 = fxy * s.p_ft;
         } else {
             // second derivatives inside the reference's 16x8 blocks, own value replicated at block and
             // image edges (solve_2d.cu:816-841,872-876); fx/fy/ft rings: s1 = row r-1, s2 = r-2, s0 = r-3
@@ -295,19 +366,28 @@ __device__ __forceinline__ void strip_step(Strip<INNER, GRAD>& s, const FusedArg
                 fy_u = top ? s.fyw[s1] : s.fyw[s0], fy_d = bot ? s.fyw[s0] : s.fyw[s1];
                 ft_u = top ? s.ftw[s1] : s.ftw[s0], ft_d = bot ? s.ftw[s0] : s.ftw[s1];
             }
-            const float hx_1 = 1.0 / (2.0 * a.hx);  // double, rounded to float (solve_2d.cu:868-869)
-            const float hy_1 = 1.0 / (2.0 * a.hy);
+            const float hx_1 = a.hx_1, hy_1 = a.hy_1;  // float(1.0 / (2.0 * h)): double, rounded to float (solve_2d.cu:868-869)
             const float fxx = (fx_r - fx_l) * hx_1;
             const float fxy = (fx_d - fx_u) * hy_1;
             const float fyy = (fy_d - fy_u) * hy_1;
             const float fxt = (ft_r - ft_l) * hx_1;
             const float fyt = (ft_d - ft_u) * hy_1;
             float J11, J22, J13, J23;
-            gradient_tensor(fxx, fxy, fyy, fxt, fyt, J11, J22, c.J12, J13, J23);
+            gradient_tensor(fxx, fxy, fyy, fxt, fyt, J11, J22, c_J12, J13, J23);
             J11_22 = v2f{J11, J22};
-            c.J13_23 = v2f{J13, J23};
+            c_J13_23 = v2f{J13, J23};
         }
-        c.den = c.ksi * J11_22 + sumH;  // update_denominator for u and v
+        const v2f c_den = c_ksi * J11_22 + sumH;  // update_denominator for u and v
+        v2f c_rden = v2f{0.f, 0.f};
+        if (FAST) {
+            c_rden = v2f{1.0f / c_den.x, 1.0f / c_den.y};
+            guard_denominators(s.guard, c_den.x, c_den.y);
+        }
+        c.den = c_den;
+        c.rden = c_rden;
+        c.J13_23 = c_J13_23;
+        c.ksi = c_ksi;
+        c.J12 = c_J12;
         // (u + du, v + dv) of row r-2 enters sweep 1's window
         s.UV[0][s2] = s.uvw[s2] + (cont ? s.start_cur : s.duvw[s2]);
     }
@@ -325,7 +405,10 @@ __device__ __forceinline__ void strip_step(Strip<INNER, GRAD>& s, const FusedArg
         const int rk = r - 2 - k;
         // window slots of rows rk-1, rk, rk+1 (rk = r-2-k  ->  slot (J - 2 - k) mod 3)
         const int sc = (J + 3 * 8 - 2 - k) % 3, su = (sc + 2) % 3, sd = (sc + 1) % 3;
-        const Coef& c = s.C[(J + 4 * kRing - 2 - k) % kRing];
+        const int ck = (J + 4 * kRing - 2 - k) % kRing;  // a constant once the sweep loop is unrolled
+        const Coef& c = s.C[ck];
+        const v2f den = c.den, rden = c.rden, J13_23 = c.J13_23;
+        const float ksi = c.ksi, J12 = c.J12;
         const bool top = EDGE && (rk == 0), bot = EDGE && (rk == h - 1);
         const v2f n_c = s.UV[k - 1][sc];
         const v2f n_l0 = from_left2(n_c), n_r0 = from_right2(n_c);
@@ -341,76 +424,70 @@ __device__ __forceinline__ void strip_step(Strip<INNER, GRAD>& s, const FusedArg
         }
         const v2f sums = sum_flux2(c.wx, c.wy, nR, nL, nD, nU, c.uvc);  // (sumU, sumV)
         float du_new, dv_new;
-        point_update(c.ksi, c.den.x, c.den.y, c.J12, c.J13_23.x, c.J13_23.y, sums.x, sums.y, dv_in, du_new, dv_new);
+        if (FAST) {  // the coupled 2x2 update of solve_2d.cu:361-367 (point_update) with the three-step division
+            const float nu = ksi * (-J13_23.x - J12 * dv_in) + sums.x;
+            du_new = div3(nu, den.x, rden.x);
+            const float nv = ksi * (-J13_23.y - J12 * du_new) + sums.y;
+            dv_new = div3(nv, den.y, rden.y);
+            guard_numerators(s.guard, nu, nv);
+            if (k == INNER) guard_results(s.guard, du_new, dv_new);
+        } else {
+            point_update(ksi, den.x, den.y, J12, J13_23.x, J13_23.y, sums.x, sums.y, dv_in, du_new, dv_new);
+        }
         if (k < INNER) {
             s.UV[k][sc] = c.uvc + v2f{du_new, dv_new};
             dv_in = s.dvc[k];      // dv^k of row r-3-k, produced by this sweep one step ago
             s.dvc[k] = dv_new;     // dv^k of row r-2-k, for the next step
         } else if (lane_stores && rk >= y0 && rk < y1) {
-            const size_t o = static_cast<size_t>(rk) * a.pitch + x;
-            a.out_du[o] = du_new;
-            a.out_dv[o] = dv_new;
+            const unsigned off = (static_cast<unsigned>(rk) * static_cast<unsigned>(a.pitch) + static_cast<unsigned>(xc)) * 4u;
+            plane_store(a.out_du, off, du_new);
+            plane_store(a.out_dv, off, dv_new);
         }
     }
 }
 
-template <int INNER, int GRAD, bool EDGE, bool POW2, bool CONT, size_t... Js>
+template <int INNER, int GRAD, bool EDGE, bool POW2, bool CONT, bool FAST, size_t... Js>
 __device__ __forceinline__ void strip_steps(Strip<INNER, GRAD>& s, const FusedArgs& a, int r_base, int x, int xc,
-                                            bool at_l, bool at_r, bool lane_stores, int y0, int y1, v2f xpm,
+                                            bool at_l, bool at_r, bool lane_stores, int y0, int y1, 
                                             float hx_2, float hy_2, std::index_sequence<Js...>)
 {
-    (strip_step<INNER, GRAD, EDGE, POW2, CONT, static_cast<int>(Js)>(s, a, r_base + static_cast<int>(Js), x, xc, at_l, at_r,
-                                                               lane_stores, y0, y1, xpm, hx_2, hy_2),
+    (strip_step<INNER, GRAD, EDGE, POW2, CONT, FAST, static_cast<int>(Js)>(s, a, r_base + static_cast<int>(Js), x, xc, at_l,
+                                                                     at_r, lane_stores, y0, y1, hx_2, hy_2),
      ...);
 }
 
 // the last, partial turn of the ring: the steps up to r_last only (wave-uniform guards)
-template <int INNER, int GRAD, bool EDGE, bool POW2, bool CONT, size_t... Js>
+template <int INNER, int GRAD, bool EDGE, bool POW2, bool CONT, bool FAST, size_t... Js>
 __device__ __forceinline__ void strip_tail(Strip<INNER, GRAD>& s, const FusedArgs& a, int r_base, int r_last, int x, int xc,
-                                           bool at_l, bool at_r, bool lane_stores, int y0, int y1, v2f xpm, float hx_2,
+                                           bool at_l, bool at_r, bool lane_stores, int y0, int y1, float hx_2,
                                            float hy_2, std::index_sequence<Js...>)
 {
     ((r_base + static_cast<int>(Js) <= r_last
-          ? strip_step<INNER, GRAD, EDGE, POW2, CONT, static_cast<int>(Js)>(s, a, r_base + static_cast<int>(Js), x, xc, at_l,
-                                                                          at_r, lane_stores, y0, y1, xpm, hx_2, hy_2)
+          ? strip_step<INNER, GRAD, EDGE, POW2, CONT, FAST, static_cast<int>(Js)>(s, a, r_base + static_cast<int>(Js), x, xc,
+                                                                                at_l, at_r, lane_stores, y0, y1, hx_2,
+                                                                                hy_2)
           : (void)0),
      ...);
 }
 
-template <int INNER, int GRAD, bool EDGE, bool POW2, bool CONT, size_t... Ts>
+template <int INNER, int GRAD, bool EDGE, bool POW2, bool CONT, bool FAST, size_t... Ts>
 __device__ __forceinline__ void strip_startup(Strip<INNER, GRAD>& s, const FusedArgs& a, int r_first, int x, int xc,
-                                              bool at_l, bool at_r, bool lane_stores, int y0, int y1, v2f xpm,
+                                              bool at_l, bool at_r, bool lane_stores, int y0, int y1, 
                                               float hx_2, float hy_2, std::index_sequence<Ts...>)
 {
     constexpr int kRing = Strip<INNER, GRAD>::kRing;
-    (strip_step<INNER, GRAD, EDGE, POW2, CONT, static_cast<int>(Ts) % kRing, static_cast<int>(Ts)>(
-         s, a, r_first + static_cast<int>(Ts), x, xc, at_l, at_r, lane_stores, y0, y1, xpm, hx_2, hy_2),
+    (strip_step<INNER, GRAD, EDGE, POW2, CONT, FAST, static_cast<int>(Ts) % kRing, static_cast<int>(Ts)>(
+         s, a, r_first + static_cast<int>(Ts), x, xc, at_l, at_r, lane_stores, y0, y1, hx_2, hy_2),
      ...);
 }
 
-template <int INNER, int GRAD, bool POW2, bool CONT>
-__global__ __launch_bounds__(256, 2) void fused_outer_kernel(FusedArgs a)
+// One trip of a wave down its strip: state set-up, the peeled start-up steps, the row loop, the partial last ring turn.
+// Returns whether any lane met operands the three-step division is not proven for (always false with FAST = false).
+template <int INNER, int GRAD, bool EDGE, bool POW2, bool CONT, bool FAST>
+__device__ __forceinline__ bool run_strip(const FusedArgs& a, int x, int xc, bool at_l, bool at_r, bool lane_stores, int y0,
+                                          int y1, float hx_2, float hy_2)
 {
     using S = Strip<INNER, GRAD>;
-    const int lane = threadIdx.x & 63;
-    const int strip_x = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (strip_x * S::kValid >= a.w) return;  // whole wave leaves; waves never synchronise with each other
-    {  // instance of a batched launch
-        const size_t off = static_cast<size_t>(blockIdx.z) * static_cast<size_t>(a.batch_stride);
-        a.f0 += off, a.f1 += off, a.u += off, a.v += off, a.du += off, a.dv += off, a.out_du += off, a.out_dv += off;
-        if (CONT) a.start_du += off, a.start_dv += off;
-    }
-    const unsigned long long t_start = a.stamps ? __builtin_amdgcn_s_memrealtime() : 0ull;
-    const int x = strip_x * S::kValid - S::kHalo + lane;
-    const int xc = min(max(x, 0), a.w - 1);
-    const int y0 = blockIdx.y * a.rows_per_strip;
-    const int y1 = min(y0 + a.rows_per_strip, a.h);
-    const bool at_l = (x == 0), at_r = (x == a.w - 1);
-    const bool lane_stores = lane >= S::kHalo && lane < 64 - S::kHalo && x < a.w;
-    const float hx_2 = a.alpha / (a.hx * a.hx);
-    const float hy_2 = a.alpha / (a.hy * a.hy);
-    const v2f xpm = v2f{static_cast<float>(x < a.w - 1) * hx_2, static_cast<float>(x > 0) * hx_2};  // (xp, xm)
-
     S s;
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
@@ -426,8 +503,12 @@ __global__ __launch_bounds__(256, 2) void fused_outer_kernel(FusedArgs a)
         for (int i = 0; i < 3; ++i) s.UV[k][i] = v2f{0.f, 0.f};
     }
 #pragma unroll
-    for (int i = 0; i < S::kRing; ++i) s.C[i] = Coef{v2f{0.f, 0.f}, v2f{0.f, 0.f}, v2f{1.f, 1.f}, v2f{0.f, 0.f}, 0.f, 0.f, v2f{0.f, 0.f}};
+    for (int i = 0; i < S::kRing; ++i) {
+        s.C[i] = Coef{};
+        s.C[i].den = s.C[i].rden = v2f{1.f, 1.f};
+    }
     s.p_fx = s.p_fy = s.p_ft = s.p_ksi = 0.f;
+    s.guard = DivGuard{0xffffffffu, 0u, 0u};
 
     // first input row: the strip's first stored row needs INNER+1 rows of halo above it
     const int r_first = y0 - S::kHalo;
@@ -438,6 +519,13 @@ __global__ __launch_bounds__(256, 2) void fused_outer_kernel(FusedArgs a)
         s.n_f1 = a.f1[o];
         s.n_uv = v2f{a.u[o], a.v[o]};
         s.n_duv = a.zero_increment ? v2f{0.f, 0.f} : v2f{a.du[o], a.dv[o]};
+        {
+            const size_t o2 = static_cast<size_t>(min(max(r_first + 1, 0), a.h - 1)) * a.pitch + xc;
+            s.m_f0 = a.f0[o2];
+            s.m_f1 = a.f1[o2];
+            s.m_uv = v2f{a.u[o2], a.v[o2]};
+            s.m_duv = a.zero_increment ? v2f{0.f, 0.f} : v2f{a.du[o2], a.dv[o2]};
+        }
         s.start_cur = s.n_start = v2f{0.f, 0.f};
         if (CONT) {  // the first step commits row r_first - 2 of the starting increment
             const size_t os = static_cast<size_t>(min(max(r_first - 2, 0), a.h - 1)) * a.pitch + xc;
@@ -446,59 +534,101 @@ __global__ __launch_bounds__(256, 2) void fused_outer_kernel(FusedArgs a)
     }
     // the last stored row y1-1 leaves the last sweep at input row (y1-1) + 2 + INNER
     const int r_last = y1 - 1 + 2 + INNER;
+    // start-up steps (a whole number of ring turns, so the row loop starts at ring position 0), then the row loop
+    constexpr int kPeel = ((3 + 2 * INNER) / S::kRing) * S::kRing;
+    strip_startup<INNER, GRAD, EDGE, POW2, CONT, FAST>(s, a, r_first, x, xc, at_l, at_r, lane_stores, y0, y1, hx_2, hy_2,
+                                                       std::make_index_sequence<kPeel>{});
+    int r = r_first + kPeel;
+    for (; r + S::kRing - 1 <= r_last; r += S::kRing)
+        strip_steps<INNER, GRAD, EDGE, POW2, CONT, FAST>(s, a, r, x, xc, at_l, at_r, lane_stores, y0, y1, hx_2, hy_2,
+                                                         std::make_index_sequence<S::kRing>{});
+    strip_tail<INNER, GRAD, EDGE, POW2, CONT, FAST>(s, a, r, r_last, x, xc, at_l, at_r, lane_stores, y0, y1, hx_2, hy_2,
+                                                    std::make_index_sequence<S::kRing - 1>{});
+    return guard_tripped(s.guard);
+}
+
+// developer switch (A/B timing builds): -DFLOW2D_FUSED_PLAIN_DIVISION keeps the compiler's division in the sweeps
+#ifdef FLOW2D_FUSED_PLAIN_DIVISION
+constexpr bool kThreeStepDivision = false;
+#else
+constexpr bool kThreeStepDivision = true;
+#endif
+
+template <int INNER, int GRAD, bool POW2, bool CONT>
+__global__ __launch_bounds__(256, 2) void fused_outer_kernel(FusedArgs a)
+{
+    using S = Strip<INNER, GRAD>;
+    const int lane = threadIdx.x & 63;
+    // block id -> block column bx and strip by: uniform strips row by row; a border-aware plan first the interior
+    // block columns (strips_interior strips each), then the first and the last block column (strips of rows_edge)
+    int bx, by;
+    const bool uniform = a.rows_interior == a.rows_edge;
+    const int inner_cols = a.blocks_x - 2, inner_blocks = inner_cols * a.strips_interior;
+    if (uniform) {
+        bx = blockIdx.x % a.blocks_x, by = blockIdx.x / a.blocks_x;
+    } else if (static_cast<int>(blockIdx.x) < inner_blocks) {
+        bx = 1 + blockIdx.x % inner_cols, by = blockIdx.x / inner_cols;
+    } else {
+        const int j = blockIdx.x - inner_blocks;
+        bx = (j & 1) ? a.blocks_x - 1 : 0, by = j >> 1;
+    }
+    const int strip_x = bx * 4 + (threadIdx.x >> 6);
+    if (strip_x * S::kValid >= a.w) return;  // whole wave leaves; waves never synchronise with each other
+    {  // instance of a batched launch
+        const size_t off = static_cast<size_t>(blockIdx.z) * static_cast<size_t>(a.batch_stride);
+        a.f0 += off, a.f1 += off, a.u += off, a.v += off, a.du += off, a.dv += off, a.out_du += off, a.out_dv += off;
+        if (CONT) a.start_du += off, a.start_dv += off;
+    }
+    const int x = strip_x * S::kValid - S::kHalo + lane;
+    const int xc = min(max(x, 0), a.w - 1);
+    int y0, y1;
+    if (uniform || bx == 0 || bx == a.blocks_x - 1) {
+        y0 = by * a.rows_edge;
+        y1 = min(y0 + a.rows_edge, a.h);
+    } else if (by == 0) {
+        y0 = 0, y1 = a.rows_edge;
+    } else if (by == a.strips_interior - 1) {
+        y0 = a.h - a.rows_edge, y1 = a.h;
+    } else {
+        y0 = a.rows_edge + (by - 1) * a.rows_interior;
+        y1 = min(y0 + a.rows_interior, a.h - a.rows_edge);
+    }
+    if (y0 >= y1) return;  // (a middle strip the rounding of rows_interior left empty)
+    const bool at_l = (x == 0), at_r = (x == a.w - 1);
+    const bool lane_stores = lane >= S::kHalo && lane < 64 - S::kHalo && x < a.w;
+    const float hx_2 = a.hx_2, hy_2 = a.hy_2;
+
     // does any row or column this wave touches sit on an image border?  (a superset test is fine)
     const int x_first = strip_x * S::kValid - S::kHalo;
     const bool edge = x_first <= 0 || x_first + 63 >= a.w - 1 || y0 <= S::kHalo + 1 || y1 + S::kHalo + 1 >= a.h;
-    // start-up steps (a whole number of ring turns, so the row loop starts at ring position 0), then the row loop
-    constexpr int kPeel = ((3 + 2 * INNER) / S::kRing) * S::kRing;
-    if (__builtin_amdgcn_readfirstlane(edge)) {
-        strip_startup<INNER, GRAD, true, POW2, CONT>(s, a, r_first, x, xc, at_l, at_r, lane_stores, y0, y1, xpm, hx_2, hy_2,
-                                                     std::make_index_sequence<kPeel>{});
-        int r = r_first + kPeel;
-        for (; r + S::kRing - 1 <= r_last; r += S::kRing)
-            strip_steps<INNER, GRAD, true, POW2, CONT>(s, a, r, x, xc, at_l, at_r, lane_stores, y0, y1, xpm, hx_2, hy_2,
-                                           std::make_index_sequence<S::kRing>{});
-        strip_tail<INNER, GRAD, true, POW2, CONT>(s, a, r, r_last, x, xc, at_l, at_r, lane_stores, y0, y1, xpm, hx_2, hy_2,
-                                                  std::make_index_sequence<S::kRing - 1>{});
-    } else {
-        strip_startup<INNER, GRAD, false, POW2, CONT>(s, a, r_first, x, xc, at_l, at_r, lane_stores, y0, y1, xpm, hx_2,
-                                                      hy_2, std::make_index_sequence<kPeel>{});
-        int r = r_first + kPeel;
-        for (; r + S::kRing - 1 <= r_last; r += S::kRing)
-            strip_steps<INNER, GRAD, false, POW2, CONT>(s, a, r, x, xc, at_l, at_r, lane_stores, y0, y1, xpm, hx_2, hy_2,
-                                            std::make_index_sequence<S::kRing>{});
-        strip_tail<INNER, GRAD, false, POW2, CONT>(s, a, r, r_last, x, xc, at_l, at_r, lane_stores, y0, y1, xpm, hx_2, hy_2,
-                                                   std::make_index_sequence<S::kRing - 1>{});
-    }
-    if (a.stamps && lane == 0) {
-        unsigned long long* rec = a.stamps + 4ull * ((static_cast<size_t>(blockIdx.y) * gridDim.x + blockIdx.x) * 4 + (threadIdx.x >> 6));
-        rec[0] = t_start;
-        rec[1] = __builtin_amdgcn_s_memrealtime();
-        rec[2] = __builtin_amdgcn_s_getreg((31 << 11) | 4);   // HW_ID: wave, simd, cu, sh, se
-        rec[3] = __builtin_amdgcn_s_getreg((31 << 11) | 20);  // XCC_ID
+    bool bad;
+    if (__builtin_amdgcn_readfirstlane(edge))
+        bad = run_strip<INNER, GRAD, true, POW2, CONT, kThreeStepDivision>(a, x, xc, at_l, at_r, lane_stores, y0, y1, hx_2, hy_2);
+    else
+        bad = run_strip<INNER, GRAD, false, POW2, CONT, kThreeStepDivision>(a, x, xc, at_l, at_r, lane_stores, y0, y1, hx_2, hy_2);
+    if (kThreeStepDivision && __builtin_amdgcn_ballot_w64(bad) != 0ull) {
+        // some lane's operands left the range the three-step division is proven for: the whole strip again with the
+        // plain division (same stores, now from the reference's own arithmetic)
+        (void)run_strip<INNER, GRAD, true, POW2, CONT, false>(a, x, xc, at_l, at_r, lane_stores, y0, y1, hx_2, hy_2);
+        if (a.fallback_count && lane == 0) atomicAdd(a.fallback_count, 1u);
     }
 }
 
-// developer diagnostics: wave start/end stamps of the most recent fused launch (FLOW2D_FUSED_STAMPS=1)
-static const bool g_stamps_enabled = std::getenv("FLOW2D_FUSED_STAMPS") != nullptr;
-static unsigned long long* g_stamps = nullptr;
-static size_t g_stamps_bytes = 0, g_stamps_waves = 0;
-
-// developer knob for occupancy experiments: dynamic LDS bytes per workgroup (81920 leaves one workgroup per CU)
-static const unsigned kLdsPad = std::getenv("FLOW2D_FUSED_LDS_PAD") ? (unsigned)std::atoi(std::getenv("FLOW2D_FUSED_LDS_PAD")) : 0u;
-
-#define FUSED_LAUNCH(N)                                                                                       \
-    do {                                                                                                      \
-        if (kLdsPad > 65536)                                                                                  \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fused_outer_kernel<N, GRAD, POW2, CONT>), \
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsPad);              \
-        fused_outer_kernel<N, GRAD, POW2, CONT><<<grid, 256, kLdsPad, stream>>>(a);                           \
-        return 0;                                                                                             \
+#define FUSED_LAUNCH(N)                                                      \
+    do {                                                                     \
+        fused_outer_kernel<N, GRAD, POW2, CONT><<<grid, 256, 0, stream>>>(a); \
+        return 0;                                                            \
     } while (0)
 
 template <int GRAD, bool POW2, bool CONT>
 int launch_for_inner_cont(int inner, dim3 grid, hipStream_t stream, const FusedArgs& a)
 {
+#ifdef FLOW2D_FUSED_DEV  // developer builds (A/B timing): only the instantiations of the 4096^2 benchmark, compiled in a minute
+    if constexpr (GRAD <= 1 && POW2 && !CONT) {
+        if (inner == 5) FUSED_LAUNCH(5);
+    }
+    return 1;
+#else
     switch (inner) {
         case 1: FUSED_LAUNCH(1);
         case 2: FUSED_LAUNCH(2);
@@ -507,6 +637,7 @@ int launch_for_inner_cont(int inner, dim3 grid, hipStream_t stream, const FusedA
         case 5: FUSED_LAUNCH(5);
         default: return 1;
     }
+#endif
 }
 
 template <int GRAD, bool POW2>
@@ -533,15 +664,24 @@ bool fused_supports(size_t inner) { return inner >= 1 && inner <= 5; }
 // offset, column as a 32-bit vector offset): the plane, height x pitch bytes, must stay below 4 GiB.
 bool fused_addressable(size_t h, size_t pitch_bytes) { return h != 0 && pitch_bytes <= 0xffffffffull / h; }
 
-// Rows per strip.  A wave spends (rows + 2*inner + 3) row steps on `rows` stored rows, so tall strips
-// waste less; but the launch should fill the chip in whole co-resident rounds (two 256-thread
-// workgroups per CU at ~200 VGPRs).  Cost model in row steps: a full round of 2 workgroups per CU
-// costs 2 * steps (VALU-issue bound), a last round with at most one workgroup per CU 1.3 * steps
-// (a lone wave per SIMD cannot saturate the VALU).  The peeled start-up steps run without the stages whose
-// rows nothing depends on yet (strip_step), which is worth about six whole steps at inner = 5; the estimate
-// below weighs the stages by their instruction counts (stage P 102, stage W 20, a sweep 46, the rest 16).
-// Pick the strip height with the smallest estimate.
-int fused_rows_per_strip(const flow2d_context* ctx, size_t w, size_t h, size_t inner)
+// Strip heights of a launch.  A wave spends (rows + 2*inner + 3) row steps on `rows` stored rows, so tall strips
+// waste less; but the launch should fill the chip in whole co-resident rounds (two 256-thread workgroups per CU), and a
+// round lasts as long as its slowest wave.  Cost model in row steps of an interior wave: a wave on an image border runs
+// the EDGE body (kEdgeCost times the instructions per row), a full round of 2 workgroups per CU costs 2 x the slowest
+// wave's steps (VALU-issue bound), a last round with at most one workgroup per CU 1.3 x (a lone wave per SIMD cannot
+// saturate the VALU).  The peeled start-up steps run without the stages whose rows nothing depends on yet
+// (strip_step), which is worth about six whole steps at inner = 5; the estimate below weighs the stages by their
+// instruction counts (stage P 102, stage W 20, a sweep 46, the rest 16).
+// Candidates: uniform strips (every launch has border waves, so its rounds run at the EDGE body's pace), and for every
+// number of strips per column the border-aware partition whose border strips are shorter by the cost ratio
+// (FusedArgs::rows_edge), with the first and last block column cut into strips of that height throughout.
+struct FusedPlan {
+    int rows_interior, rows_edge, strips_interior, blocks_x, blocks;  // blocks: the launch's grid (per batch instance)
+};
+// EDGE body / interior body: 1.2-1.26 in VALU instructions per row step; FLOW2D_FUSED_EDGE_COST overrides (developer knob)
+static const double kEdgeCost = std::getenv("FLOW2D_FUSED_EDGE_COST") ? std::atof(std::getenv("FLOW2D_FUSED_EDGE_COST")) : 1.22;
+
+FusedPlan fused_plan(const flow2d_context* ctx, size_t w, size_t h, size_t inner)
 {
     const int valid = 64 - 2 * ((int)inner + 1);
     const long blocks_x = (div_up(w, valid) + 3) / 4;
@@ -551,23 +691,41 @@ int fused_rows_per_strip(const flow2d_context* ctx, size_t w, size_t h, size_t i
     const int peel = ((3 + 2 * (int)inner) / ring) * ring;
     double saved = 2 * 102.0 + 3 * 20.0;
     for (int k = 1; k <= (int)inner; ++k) saved += 46.0 * std::min(3 + 2 * k, peel);
-    const double saved_steps = saved / (138.0 + 46.0 * (double)inner);
-    double best = 1e300;
-    int best_rows = 1;
-    for (long ny = 1; ny <= (long)h; ++ny) {
-        const long rows = (long)((h + ny - 1) / ny);
-        if (rows < 1) break;
-        if ((long)((h + rows - 1) / rows) != ny) continue;  // same ny reachable with fewer rows: skip duplicates
-        const double steps = (double)(rows + 2 * (long)inner + 3) - saved_steps;  // the last ring turn is partial
-        const long blocks = blocks_x * ny * (long)ctx->batch_count;  // the instances of a batched launch share the chip
+    const double halo = (double)(2 * (long)inner + 3) - saved / (138.0 + 46.0 * (double)inner);  // the last ring turn is partial
+    const long batch = (long)ctx->batch_count;  // the instances of a batched launch share the chip
+    auto rounds = [&](long blocks, double slowest) {
         const long full = blocks / cap, rem = blocks % cap;
-        const double cost = full * 2.0 * steps + (rem == 0 ? 0.0 : (rem <= cus ? 1.3 * steps : 2.0 * steps));
-        if (cost < best - 1e-9) {
-            best = cost;
-            best_rows = (int)rows;
-        }
+        return full * 2.0 * slowest + (rem == 0 ? 0.0 : (rem <= cus ? 1.3 * slowest : 2.0 * slowest));
+    };
+    double best = 1e300;
+    FusedPlan plan{1, 1, (int)h, (int)blocks_x, (int)(blocks_x * (long)h)};
+    for (long ny = 1; ny <= (long)h; ++ny) {  // uniform strips
+        const long rows = (long)((h + ny - 1) / ny);
+        if ((long)((h + rows - 1) / rows) != ny) continue;  // same ny reachable with fewer rows: skip duplicates
+        const double cost = rounds(blocks_x * ny * batch, kEdgeCost * ((double)rows + halo));
+        if (cost < best - 1e-9) best = cost, plan = FusedPlan{(int)rows, (int)rows, (int)ny, (int)blocks_x, (int)(blocks_x * ny)};
     }
-    return best_rows;
+    for (long ny = 3; blocks_x >= 3 && ny <= (long)h / 2; ++ny) {  // border-aware: ny strips per interior column
+        // rows_edge = (rows_interior + halo) / kEdgeCost - halo and 2 rows_edge + (ny - 2) rows_interior = h
+        const double ri_real = ((double)h + 2.0 * halo - 2.0 * halo / kEdgeCost) / ((double)(ny - 2) + 2.0 / kEdgeCost);
+        long re = (long)std::floor((ri_real + halo) / kEdgeCost - halo);
+        if (re < 1 || 2 * re >= (long)h) continue;
+        const long ri = ((long)h - 2 * re + (ny - 3)) / (ny - 2);
+        if (ri < re) continue;
+        const long ny_edge = ((long)h + re - 1) / re;
+        const long blocks = ((blocks_x - 2) * ny + 2 * ny_edge) * batch;
+        const double slowest = std::max((double)ri + halo, kEdgeCost * ((double)re + halo));
+        const double cost = rounds(blocks, slowest);
+        if (cost < best - 1e-9)
+            best = cost, plan = FusedPlan{(int)ri, (int)re, (int)ny, (int)blocks_x, (int)((blocks_x - 2) * ny + 2 * ny_edge)};
+    }
+    return plan;
+}
+
+// (kept for callers that want one number: the uniform strip height, or the interior height of a border-aware plan)
+int fused_rows_per_strip(const flow2d_context* ctx, size_t w, size_t h, size_t inner)
+{
+    return fused_plan(ctx, w, h, inner).rows_interior;
 }
 
 // One outer iteration: reads du/dv (previous outer iteration), writes out_du/out_dv (after `inner` sweeps).
@@ -578,24 +736,22 @@ int launch_fused_outer(flow2d_context* ctx, int constancy, const float* f0, cons
                        const float* start_dv)
 {
     if (!fused_supports(inner) || !fused_addressable(h, pitch_bytes)) return FLOW2D_ERR_UNSUPPORTED;
-    FusedArgs a{f0, f1, u, v, du, dv, out_du, out_dv, (int)w, (int)h, (int)(pitch_bytes / 4), rows_per_strip,
+    // rows_per_strip > 0: uniform strips of that height (developer override); 0: the planner's choice
+    FusedPlan plan = fused_plan(ctx, w, h, inner);
+    if (rows_per_strip > 0)
+        plan = FusedPlan{rows_per_strip, rows_per_strip, (int)div_up(h, rows_per_strip), plan.blocks_x,
+                         plan.blocks_x * (int)div_up(h, rows_per_strip)};
+    FusedArgs a{f0, f1, u, v, du, dv, out_du, out_dv, (int)w, (int)h, (int)(pitch_bytes / 4), plan.rows_interior,
+                plan.rows_edge, plan.strips_interior, plan.blocks_x,
                 zero_increment ? 1 : 0, start_du, start_dv, (start_du && start_dv) ? 1 : 0, hx, hy, alpha, e_smooth,
-                e_data, static_cast<unsigned long long>(ctx->batch_stride_floats), nullptr};
+                e_data,
+                2.f * hx, 2.f * hy, 4.f * hx, 4.f * hy, 1.f / (2.f * hx), 1.f / (2.f * hy), 1.f / (4.f * hx), 1.f / (4.f * hy),
+                static_cast<float>(1.0 / (2.0 * hx)), static_cast<float>(1.0 / (2.0 * hy)), alpha / (hx * hx), alpha / (hy * hy),
+                static_cast<unsigned long long>(ctx->batch_stride_floats), ctx->fused_fallbacks};
     const int valid = 64 - 2 * ((int)inner + 1);
     const unsigned strips_x = div_up(w, valid);
-    const dim3 grid(div_up(strips_x, 4), div_up(h, rows_per_strip), ctx->batch_count);
+    const dim3 grid(plan.blocks, 1, ctx->batch_count);
     const bool pow2 = is_power_of_two(hx) && is_power_of_two(hy);
-    if (g_stamps_enabled) {
-        const size_t need = static_cast<size_t>(grid.x) * grid.y * 4 * 4 * sizeof(unsigned long long);
-        if (need > g_stamps_bytes) {
-            if (g_stamps) (void)hipFree(g_stamps);
-            FLOW2D_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&g_stamps), need));
-            g_stamps_bytes = need;
-        }
-        FLOW2D_HIP_TRY(hipMemsetAsync(g_stamps, 0, need, ctx->stream));
-        a.stamps = g_stamps;
-        g_stamps_waves = static_cast<size_t>(grid.x) * grid.y * 4;
-    }
     int rc;
     if (constancy == FLOW2D_CONSTANCY_GRADIENT)
         rc = pow2 ? launch_for_inner<1, true>((int)inner, grid, ctx->stream, a)
@@ -616,15 +772,3 @@ int launch_fused_outer(flow2d_context* ctx, int constancy, const float* f0, cons
 
 }  // namespace flow2d
 
-// developer diagnostics, not part of the C-ABI header: copies the stamps of the most recent fused launch
-// (4 x u64 per wave: start, end [100 MHz ticks], HW_ID, XCC_ID; all zero for waves that left at once)
-extern "C" __attribute__((visibility("default"))) int flow2d_debug_fused_stamps(unsigned long long* host, size_t capacity_waves,
-                                                                                size_t* waves)
-{
-    if (!g_stamps || !host || !waves) return FLOW2D_ERR_INVALID_ARGUMENT;
-    *waves = g_stamps_waves;
-    const size_t n = g_stamps_waves < capacity_waves ? g_stamps_waves : capacity_waves;
-    FLOW2D_HIP_TRY(hipDeviceSynchronize());
-    FLOW2D_HIP_TRY(hipMemcpy(host, g_stamps, n * 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
-    return FLOW2D_OK;
-}

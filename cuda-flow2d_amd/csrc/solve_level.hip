@@ -29,7 +29,7 @@ int launch_tiled_outer(flow2d_context* ctx, int constancy, const float* f0, cons
                        const float* v, const float* du, const float* dv, size_t w, size_t h, size_t pitch_bytes, float hx,
                        float hy, float alpha, float e_smooth, float e_data, size_t inner, float* out_du, float* out_dv,
                        bool zero_increment);
-int fused_rows_per_strip(const flow2d_context* ctx, size_t w, size_t h, size_t inner);
+
 int launch_fused_outer(flow2d_context* ctx, int constancy, const float* f0, const float* f1, const float* u,
                        const float* v, const float* du, const float* dv, size_t w, size_t h, size_t pitch_bytes,
                        float hx, float hy, float alpha, float e_smooth, float e_data, size_t inner, float* out_du,
@@ -182,7 +182,7 @@ int flow2d_solve_level(flow2d_context* ctx, const float* frame_0, const float* f
             const size_t sweeps = inner / chunks + (c < inner % chunks ? 1 : 0);
             int out = 0;
             while (out == source || out == in) ++out;
-            const int rows = rows_env > 0 ? rows_env : flow2d::fused_rows_per_strip(ctx, p->width, p->height, sweeps);
+            const int rows = rows_env > 0 ? rows_env : 0;  // 0: the launcher plans the strip heights (solve_fused.hip, FusedPlan)
             if (per_launch) FLOW2D_HIP_TRY(mark(ctx, slot));
             int st = flow2d::launch_fused_outer(ctx, p->data_constancy, frame_0, frame_1, flow_u, flow_v, pair_u[source],
                                                 pair_v[source], p->width, p->height, p->pitch_bytes, p->hx, p->hy,

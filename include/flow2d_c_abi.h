@@ -328,6 +328,14 @@ typedef struct flow2d_timing_record {
     double algorithmic_bytes_per_launch; /* W*H*40 per sweep launch, W*H*(32+40*inner)/ceil(inner/5) per fused launch */
 } flow2d_timing_record;
 
+/* Diagnostics of the fused kernel (FLOW2D_SOLVER_FUSED): its sweeps divide through a reciprocal prepared once per pixel
+ * and outer iteration (three instructions instead of the eleven of a correctly rounded division; bit-identical for all
+ * operands inside the normal range, proven by exhaustion over all significand pairs), and a wavefront that meets
+ * operands outside that range -- a denominator outside [2^-30, 2^40], a non-zero numerator below 2^-80, an infinite or
+ * NaN result -- repeats its strip with the plain division.  Number of such repeats on this context since it was
+ * created (synchronises the stream). */
+FLOW2D_API int flow2d_fused_fallbacks(flow2d_context* ctx, unsigned long long* waves);
+
 FLOW2D_API int flow2d_timing_enable(flow2d_context* ctx, int mode);
 /* mode 2 brackets individual launches only for levels of at least min_width x min_height pixels
  * (default 0 x 0 = every level); smaller levels still get their mode-1 record. */

@@ -29,8 +29,8 @@ def main():
                 ctx.record(e1)
                 ms = ctx.elapsed_ms(e0, e1)
             bytes_ = w * h * 10 * (32 + 40 * inner)
-            print("constancy %d algo %d: level solve %.3f ms -> %.1f Mpix-iters/s, %.2f TB/s algorithmic" %
-                  (constancy, algo, ms, w * h * 10 * inner / ms / 1e3, bytes_ / ms / 1e9))
+            print("constancy %d algo %d: level solve %.3f ms -> %.1f Mpix-iters/s, %.2f TB/s algorithmic (fallback waves so far %d)" %
+                  (constancy, algo, ms, w * h * 10 * inner / ms / 1e3, bytes_ / ms / 1e9, ctx.fused_fallbacks()))
     ctx.close()
 
 
