@@ -348,10 +348,18 @@ class Job:
         self.single = cfg["pairs_per_rank"] == 1
         self.grouped = not self.single and args.batch_mode == "groups"
         self.group = cfg["pairs_per_rank"] if self.grouped else 1
+        # Mid-size single-pair workloads (config 2): consecutive STEPS are handed to the batch entry `step_group` at a time
+        # as independent pairs in planes of their own, and the C++ object forms a lock-step group of them itself
+        # (OpticalFlowBatch2D::ComputeFlowBatchDeviceGrouped: gather, one launch per kernel for the group, hand back).
+        # A step is still one pair's whole pyramid; K steps are K pairs.
+        self.step_group = 1
+        if self.single:
+            self.step_group = args.step_group if args.step_group > 0 else (4 if w * h <= 2048 * 2048 else 1)
+        self.pending = []
         self.rotate = self.single or self.grouped  # a step is one entry; steps rotate over the lanes
         self.n_lanes = max(1, min(args.max_lanes, args.pipeline if self.rotate else cfg["pairs_per_rank"] * args.pipeline))
         self.runner = flow2d.OpticalFlowBatch(w, h, cfg["constancy"], lanes=self.n_lanes, device=local_rank,
-                                              group_size=self.group)
+                                              group_size=self.group if self.step_group == 1 else self.step_group)
         self.ctx = flow2d.Context(local_rank)  # plane allocation, uploads, downloads (created after the lanes' streams)
         self.runner.use_graph(not args.no_graph)
         # rank 0's parameter block on every rank (RCCL broadcast), then the same solve everywhere
@@ -366,7 +374,12 @@ class Job:
         c, G = self.ctx, self.group
         # entries: (frame 0, frame 1, u, v, [global pair indices]); planes are G containers tall
         self.sets = []
-        if self.rotate:
+        if self.step_group > 1:  # per lane: step_group output pairs; the input pair is shared (read only)
+            f0, f1 = c.plane(w, h, frames[0][0]), c.plane(w, h, frames[0][1])
+            for lane in range(self.n_lanes):
+                for _ in range(self.step_group):
+                    self.sets.append((f0, f1, c.plane(w, h), c.plane(w, h), list(self.owned)))
+        elif self.rotate:
             stacked = (np.vstack([f[0] for f in frames]), np.vstack([f[1] for f in frames]))
             for lane in range(self.n_lanes):
                 if out_tensor is not None and lane == 0:  # lane 0 writes straight into the gather buffer [2, G, h, pitch]
@@ -395,9 +408,23 @@ class Job:
         cols = [[q[i].ptr for q in sets] for i in range(4)]
         self.runner.compute_flow_batch_device(*cols, self.params, first_lane=first_lane)
 
+    def flush(self):
+        """Hands the collected steps of a step group to the batch entry (a partial group at the end of a region)."""
+        if not self.pending:
+            return
+        n, lane = len(self.pending), (self.pending[0] // self.step_group) % self.n_lanes
+        sets = self.sets[lane * self.step_group:lane * self.step_group + n]
+        cols = [[q[i].ptr for q in sets] for i in range(4)]
+        self.runner.compute_flow_batch_device_grouped(*cols, self.params, first_lane=lane)
+        self.pending = []
+
     def step(self, index):
         """One pass over this rank's pairs: ONE call into the C++ batch entry (replayed HIP graphs unless --no-graph)."""
-        if self.rotate:
+        if self.step_group > 1:
+            self.pending.append(index)
+            if len(self.pending) == self.step_group:
+                self.flush()
+        elif self.rotate:
             lane = index % self.n_lanes
             self._queue([self.sets[lane]], lane)
         else:
@@ -406,7 +433,12 @@ class Job:
     def eager_pass(self):
         """Every plane set once, launched eagerly (no graph): the recomputation the output check compares with."""
         self.runner.use_graph(False)
-        self._queue(self.sets, 0)
+        if self.step_group > 1:
+            for k in range(self.n_lanes * self.step_group):
+                self.step(k)
+            self.flush()
+        else:
+            self._queue(self.sets, 0)
         self.sync()
         self.runner.use_graph(not self.args.no_graph)
 
@@ -442,12 +474,14 @@ def timed_region(job, batch, torch, steps, warmup):
         job.sync()
         torch.cuda.synchronize()
 
-    for k in range(max(warmup, 1) * (job.n_lanes if job.rotate else 1)):
+    for k in range(max(warmup, 1) * (job.n_lanes if job.rotate else 1) * job.step_group):
         job.step(k)  # also records the graphs of every lane
+    job.flush()
     barrier()
     t0 = time.perf_counter()
     for k in range(steps):
         job.step(k)
+    job.flush()
     barrier()
     return batch.max_over_ranks(time.perf_counter() - t0)
 
@@ -484,7 +518,9 @@ def host_entry_leg(job, batch, torch, steps):
     frames = [synthetic_pair(w, h, *pair_shift(job.workload, cfg, gk)) for gk in job.owned]
     f0s = [flow2d.HostImage(w, h, True, f[0]) for f in frames]
     f1s = [flow2d.HostImage(w, h, True, f[1]) for f in frames]
-    n_sets = 2 * job.n_lanes
+    N = job.step_group  # steps handed over together (config 2: the batch object forms a lock-step group of them)
+    n_sets = 2 * job.n_lanes * N
+    steps = max(N, steps // N * N)
     outs = [([flow2d.HostImage(w, h, True) for _ in range(G)], [flow2d.HostImage(w, h, True) for _ in range(G)])
             for _ in range(n_sets)]
     images = f0s + f1s + [q for us, vs in outs for q in us + vs]
@@ -492,12 +528,12 @@ def host_entry_leg(job, batch, torch, steps):
     runner = job.runner
     runner.use_graph(not job.args.no_graph)
 
-    def step(k):
-        us, vs = outs[k % n_sets]
-        if job.rotate:  # one entry (a pair, or one lock-step group of the rank's pairs) per step, steps rotate over the lanes
-            runner.compute_flow_batch(f0s, f1s, us, vs, job.params, first_lane=k % job.n_lanes)
-        else:
-            runner.compute_flow_batch(f0s, f1s, us, vs, job.params, first_lane=0)
+    def call(c):
+        """steps c*N .. c*N + N-1 in one call of the batch entry"""
+        us = [q for j in range(N) for q in outs[(c * N + j) % n_sets][0]]
+        vs = [q for j in range(N) for q in outs[(c * N + j) % n_sets][1]]
+        # one entry (a pair, or a lock-step group) per call, calls rotate over the lanes; lanes mode: the pairs spread from lane 0
+        runner.compute_flow_batch(f0s * N, f1s * N, us, vs, job.params, first_lane=(c % job.n_lanes) if job.rotate else 0)
 
     def barrier():
         batch.barrier()
@@ -505,12 +541,12 @@ def host_entry_leg(job, batch, torch, steps):
         torch.cuda.synchronize()
 
     try:
-        for k in range(n_sets):  # warm-up: allocates the staging planes, records the graphs of both slots of every lane
-            step(k)
+        for c in range(n_sets // N):  # warm-up: allocates the staging planes, records the graphs of both slots of every lane
+            call(c)
         barrier()
         t0 = time.perf_counter()
-        for k in range(steps):
-            step(k)
+        for c in range(steps // N):
+            call(c)
         barrier()
         elapsed = batch.max_over_ranks(time.perf_counter() - t0)
         # every delivered flow image against the device-resident result of the same pair (sha of the timed region's fields)
@@ -690,6 +726,9 @@ def main():
                     help="independent pairs in flight per GPU when a step holds a single pair: consecutive steps go to "
                          "alternating streams so one pair's launch-bound coarse levels overlap the next pair's fine levels")
     ap.add_argument("--max-lanes", type=int, default=4, help="upper bound on the lanes (streams) per GPU")
+    ap.add_argument("--step-group", type=int, default=0,
+                    help="single-pair workloads: consecutive steps handed to the batch entry this many at a time, which "
+                         "forms a lock-step group of them (0 = automatic: 4 up to 2048^2, else 1)")
     ap.add_argument("--batch-mode", choices=["groups", "lanes"], default="groups",
                     help="batched workloads: all pairs of a step as one lock-step group (every kernel launched once for "
                          "the group) or spread one by one over the lanes")
@@ -743,7 +782,7 @@ def main():
     finest, pair_latency_ms = roofline_sample(job)
     copy_gbs = measured_copy_peak(flow2d, local_rank) if rank == 0 else None
     first_pair = job.first_pair
-    n_lanes = job.n_lanes
+    n_lanes, step_group = job.n_lanes, job.step_group
     levels_run = int(min(cfg["levels"], flow2d.host_lib().flow2d_host_max_warp_level_static(w, h, cfg["scale"])))
     job.close()
 
@@ -837,6 +876,7 @@ def main():
                 "parallelism": "independent pairs, one process per GPU, no data-path collective",
                 "host_path": "OpticalFlowBatch2D::ComputeFlowBatchDevice (C++): one call per step",
                 "streams_per_gpu": n_lanes, "hip_graph_replay": not args.no_graph,
+                "steps_per_lock_step_group": step_group,
                 "batch_mode": ("lock-step group" if args.batch_mode == "groups" else "lanes") if cfg["pairs_per_rank"] > 1 else None,
                 "timed_region": "graph-replayed steps only; output check, roofline sample, batch leg and baselines follow it",
             },

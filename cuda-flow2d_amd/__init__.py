@@ -95,6 +95,7 @@ def hip_lib():
         L.flow2d_copy_h2d_2d.argtypes = [vp, vp, sz, vp, sz, sz, sz]
         L.flow2d_copy_d2h_2d.argtypes = [vp, vp, sz, vp, sz, sz, sz]
         L.flow2d_copy_d2d.argtypes = [vp, vp, vp, sz]
+        L.flow2d_copy_planes.argtypes = [vp, sz, C.POINTER(vp), C.POINTER(vp), sz, sz, sz]
         L.flow2d_event_create.argtypes = [vp, C.POINTER(vp)]
         L.flow2d_event_record.argtypes = [vp, vp]
         L.flow2d_event_synchronize.argtypes = [vp, vp]
@@ -214,6 +215,12 @@ class Context:
             p.fill_bytes(0)
             p.upload(data)
         return p
+
+    def copy_planes(self, srcs, dsts, width, height):
+        """flow2d_copy_planes: the planes srcs[i] -> dsts[i] (same pitch) with one launch."""
+        n = len(srcs)
+        a, b = (C.c_void_p * n)(*[p.ptr for p in srcs]), (C.c_void_p * n)(*[p.ptr for p in dsts])
+        _check(hip_lib().flow2d_copy_planes(self.handle, n, a, b, srcs[0].pitch, width, height), "flow2d_copy_planes")
 
     def synchronize(self):
         _check(hip_lib().flow2d_synchronize(self.handle), "flow2d_synchronize")
@@ -457,6 +464,8 @@ def host_lib():
         L.flow2d_host_batch_compute.argtypes = [vp, sz, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp),
                                                 C.POINTER(HostParams), sz]
         L.flow2d_host_batch_synchronize.argtypes = [vp]
+        L.flow2d_host_batch_compute_grouped.argtypes = [vp, sz, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp),
+                                                        C.POINTER(HostParams), sz]
         L.flow2d_host_data2d_create.restype = vp
         L.flow2d_host_data2d_create.argtypes = [sz, sz, i]
         L.flow2d_host_data2d_destroy.argtypes = [vp]
@@ -594,6 +603,16 @@ class OpticalFlowBatch:
         rc = host_lib().flow2d_host_batch_compute(self.handle, n, *arrays, C.byref(params), first_lane)
         if rc:
             raise Flow2DError(rc, "OpticalFlowBatch2D::ComputeFlowBatchDevice")
+
+    def compute_flow_batch_device_grouped(self, dev_f0s, dev_f1s, dev_us, dev_vs, params, first_lane=0):
+        """Independent pairs (one container per plane); the object forms the lock-step groups (gather, group, hand back)."""
+        n = len(dev_f0s)
+        if not (len(dev_f1s) == len(dev_us) == len(dev_vs) == n):
+            raise ValueError("one frame 0, frame 1, u and v plane per pair")
+        arrays = [(C.c_void_p * n)(*a) for a in (dev_f0s, dev_f1s, dev_us, dev_vs)]
+        rc = host_lib().flow2d_host_batch_compute_grouped(self.handle, n, *arrays, C.byref(params), first_lane)
+        if rc:
+            raise Flow2DError(rc, "OpticalFlowBatch2D::ComputeFlowBatchDeviceGrouped")
 
     def compute_flow_batch(self, frames_0, frames_1, flows_u, flows_v, params, first_lane=0):
         """OpticalFlowBatch2D::ComputeFlowBatch: HostImage objects in and out, uploads / downloads pipelined against the

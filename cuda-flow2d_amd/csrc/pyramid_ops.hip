@@ -5,6 +5,7 @@
 // (< 3 % of a level's bytes).  Layout: one wave = 64 consecutive pixels of one row so
 // every global access of a wave is one contiguous 256-byte row segment; blocks are 64x4.
 // All arithmetic follows the reference's operation order (no FMA contraction) -- see each kernel.
+#include <algorithm>
 #include <cmath>
 #include <utility>
 
@@ -497,6 +498,51 @@ int flow2d_add_2d_pair(flow2d_context* ctx, float* operand_0_a, const float* ope
 {
     if (!operand_0_b || !operand_1_b) return FLOW2D_ERR_INVALID_ARGUMENT;
     return launch_add(ctx, operand_0_a, operand_1_a, operand_0_b, operand_1_b, width, height, pitch_bytes);
+}
+
+// ---- flow2d_copy_planes: up to 64 independent planes copied by ONE launch (pointer tables in the kernel arguments) ----
+namespace {
+struct PlaneTable {
+    const float* src[FLOW2D_COPY_PLANES_MAX];
+    float* dst[FLOW2D_COPY_PLANES_MAX];
+};
+// one float4 per lane, rows of a plane in blockIdx.y, the plane in blockIdx.z; the row tail that is no whole float4
+// goes float by float
+__global__ __launch_bounds__(256) void copy_planes_kernel(PlaneTable t, int width, int height, int pitch_floats)
+{
+    const float* src = t.src[blockIdx.z];
+    float* dst = t.dst[blockIdx.z];
+    const int quads = width >> 2;
+    for (int y = blockIdx.y; y < height; y += gridDim.y) {
+        const size_t row = static_cast<size_t>(y) * pitch_floats;
+        for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < quads; q += gridDim.x * blockDim.x)
+            reinterpret_cast<float4*>(dst + row)[q] = reinterpret_cast<const float4*>(src + row)[q];
+        const int x = (quads << 2) + blockIdx.x * blockDim.x + threadIdx.x;
+        if (x < width) dst[row + x] = src[row + x];
+    }
+}
+}  // namespace
+
+int flow2d_copy_planes(flow2d_context* ctx, size_t count, const void* const* src_planes, void* const* dst_planes,
+                       size_t pitch_bytes, size_t width, size_t height)
+{
+    FLOW2D_ENTER(ctx);
+    if (count == 0) return FLOW2D_OK;
+    if (!src_planes || !dst_planes || count > FLOW2D_COPY_PLANES_MAX) return FLOW2D_ERR_INVALID_ARGUMENT;
+    PlaneTable t{};
+    for (size_t i = 0; i < count; ++i) {
+        if (!flow2d::plane_args_ok(src_planes[i], width, height, pitch_bytes) ||
+            !flow2d::plane_args_ok(dst_planes[i], width, height, pitch_bytes) || src_planes[i] == dst_planes[i])
+            return FLOW2D_ERR_INVALID_ARGUMENT;
+        t.src[i] = static_cast<const float*>(src_planes[i]);
+        t.dst[i] = static_cast<float*>(dst_planes[i]);
+    }
+    const unsigned bx = std::max(1u, std::min(8u, flow2d::div_up(width / 4 + 1, 256)));
+    const unsigned by = static_cast<unsigned>(std::min<size_t>(height, 1024));
+    copy_planes_kernel<<<dim3(bx, by, static_cast<unsigned>(count)), 256, 0, ctx->stream>>>(t, static_cast<int>(width), static_cast<int>(height),
+                                                                                   static_cast<int>(pitch_bytes / 4));
+    FLOW2D_CHECK_LAUNCH();
+    return FLOW2D_OK;
 }
 
 int flow2d_gaussian_kernel(float sigma, float* taps, int* out_radius)

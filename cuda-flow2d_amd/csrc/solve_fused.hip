@@ -132,7 +132,10 @@ __device__ __forceinline__ float div3(float n, float d, float y)
 // bit patterns, vector ALU only (a comparison per division would go through the scalar unit: measured, it costs more than
 // the divisions it guards) -- and judged once, after the strip:
 //   tiny: min of (bits(n) << 1) - 1 over the numerators: the shift drops the sign, the decrement sends a zero (harmless:
-//         q0 = r = q = 0) to the top; a non-zero numerator below 2^-80 lands below kTinyLimit
+//         q0 = r = q = 0) to the top; a non-zero numerator below 2^-80 lands below kTinyLimit.  The one zero that is not
+//         harmless is a numerator of exactly -0, whose quotient is -0 while the three steps give +0; it takes a -0 in the
+//         flow planes to produce one (the sum of the four face terms is -0 only if all four are), so the same
+//         accumulator takes bits(x) ^ 0x80000000 of every flow value read: 0 for a -0
 //   den : max of bits(den) - bits(2^-30): above kDenSpan for a denominator outside [2^-30, 2^40], negative or NaN
 //   out : max of bits(du, dv) << 1 over the stored results: above kOutLimit for an infinity or a NaN
 struct DivGuard {
@@ -146,6 +149,12 @@ constexpr unsigned kOutLimit = 0xfefffffeu;                    // FLT_MAX << 1
 __device__ __forceinline__ void guard_numerators(DivGuard& g, float nu, float nv)
 {
     g.tiny = min(g.tiny, min((__float_as_uint(nu) << 1) - 1u, (__float_as_uint(nv) << 1) - 1u));
+    asm volatile("" : "+v"(g.tiny));
+}
+__device__ __forceinline__ void guard_flow_row(DivGuard& g, v2f uv, v2f duv)
+{
+    g.tiny = min(min(g.tiny, min(__float_as_uint(uv.x) ^ 0x80000000u, __float_as_uint(uv.y) ^ 0x80000000u)),
+                 min(__float_as_uint(duv.x) ^ 0x80000000u, __float_as_uint(duv.y) ^ 0x80000000u));
     asm volatile("" : "+v"(g.tiny));
 }
 __device__ __forceinline__ void guard_denominators(DivGuard& g, float du, float dv)
@@ -226,6 +235,7 @@ __device__ __forceinline__ void strip_step(Strip<INNER, GRAD>& s, const FusedArg
     constexpr bool cont = CONT;
     const float dv_row3 = cont ? s.start_cur.y : s.duvw[s0].y;  // start_cur still is row r-3 here
     if (cont) {
+        if (FAST) guard_flow_row(s.guard, s.n_start, s.n_start);
         s.start_cur = s.n_start;  // row r-2
         const int rs = min(max(r - 1, 0), h - 1);
         const unsigned off = (static_cast<unsigned>(rs) * static_cast<unsigned>(a.pitch) + static_cast<unsigned>(xc)) * 4u;
@@ -235,6 +245,7 @@ __device__ __forceinline__ void strip_step(Strip<INNER, GRAD>& s, const FusedArg
     s.f1w[s0] = s.n_f1;
     s.uvw[s0] = s.n_uv;
     s.duvw[s0] = s.n_duv;
+    if (FAST) guard_flow_row(s.guard, s.n_uv, s.n_duv);
     if (GRAD == 3) {
         s.lf0w[s0] = log1p_frame(s.n_f0);
         s.lf1w[s0] = log1p_frame(s.n_f1);

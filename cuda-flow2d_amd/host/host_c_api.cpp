@@ -206,6 +206,27 @@ HOST_API int flow2d_host_batch_compute(flow2d_host_batch* h, size_t count, void*
     return h->batch.ComputeFlowBatchDevice(count, f0.data(), f1.data(), u.data(), v.data(), bag, first_lane) ? 0 : 2;
 }
 
+// OpticalFlowBatch2D::ComputeFlowBatchDeviceGrouped: `count` independent pairs, grouped by the object.  0 on success.
+HOST_API int flow2d_host_batch_compute_grouped(flow2d_host_batch* h, size_t count, void* const* dev_frames_0,
+                                               void* const* dev_frames_1, void* const* dev_flows_u,
+                                               void* const* dev_flows_v, const flow2d_host_params* params,
+                                               size_t first_lane)
+{
+    if (!h || !params || (count && (!dev_frames_0 || !dev_frames_1 || !dev_flows_u || !dev_flows_v))) return 1;
+    flow2d_host_params p = *params;
+    OperationParameters bag;
+    FillBag(bag, p);
+    auto dp = [](void* q) { return static_cast<DevicePtr>(reinterpret_cast<uintptr_t>(q)); };
+    std::vector<DevicePtr> f0(count), f1(count), u(count), v(count);
+    for (size_t k = 0; k < count; ++k) {
+        f0[k] = dp(dev_frames_0[k]);
+        f1[k] = dp(dev_frames_1[k]);
+        u[k] = dp(dev_flows_u[k]);
+        v[k] = dp(dev_flows_v[k]);
+    }
+    return h->batch.ComputeFlowBatchDeviceGrouped(count, f0.data(), f1.data(), u.data(), v.data(), bag, first_lane) ? 0 : 2;
+}
+
 // Host images for the H<->D-inclusive entry: Data2D objects in pageable or page-locked memory (HostMemory::Pinned, the
 // reference's ALLOCATE_PINNED_MEMORY option as a run-time choice).  The caller fills / reads them through the pointer.
 HOST_API Data2D* flow2d_host_data2d_create(size_t width, size_t height, int pinned)

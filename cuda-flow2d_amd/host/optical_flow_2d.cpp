@@ -144,6 +144,10 @@ void OpticalFlow2D::Destroy()
             if (p) flow2d_plane_free(context_, AsPlane(p));
             p = 0;
         }
+        for (DevicePtr& p : group_staging_) {
+            if (p) flow2d_plane_free(context_, AsPlane(p));
+            p = 0;
+        }
     }
     all_planes_.clear();
     free_planes_.clear();
@@ -319,15 +323,14 @@ void OpticalFlow2D::ComputeFlow(Data2D& frame_0, Data2D& frame_1, Data2D& flow_u
 
 namespace {
 // Everything a recorded pyramid depends on: the four caller buffers and the nine (+1) parameters.
-std::vector<unsigned char> GraphKey(DevicePtr a, DevicePtr b, DevicePtr c, DevicePtr d, OperationParameters& params)
+std::vector<unsigned char> GraphKey(const std::vector<DevicePtr>& planes, OperationParameters& params)
 {
     std::vector<unsigned char> key;
     auto put = [&key](const void* p, size_t n) {
         const unsigned char* q = static_cast<const unsigned char*>(p);
         key.insert(key.end(), q, q + n);
     };
-    const DevicePtr ptrs[4] = {a, b, c, d};
-    put(ptrs, sizeof(ptrs));
+    put(planes.data(), planes.size() * sizeof(DevicePtr));
     const char* size_keys[] = {"warp_levels_count", "outer_iterations_count", "inner_iterations_count", "median_radius"};
     const char* float_keys[] = {"warp_scale_factor", "equation_alpha", "equation_smoothness", "equation_data",
                                 "gaussian_sigma"};
@@ -358,13 +361,10 @@ void OpticalFlow2D::DropGraphs()
     graphs_.clear();
 }
 
-bool OpticalFlow2D::ComputeFlowDevice(DevicePtr dev_frame_0, DevicePtr dev_frame_1, DevicePtr dev_flow_u,
-                                      DevicePtr dev_flow_v, OperationParameters& params)
+// Replays the graph recorded under `key`, recording it first (by running `queue` under stream capture) when the
+// combination is new.
+bool OpticalFlow2D::ReplayOrRecord(std::vector<unsigned char> key, const std::function<bool()>& queue)
 {
-    if (!IsInitialized() || !dev_frame_0 || !dev_frame_1 || !dev_flow_u || !dev_flow_v) return false;
-    if (!use_graph || timing_mode != 0) return QueuePair(dev_frame_0, dev_frame_1, dev_flow_u, dev_flow_v, params);
-
-    std::vector<unsigned char> key = GraphKey(dev_frame_0, dev_frame_1, dev_flow_u, dev_flow_v, params);
     auto it = graphs_.find(key);
     if (it == graphs_.end()) {
         if (graphs_.size() >= kMaxGraphs) {
@@ -378,7 +378,7 @@ bool OpticalFlow2D::ComputeFlowDevice(DevicePtr dev_frame_0, DevicePtr dev_frame
             graphs_.erase(oldest);
         }
         if (CheckFlow2DError(flow2d_capture_begin(context_), "flow2d_capture_begin")) return false;
-        const bool queued = QueuePair(dev_frame_0, dev_frame_1, dev_flow_u, dev_flow_v, params);
+        const bool queued = queue();
         void* exec = nullptr;
         const bool ended = !CheckFlow2DError(flow2d_capture_end(context_, &exec), "flow2d_capture_end");
         if (!queued || !ended) {
@@ -391,13 +391,87 @@ bool OpticalFlow2D::ComputeFlowDevice(DevicePtr dev_frame_0, DevicePtr dev_frame
     return !CheckFlow2DError(flow2d_graph_launch(context_, it->second.exec), "flow2d_graph_launch");
 }
 
+bool OpticalFlow2D::ComputeFlowDevice(DevicePtr dev_frame_0, DevicePtr dev_frame_1, DevicePtr dev_flow_u,
+                                      DevicePtr dev_flow_v, OperationParameters& params)
+{
+    if (!IsInitialized() || !dev_frame_0 || !dev_frame_1 || !dev_flow_u || !dev_flow_v) return false;
+    active_group_ = group_;
+    if (!use_graph || timing_mode != 0) return QueuePair(dev_frame_0, dev_frame_1, dev_flow_u, dev_flow_v, params);
+    return ReplayOrRecord(GraphKey({dev_frame_0, dev_frame_1, dev_flow_u, dev_flow_v}, params), [&] {
+        return QueuePair(dev_frame_0, dev_frame_1, dev_flow_u, dev_flow_v, params);
+    });
+}
+
+bool OpticalFlow2D::ComputeFlowGroupDevice(size_t count, const DevicePtr* dev_frames_0, const DevicePtr* dev_frames_1,
+                                           const DevicePtr* dev_flows_u, const DevicePtr* dev_flows_v,
+                                           OperationParameters& params)
+{
+    if (!IsInitialized() || !dev_frames_0 || !dev_frames_1 || !dev_flows_u || !dev_flows_v) return false;
+    if (count == 0 || count > group_ || 2 * count > FLOW2D_COPY_PLANES_MAX) {
+        std::printf("Error: '%s': a group of %zu pairs (1..%zu).\n", GetName(), count, group_);
+        return false;
+    }
+    std::vector<DevicePtr> planes;
+    for (size_t g = 0; g < count; ++g) {
+        if (!dev_frames_0[g] || !dev_frames_1[g] || !dev_flows_u[g] || !dev_flows_v[g]) return false;
+        planes.insert(planes.end(), {dev_frames_0[g], dev_frames_1[g], dev_flows_u[g], dev_flows_v[g]});
+    }
+    for (DevicePtr& p : group_staging_) {  // the tall staging containers, at the first scattered group
+        if (p) continue;
+        void* plane = nullptr;
+        size_t pitch = 0;
+        if (CheckFlow2DError(flow2d_plane_alloc(context_, dev_container_size_.width, dev_container_size_.height * group_,
+                                                &plane, &pitch),
+                             "flow2d_plane_alloc") ||
+            pitch != dev_container_size_.pitch)
+            return false;
+        p = static_cast<DevicePtr>(reinterpret_cast<uintptr_t>(plane));
+    }
+    if (!use_graph || timing_mode != 0)
+        return QueueScatteredGroup(count, dev_frames_0, dev_frames_1, dev_flows_u, dev_flows_v, params);
+    return ReplayOrRecord(GraphKey(planes, params), [&] {
+        return QueueScatteredGroup(count, dev_frames_0, dev_frames_1, dev_flows_u, dev_flows_v, params);
+    });
+}
+
+// gather the frames -> the group's pyramid on the staging containers -> hand the flows back
+bool OpticalFlow2D::QueueScatteredGroup(size_t count, const DevicePtr* dev_frames_0, const DevicePtr* dev_frames_1,
+                                        const DevicePtr* dev_flows_u, const DevicePtr* dev_flows_v,
+                                        OperationParameters& params)
+{
+    const size_t stride = GroupStrideBytes();
+    auto slot = [&](int which, size_t g) -> void* { return reinterpret_cast<char*>(AsPlane(group_staging_[which])) + g * stride; };
+    std::vector<const void*> src;
+    std::vector<void*> dst;
+    for (size_t g = 0; g < count; ++g) {
+        src.push_back(AsPlane(dev_frames_0[g])), dst.push_back(slot(0, g));
+        src.push_back(AsPlane(dev_frames_1[g])), dst.push_back(slot(1, g));
+    }
+    if (CheckFlow2DError(flow2d_copy_planes(context_, src.size(), src.data(), dst.data(), dev_container_size_.pitch,
+                                            dev_container_size_.width, dev_container_size_.height),
+                         "flow2d_copy_planes"))
+        return false;
+    active_group_ = count;
+    const bool ok = QueuePair(group_staging_[0], group_staging_[1], group_staging_[2], group_staging_[3], params);
+    active_group_ = group_;
+    if (!ok) return false;
+    src.clear(), dst.clear();
+    for (size_t g = 0; g < count; ++g) {
+        src.push_back(slot(2, g)), dst.push_back(AsPlane(dev_flows_u[g]));
+        src.push_back(slot(3, g)), dst.push_back(AsPlane(dev_flows_v[g]));
+    }
+    return !CheckFlow2DError(flow2d_copy_planes(context_, src.size(), src.data(), dst.data(), dev_container_size_.pitch,
+                                                dev_container_size_.width, dev_container_size_.height),
+                             "flow2d_copy_planes");
+}
+
 bool OpticalFlow2D::QueuePair(DevicePtr dev_frame_0, DevicePtr dev_frame_1, DevicePtr dev_flow_u,
                               DevicePtr dev_flow_v, OperationParameters& params)
 {
     const size_t bytes = dev_container_size_.pitch * dev_container_size_.height;
     // a lock-step group: from here to the end of the run every launch, memset and device copy of this context acts on
     // all group_ pairs (instance g of every plane, pool and caller alike, GroupStrideBytes() * g behind its pointer)
-    if (group_ > 1 && CheckFlow2DError(flow2d_context_set_batch(context_, group_, GroupStrideBytes()), "flow2d_context_set_batch"))
+    if (group_ > 1 && CheckFlow2DError(flow2d_context_set_batch(context_, active_group_, GroupStrideBytes()), "flow2d_context_set_batch"))
         return false;
     dev_frame_0_ = Acquire();
     dev_frame_1_ = Acquire();

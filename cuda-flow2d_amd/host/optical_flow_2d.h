@@ -16,6 +16,7 @@
 #pragma once
 
 #include <cstddef>
+#include <functional>
 #include <map>
 #include <vector>
 
@@ -95,6 +96,14 @@ public:
     size_t group_size = 1;
     size_t GroupStrideBytes() const { return dev_container_size_.pitch * dev_container_size_.height; }
 
+    // A lock-step group formed from `count` (1 .. group_size) independent pairs, every plane a container of its own
+    // anywhere on the device: the frames are gathered into the object's tall staging containers (one launch,
+    // flow2d_copy_planes), the group is computed like a tall-container group of `count` pairs, and the flows are handed
+    // back to the callers' planes (one launch).  Queued, not synchronised; with use_graph the whole sequence is recorded
+    // per (planes, parameters) combination and replayed.  Each pair's flow is bit-identical to its own ComputeFlowDevice.
+    bool ComputeFlowGroupDevice(size_t count, const DevicePtr* dev_frames_0, const DevicePtr* dev_frames_1,
+                                const DevicePtr* dev_flows_u, const DevicePtr* dev_flows_v, OperationParameters& params);
+
     const DataSize3& ContainerSize() const { return dev_container_size_; }
     // Device time of the last ComputeFlow (events around upload..download), milliseconds.
     float LastTotalMs() const { return last_total_ms_; }
@@ -115,6 +124,9 @@ private:
     bool RunPyramid(OperationParameters& params);
     bool QueuePair(DevicePtr dev_frame_0, DevicePtr dev_frame_1, DevicePtr dev_flow_u, DevicePtr dev_flow_v,
                    OperationParameters& params);
+    bool QueueScatteredGroup(size_t count, const DevicePtr* dev_frames_0, const DevicePtr* dev_frames_1,
+                             const DevicePtr* dev_flows_u, const DevicePtr* dev_flows_v, OperationParameters& params);
+    bool ReplayOrRecord(std::vector<unsigned char> key, const std::function<bool()>& queue);
     void DropGraphs();
     DevicePtr Acquire();
     void Release(DevicePtr p);
@@ -122,6 +134,8 @@ private:
     static constexpr size_t kContainersCount = 12;  // optical_flow_2d.h:45 of the reference
     DataSize3 dev_container_size_{0, 0, 0};
     size_t group_ = 1;  // group_size as it was at Initialize
+    size_t active_group_ = 1;  // pairs of the group being queued (a scattered group may be smaller than group_)
+    DevicePtr group_staging_[4] = {0, 0, 0, 0};  // ComputeFlowGroupDevice: tall frame 0, frame 1, flow u, flow v (first use)
     std::vector<DevicePtr> all_planes_;
     std::vector<DevicePtr> free_planes_;
     DevicePtr dev_frame_0_ = 0, dev_frame_1_ = 0, dev_flow_u_ = 0, dev_flow_v_ = 0;  // valid inside a run

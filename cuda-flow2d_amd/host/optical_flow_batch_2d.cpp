@@ -1,5 +1,6 @@
 #include "optical_flow_batch_2d.h"
 
+#include <algorithm>
 #include <cstdio>
 
 #include "device_utils.h"
@@ -55,6 +56,24 @@ bool OpticalFlowBatch2D::ComputeFlowBatchDevice(size_t count, const DevicePtr* d
         lane.flow.use_graph = use_graph;
         lane.flow.timing_mode = 0;
         ok &= lane.flow.ComputeFlowDevice(dev_frames_0[k], dev_frames_1[k], dev_flows_u[k], dev_flows_v[k], params);
+    }
+    return ok;
+}
+
+bool OpticalFlowBatch2D::ComputeFlowBatchDeviceGrouped(size_t count, const DevicePtr* dev_frames_0,
+                                                       const DevicePtr* dev_frames_1, const DevicePtr* dev_flows_u,
+                                                       const DevicePtr* dev_flows_v, OperationParameters& params,
+                                                       size_t first_lane)
+{
+    if (lanes_.empty() || (count != 0 && (!dev_frames_0 || !dev_frames_1 || !dev_flows_u || !dev_flows_v))) return false;
+    bool ok = true;
+    size_t group = 0;
+    for (size_t k = 0; k < count; k += group_size_, ++group) {
+        const size_t n = std::min(group_size_, count - k);
+        Lane& lane = *lanes_[(first_lane + group) % lanes_.size()];
+        lane.flow.use_graph = use_graph;
+        lane.flow.timing_mode = 0;
+        ok &= lane.flow.ComputeFlowGroupDevice(n, dev_frames_0 + k, dev_frames_1 + k, dev_flows_u + k, dev_flows_v + k, params);
     }
     return ok;
 }

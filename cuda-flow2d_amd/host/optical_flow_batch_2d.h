@@ -43,6 +43,15 @@ public:
                                 const DevicePtr* dev_flows_u, const DevicePtr* dev_flows_v, OperationParameters& params,
                                 size_t first_lane = 0);
 
+    // Lock-step groups formed by the object itself (group_size > 1): `count` INDEPENDENT pairs, every plane a container
+    // of its own (any allocation of this device, ContainerSize()); consecutive runs of up to GroupSize() pairs become
+    // one group each (OpticalFlow2D::ComputeFlowGroupDevice: gather, one launch per kernel for the group, hand back),
+    // group k on lane (first_lane + k) mod lanes.  The last group may be smaller.  Mid-size frames (1024^2, 1080p) gain
+    // a third in throughput over one pair per lane; each pair's flow is bit-identical to its own ComputeFlowDevice.
+    bool ComputeFlowBatchDeviceGrouped(size_t count, const DevicePtr* dev_frames_0, const DevicePtr* dev_frames_1,
+                                       const DevicePtr* dev_flows_u, const DevicePtr* dev_flows_v,
+                                       OperationParameters& params, size_t first_lane = 0);
+
     // The same for HOST images -- the bracket of the reference's own timer, uploads and downloads included
     // (optical_flow_2d.cpp:173-179,214-215,544-554) -- as a three-stage pipeline: an upload stream copies pair k + 1 into
     // a lane's staging planes while the lanes compute pair k (and the pairs before it) and a download stream copies

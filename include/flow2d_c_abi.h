@@ -109,6 +109,15 @@ FLOW2D_API int flow2d_copy_d2h_2d(flow2d_context* ctx, void* dst_host, size_t ds
                                   size_t src_pitch_bytes, size_t width_bytes, size_t height);
 FLOW2D_API int flow2d_copy_d2d(flow2d_context* ctx, void* dst_dev, const void* src_dev, size_t bytes);
 
+/* `count` (at most FLOW2D_COPY_PLANES_MAX) independent planes of one geometry copied by ONE launch on the context's stream:
+ * plane i from src_planes[i] to dst_planes[i] (width floats x height rows, both of pitch_bytes).  This is how a lock-step
+ * group gathers pairs that live in containers of their own into its tall staging containers and hands the flows back
+ * (OpticalFlow2D::ComputeFlowGroupDevice): two launches per group instead of 4 x count cuMemcpyDtoD calls.  Not subject
+ * to flow2d_context_set_batch (the tables name every plane). */
+#define FLOW2D_COPY_PLANES_MAX 64
+FLOW2D_API int flow2d_copy_planes(flow2d_context* ctx, size_t count, const void* const* src_planes,
+                                  void* const* dst_planes, size_t pitch_bytes, size_t width, size_t height);
+
 /* ---- page-locked host memory  (replaces cuMemAllocHost / cuMemFreeHost, the reference's ALLOCATE_PINNED_MEMORY
  *      option: src/data_types/data2d.cpp:34,60-61,80-82) --------------------------------------------------------
  * flow2d_copy_h2d_2d / flow2d_copy_d2h_2d are asynchronous on the context's stream; from and to pageable memory the

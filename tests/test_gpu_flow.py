@@ -605,3 +605,47 @@ def test_opt_in_sor_pyramid(flow2d, oracle, make_flow, constancy):
     assert np.array_equal(u, ou) and np.array_equal(v, ov)
     ju, jv, _ = oracle.compute_flow(f0, f1, 4, 0.5, 3, 4, 35.0, 0.001, 0.001, 5, 1.5, constancy)
     assert not np.array_equal(ou, ju)  # it really is a different relaxation
+
+
+@pytest.mark.parametrize("constancy,sigma", [(0, 1.5), (1, 1.5), (0, 0.0), (3, 1.5)])
+def test_groups_formed_from_scattered_planes(flow2d, oracle, constancy, sigma):
+    """OpticalFlowBatch2D::ComputeFlowBatchDeviceGrouped: eleven independent pairs, every plane an allocation of its own,
+    through two lanes in groups of four (4 + 4 + 3: the last group is smaller).  The object gathers the frames into its
+    tall staging containers, computes each group with one launch per kernel and hands the flows back; every pair equals
+    the oracle, eager and replayed from graphs, and the frames are left untouched."""
+    w, h, G, n = (208, 144, 4, 11) if constancy != 3 else (208, 144, 4, 5)
+    alpha = 35.0 if constancy != 3 else 0.0005
+    p = (3, 0.5, 2, 5, alpha, 0.001, 0.001, 5, sigma)
+    pairs = [oracle.synthetic_pair(w, h, 1.0 + 0.25 * k, -0.5 + 0.2 * k, seed=120 + k, noise=True) for k in range(n)]
+    c = flow2d.Context(0)
+    batch = flow2d.OpticalFlowBatch(w, h, constancy, lanes=2, group_size=G)
+    try:
+        f0s = [c.plane(w, h, q[0]) for q in pairs]
+        f1s = [c.plane(w, h, q[1]) for q in pairs]
+        us = [c.plane(w, h) for _ in pairs]
+        vs = [c.plane(w, h) for _ in pairs]
+        c.synchronize()
+        if constancy == 3:  # the CPU's logf differs from the device's in the last place: Log pairs against single-pair runs
+            single = flow2d.OpticalFlow(w, h, constancy, ctx=c)
+            want = []
+            for k in range(n):
+                single.compute_flow_device(f0s[k].ptr, f1s[k].ptr, us[k].ptr, vs[k].ptr, single.params(*p))
+                c.synchronize()
+                want.append((us[k].download(), vs[k].download()))
+            single.close()
+        else:
+            want = [oracle.compute_flow(f0, f1, *p, constancy)[:2] for f0, f1 in pairs]
+        for graph in (False, True, True):
+            batch.use_graph(graph)
+            for q in us + vs:
+                q.fill_bytes(0x7f)
+            c.synchronize()
+            batch.compute_flow_batch_device_grouped([q.ptr for q in f0s], [q.ptr for q in f1s], [q.ptr for q in us],
+                                                    [q.ptr for q in vs], batch.params(*p))
+            batch.synchronize()
+            for k in range(n):
+                assert np.array_equal(us[k].download(), want[k][0]) and np.array_equal(vs[k].download(), want[k][1]), (graph, k)
+                assert np.array_equal(f0s[k].download(), pairs[k][0]) and np.array_equal(f1s[k].download(), pairs[k][1])
+    finally:
+        batch.close()
+        c.close()

@@ -126,3 +126,19 @@ def test_border_aware_strip_plan_covers_every_pixel(ctx, oracle, w, h, cw, ch, c
     hx, hy = np.float32(cw / w), np.float32(ch / h)
     a, b, odu, odv = fused_vs_oracle(ctx, oracle, f0, f1, u, v, w, h, cw, ch, hx, hy, 3.5, 2, 5, constancy)
     assert np.array_equal(a, odu) and np.array_equal(b, odv)
+
+
+def test_negative_zero_in_the_flow_falls_back(ctx, oracle):
+    """A numerator of exactly -0 is the one zero the three-step division gets wrong (+0 where the quotient is -0).  It
+    takes a -0 in the flow planes to make one: flat frames and a flow plane of -0 do (every face term is -0, the data
+    term too).  The guard sees the -0 entries as they are read and sends the waves to the plain division: same bits as
+    the oracle, signs of zeros included."""
+    w, h = 640, 200
+    f0 = np.full((h, w), 80.0, np.float32)
+    f1 = f0.copy()
+    u = np.full((h, w), -0.0, np.float32)
+    v = np.zeros((h, w), np.float32)
+    before = ctx.fused_fallbacks()
+    a, b, odu, odv = fused_vs_oracle(ctx, oracle, f0, f1, u, v, w, h, w, h, np.float32(1.0), np.float32(1.0), 35.0, 2, 5, 0)
+    assert np.array_equal(bits(a), bits(odu)) and np.array_equal(bits(b), bits(odv))
+    assert ctx.fused_fallbacks() > before

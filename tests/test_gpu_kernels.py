@@ -351,3 +351,21 @@ def test_sor_rejects_bad_omega_and_fused(ctx, flow2d):
     with pytest.raises(flow2d.Flow2DError) as e:  # the fused kernels are Jacobi only
         ctx.solve_level(*planes, w, h, 1.0, 1.0, 3.5, 0.001, 0.001, 1, 1, 0, 2, sor_omega=1.2)
     assert e.value.status == 5
+
+
+@pytest.mark.parametrize("w,h,cw,ch", [(100, 70, 128, 80), (257, 33, 300, 40), (7, 5, 8, 8), (1024, 300, 1024, 300)])
+def test_copy_planes(ctx, flow2d, w, h, cw, ch):
+    """flow2d_copy_planes: several independent planes by one launch, only the w x h corner of each container."""
+    rng = np.random.default_rng(3)
+    n = 5
+    data = [rng.normal(0, 1, (ch, cw)).astype(np.float32) for _ in range(n)]
+    srcs = [ctx.plane(cw, ch, a) for a in data]
+    dsts = [ctx.plane(cw, ch).fill_bytes(0x7f) for _ in range(n)]
+    ctx.copy_planes(srcs, dsts, w, h)
+    poison = np.frombuffer(b"\x7f\x7f\x7f\x7f", np.float32)[0]
+    for a, d in zip(data, dsts):
+        got = d.download()
+        assert np.array_equal(got[:h, :w], a[:h, :w])
+        assert (got[h:, :] == poison).all() and (got[:, w:] == poison).all()  # nothing outside the corner is touched
+    with pytest.raises(flow2d.Flow2DError):
+        ctx.copy_planes([srcs[0]], [srcs[0]], w, h)  # in == out

@@ -8,8 +8,13 @@
 // Claim checked here: q == RN(n / d), bit for bit, for EVERY pair of fp32 significands (2^23 x 2^23 pairs, n and d in
 // [1, 2)).  All four steps commute exactly with scaling n or d by a power of two as long as nothing leaves the normal
 // range, so the significand check covers every normal (n, d) whose q0, r and q stay normal or are exactly zero -- which
-// is what the kernel's guard establishes at run time (r neither denormal nor infinite nor NaN, d within [2^-30, 2^40]).
-// The second kernel checks that guard on random operands of every magnitude, tiny and huge ones included.
+// is what the kernel's guard establishes at run time: d within [2^-30, 2^40], n zero or at least 2^-80 in magnitude
+// (then q0 >= 2^-121 is normal and r, a multiple of 2^-128 at least, is exact), the result finite.  The second kernel
+// applies that very guard (the kernel's own integer test on the bit patterns) to random operands of every magnitude,
+// tiny, denormal and huge numerators included: whatever passes the guard must equal n / d.
+// Two cheaper guards were tried and are NOT sufficient: the class of r alone (r == 0 is ambiguous: a true zero, or a
+// residual below the denormal grid rounded away -- 8.3e6 wrong quotients of 1.7e10 passed) and the wave's sticky IEEE
+// exception flags (TRAPSTS.EXCP stays 0 on gfx950 unless traps are enabled).
 //
 // (Markstein's theorem gives q == RN(n / d) when q0 is a faithful rounding of n / d; RN(n * RN(1 / d)) can be 1.5 ulp
 // off when n < d, so the theorem alone does not cover this sequence.)
@@ -71,8 +76,14 @@ __device__ __forceinline__ unsigned long long lcg(unsigned long long& s)
     return s;
 }
 
-// the run-time guard of the kernel: r must be a normal number or zero (v_cmp_class_f32), d within [2^-30, 2^40]
-__device__ __forceinline__ bool guard_ok(float r) { return !__builtin_isinf(r) && !__builtin_isnan(r) && (r == 0.f || __builtin_fabsf(r) >= 1.17549435e-38f); }
+// the run-time guard of the kernel (solve_fused.hip, DivGuard): tiny numerators by an integer test on the bit pattern
+// -- the shift drops the sign, the decrement sends a zero to the top -- and non-finite results
+__device__ __forceinline__ bool guard_ok(float n, float q)
+{
+    const unsigned tiny = (__float_as_uint(n) << 1) - 1u;   // kTinyLimit = 2 * bits(2^-80) - 1
+    const unsigned out = __float_as_uint(q) << 1;           // kOutLimit  = bits(FLT_MAX) << 1
+    return !(tiny < 2u * 0x17800000u - 1u) && !(out > 0xfefffffeu);
+}
 
 __global__ __launch_bounds__(256) void random_magnitudes(unsigned long long seed, int per_thread, Report* rep)
 {
@@ -89,63 +100,17 @@ __global__ __launch_bounds__(256) void random_magnitudes(unsigned long long seed
         float r;
         const float got = three_step(n, d, y, &r);
         const float want = n / d;
-        if (!guard_ok(r)) {
+        // (a numerator of exactly -0 gives +0 where n / d gives -0: the kernel keeps -0 out of its numerators by sending
+        //  any flow plane that holds a -0 to the fallback, see guard_flow_row; it is excluded here)
+        if (!guard_ok(n, got) || __float_as_uint(n) == 0x80000000u) {
             ++trips;
-        } else if (__float_as_uint(got) != __float_as_uint(want) && !(got == 0.f && want == 0.f)) {
+        } else if (__float_as_uint(got) != __float_as_uint(want)) {  // bit for bit, the sign of a zero included
             ++misses;
             const unsigned slot = atomicAdd(&rep->listed, 1u);
             if (slot < 256) {
                 rep->list[slot][0] = __float_as_uint(n);
                 rep->list[slot][1] = __float_as_uint(d);
             }
-        }
-    }
-    if (trips) atomicAdd(&rep->guard_trips, trips);
-    if (misses) atomicAdd(&rep->guard_misses, misses);
-}
-
-// The guard the kernel uses: the wave's sticky IEEE exception flags (TRAPSTS.EXCP, accumulated by the hardware for
-// every VALU instruction whether or not traps are enabled).  Cleared before the three steps, read after them: any of
-// invalid / input-denormal / overflow / underflow set  =>  the wave falls back to true division.  Checked here wave
-// by wave on random operands: most lanes of a wave get ordinary magnitudes, a few get tiny or huge numerators.
-__global__ __launch_bounds__(256) void trapsts_guard(unsigned long long seed, int per_thread, Report* rep, unsigned* flag_histogram)
-{
-    unsigned long long s = seed + 0x9e3779b97f4a7c15ull * (blockIdx.x * blockDim.x + threadIdx.x + 1);
-    unsigned long long trips = 0, misses = 0;
-    for (int i = 0; i < per_thread; ++i) {
-        const unsigned long long a = lcg(s), b = lcg(s);
-        unsigned nbits = (unsigned)(a >> 32);
-        if ((a & 0xfff) != 0) {  // 4095 of 4096 lanes: exponent in [-60, 60]
-            const unsigned e = 127u - 60u + (unsigned)((a >> 12) % 121u);
-            nbits = (nbits & 0x807fffffu) | (e << 23);
-        }
-        const float n = __uint_as_float(nbits);
-        const unsigned dexp = 127u - 30u + (unsigned)((b >> 40) % 71u);
-        const float d = __uint_as_float((dexp << 23) | ((unsigned)(b >> 8) & 0x7fffffu));
-        const bool usable = !(__builtin_isnan(n) || __builtin_isinf(n));
-        const float y = 1.0f / d;
-        const float want = n / d;
-        float q0, r, got;
-        // clear the flags, run the three steps on (n, d, y), read the flags: all inside one asm so nothing else can slip in
-        unsigned flags;
-        asm volatile(
-            "s_nop 4\n\t"
-            "s_setreg_imm32_b32 hwreg(HW_REG_TRAPSTS, 0, 9), 0\n\t"
-            "s_nop 4\n\t"
-            "v_mul_f32 %1, %4, %6\n\t"
-            "v_fma_f32 %2, -%1, %5, %4\n\t"
-            "v_fma_f32 %3, %2, %6, %1\n\t"
-            "s_nop 7\n\t"
-            "s_getreg_b32 %0, hwreg(HW_REG_TRAPSTS, 0, 9)\n\t"
-            : "=s"(flags), "=&v"(q0), "=&v"(r), "=&v"(got)
-            : "v"(usable ? n : 1.0f), "v"(d), "v"(y));
-        const bool lane_wrong = usable && __float_as_uint(got) != __float_as_uint(want) && !(got == 0.f && want == 0.f);
-        const bool wave_wrong = __ballot(lane_wrong) != 0ull;
-        const bool tripped = (flags & 0x1bu) != 0;  // invalid | input denormal | overflow | underflow
-        if ((threadIdx.x & 63) == 0) {
-            trips += tripped;
-            misses += (wave_wrong && !tripped);
-            atomicAdd(&flag_histogram[flags & 0x3f], 1u);
         }
     }
     if (trips) atomicAdd(&rep->guard_trips, trips);
@@ -189,30 +154,10 @@ int main(int argc, char** argv)
     for (int pass = 0; pass < 4; ++pass) random_magnitudes<<<blocks, 256>>>(12345ull + pass, per_thread, dev);
     if (hipDeviceSynchronize() != hipSuccess) return 3;
     hipMemcpy(&host, dev, sizeof(host), hipMemcpyDeviceToHost);
-    std::printf("random magnitudes: %.4g pairs (n any finite float, d in [2^-30, 2^41)): guard trips %llu, wrong with the guard "
-                "passed %llu\n", 4.0 * blocks * 256 * per_thread, host.guard_trips, host.guard_misses);
+    std::printf("random magnitudes: %.4g pairs (n any finite float bit pattern, d in [2^-30, 2^41)): sent to the fallback by the "
+                "guard %llu, passed the guard and differ from n / d: %llu\n", 4.0 * blocks * 256 * per_thread, host.guard_trips,
+                host.guard_misses);
     for (unsigned i = 0; i < host.listed && i < 16; ++i)
         std::printf("  guard miss: n = %#010x  d = %#010x\n", host.list[i][0], host.list[i][1]);
-    // (r == 0 is ambiguous -- a true zero or a residual below the denormal grid rounded away -- so a class test of r
-    //  alone lets wrong quotients of tiny numerators through; the exception flags do not)
-    const unsigned long long class_guard_misses = host.guard_misses;
-
-    std::memset(&host, 0, sizeof(host));
-    hipMemcpy(dev, &host, sizeof(host), hipMemcpyHostToDevice);
-    unsigned* hist;
-    hipMalloc(&hist, 64 * sizeof(unsigned));
-    hipMemset(hist, 0, 64 * sizeof(unsigned));
-    for (int pass = 0; pass < 4; ++pass) trapsts_guard<<<blocks, 256>>>(777ull + pass, per_thread, dev, hist);
-    if (hipDeviceSynchronize() != hipSuccess) return 3;
-    hipMemcpy(&host, dev, sizeof(host), hipMemcpyDeviceToHost);
-    unsigned hh[64];
-    hipMemcpy(hh, hist, sizeof(hh), hipMemcpyDeviceToHost);
-    const double waves = 4.0 * blocks * 4 * per_thread;
-    std::printf("TRAPSTS guard: %.4g waves of 64 random pairs: tripped %llu (%.2f %%), a wrong lane in a wave that did not trip: %llu\n",
-                waves, host.guard_trips, 100.0 * host.guard_trips / waves, host.guard_misses);
-    std::printf("  flag patterns seen (bit0 invalid, 1 input denormal, 2 div0, 3 overflow, 4 underflow, 5 inexact):");
-    for (int i = 0; i < 64; ++i)
-        if (hh[i]) std::printf("  %#04x: %u", i, hh[i]);
-    std::printf("\n(class-of-r guard alone: %llu wrong quotients passed)\n", class_guard_misses);
     return (sig_mismatches || host.guard_misses) ? 1 : 0;
 }
