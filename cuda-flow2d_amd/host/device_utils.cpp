@@ -4,8 +4,11 @@
 #include <cstdio>
 
 namespace {
-flow2d_context* g_context = nullptr;
-bool g_owned = false;
+// per host thread: a process that drives several GPUs from one thread each (flow2d_batch --gpus N) gives every thread
+// its own current context, like the CUDA driver's per-thread current context the reference relies on (cuCtxCreate,
+// src/utils/cuda_utils.cpp:43)
+thread_local flow2d_context* g_context = nullptr;
+thread_local bool g_owned = false;
 }  // namespace
 
 bool CheckFlow2DError(int status, const char* where)
