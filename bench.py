@@ -13,7 +13,8 @@ Order of a run
   1. warm-up (records the HIP graphs), barrier
   2. TIMED REGION: exactly K steps, replayed from the recorded graphs, nothing else; barrier; max over ranks
   3. output check: the flow fields the timed steps left in HBM are hashed; an eager (un-graphed) recomputation
-     must give the same bits, and for single-pair workloads all streams must agree
+     must give the same bits, for single-pair workloads all streams must agree, and the first pair's flow must equal
+     the CPU oracle's in every pixel (output_check.oracle)
   4. host-entry leg: the same pairs from HOST images to HOST flows (uploads and downloads inside the bracket, pipelined
      against the pyramids by OpticalFlowBatch2D::ComputeFlowBatch): pairs_per_s_incl_h2d, SURVEY 8(d) metric 2 as defined
   5. roofline sample: eager passes with HIP events on the launch stream around every finest-level solver launch;
@@ -571,6 +572,25 @@ def host_entry_leg(job, batch, torch, steps):
             q.close()
 
 
+def oracle_check(job):
+    """The line's own parity bit: the first pair's flow as the timed region left it in HBM against the CPU oracle
+    (oracle/flow2d_oracle.c, the checker -- never the thing measured) on the same pair, every pixel, bit for bit.
+    Rank 0, after the timed region; a few seconds of OpenMP at 4096^2."""
+    from oracle import oracle as O
+
+    cfg = job.cfg
+    O.lib()
+    h = cfg["h"]
+    _, _, pu, pv, _ = job.sets[0]
+    u, v = pu.download()[:h], pv.download()[:h]
+    t0 = time.perf_counter()
+    ou, ov, _ = O.compute_flow(job.first_pair[0], job.first_pair[1], cfg["levels"], cfg["scale"], cfg["outer"], cfg["inner"],
+                               cfg["alpha"], 0.001, 0.001, cfg["median"], cfg["sigma"], cfg["constancy"])
+    return {"first_pair_equals_cpu_oracle": bool(np.array_equal(u, ou) and np.array_equal(v, ov)),
+            "pixels_compared": int(2 * u.size), "oracle_seconds": round(time.perf_counter() - t0, 2),
+            "max_abs_difference": float(max(np.abs(u - ou).max(), np.abs(v - ov).max()))}
+
+
 def roofline_sample(job, passes=3):
     """Eager passes of the first pair on a stream of its own, alone on the GPU, with HIP events on that stream around
     every level's solve and every finest-level solver launch (flow2d_timing_enable mode 2)."""
@@ -582,6 +602,11 @@ def roofline_sample(job, passes=3):
     try:
         f0, f1 = (c.plane(w, h, a) for a in job.first_pair)
         u, v = c.plane(w, h), c.plane(w, h)
+        # the CPU-side checks before this leg leave the GPU idle for seconds: a few untimed passes bring its clocks back
+        # up before the sampled ones
+        for _ in range(4):
+            flow.compute_flow_device(f0.ptr, f1.ptr, u.ptr, v.ptr, job.params, 0)
+        c.synchronize()
         flow.reset_timings()
         for _ in range(passes):
             flow.compute_flow_device(f0.ptr, f1.ptr, u.ptr, v.ptr, job.params, 2)
@@ -720,6 +745,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-reference-baseline", action="store_true")
     ap.add_argument("--no-batch-leg", action="store_true")
+    ap.add_argument("--no-oracle-check", action="store_true",
+                    help="skip comparing the first pair's flow with the CPU oracle (output_check.oracle)")
     ap.add_argument("--no-host-entry-leg", action="store_true", help="skip the H<->D-inclusive leg (pairs_per_s_incl_h2d)")
     ap.add_argument("--no-graph", action="store_true", help="launch every step eagerly instead of replaying HIP graphs")
     ap.add_argument("--pipeline", type=int, default=4,
@@ -776,6 +803,9 @@ def main():
     free_b, total_b = job.ctx.mem_info()
     elapsed = timed_region(job, batch, torch, args.steps, args.warmup)   # <- the number
     check = output_check(job)
+    if rank == 0 and not args.no_oracle_check:
+        check["oracle"] = oracle_check(job)
+        check["ok"] = check["ok"] and check["oracle"]["first_pair_equals_cpu_oracle"]
     host_entry = host_entry_leg(job, batch, torch, max(5, min(args.steps, 50))) if not args.no_host_entry_leg else None
     if host_entry is not None and not host_entry["flows_bit_identical_to_device_resident_run"]:
         check["ok"] = False
@@ -909,7 +939,7 @@ def main():
         print(json.dumps(out))
     batch.shutdown()
     if not ok:
-        sys.exit("bench.py: output check failed (graph replay and eager recomputation disagree)")
+        sys.exit("bench.py: output check failed (graph replay / eager recomputation / CPU oracle / host entry disagree)")
 
 
 if __name__ == "__main__":

@@ -301,7 +301,8 @@ int flow2d_host_free(flow2d_context* ctx, void* host_ptr)
 
 int flow2d_context_set_batch(flow2d_context* ctx, size_t count, size_t stride_bytes)
 {
-    if (!ctx || count == 0 || count > 65535 || (count > 1 && (stride_bytes == 0 || stride_bytes % 16 != 0)))
+    // (two-plane launches carry planes x count in grid.z, which ends at 65535)
+    if (!ctx || count == 0 || count > FLOW2D_BATCH_MAX || (count > 1 && (stride_bytes == 0 || stride_bytes % 16 != 0)))
         return FLOW2D_ERR_INVALID_ARGUMENT;
     ctx->batch_count = static_cast<unsigned>(count);
     ctx->batch_stride_floats = count > 1 ? stride_bytes / sizeof(float) : 0;

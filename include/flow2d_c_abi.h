@@ -87,7 +87,9 @@ FLOW2D_API int flow2d_synchronize(flow2d_context* ctx); /* cuStreamSynchronize(N
  * instance b at plane pointer + b * stride_bytes (pairs stored one below the other in tall containers; stride a
  * multiple of 16).  One launch then holds the work of all instances (grid.z), so a level of a mid-size frame fills the
  * chip and the launch-bound coarse levels cost one launch per batch instead of one per pair.  count = 1 switches it
- * off (the default).  Results per instance are those of the unbatched call. */
+ * off (the default).  Results per instance are those of the unbatched call.  At most FLOW2D_BATCH_MAX instances (the
+ * two-plane launches put 2 x count into grid.z). */
+#define FLOW2D_BATCH_MAX 32767
 FLOW2D_API int flow2d_context_set_batch(flow2d_context* ctx, size_t count, size_t stride_bytes);
 /* cuMemGetInfo, optical_flow_2d.cpp:91 */
 FLOW2D_API int flow2d_mem_info(flow2d_context* ctx, size_t* free_bytes, size_t* total_bytes);

@@ -649,3 +649,33 @@ def test_groups_formed_from_scattered_planes(flow2d, oracle, constancy, sigma):
     finally:
         batch.close()
         c.close()
+
+
+def test_cli_full_settings_xml_values(flow2d, tmp_path):
+    """The `flow2d` binary with the values of the reference's settings.xml untouched (20 levels at 0.9, 20 x 5 sweeps,
+    median 5, sigma 0.45, alpha 3.5) on rub1/rub2: the flow raws it writes hash to what the reference's own kernels
+    produced for this configuration on the MI355X (tests/golden/ref_kernels_golden.npz, `rub_settings`)."""
+    import hashlib
+    out = tmp_path / "out"
+    out.mkdir()
+    xml = open(os.path.join(ROOT, "cuda-flow2d_amd", "host", "settings_rub.xml")).read()
+    xml = xml.replace("./tests/data/", os.path.join(ROOT, "tests", "data") + "/").replace("./gpurun_out/", str(out) + "/")
+    assert 'levels="20"' in xml and 'outer="20"' in xml
+    s = tmp_path / "settings.xml"
+    s.write_text(xml)
+    assert subprocess.call([flow2d.CLI_PATH, str(s)], stdout=subprocess.DEVNULL) == 0
+    golden = np.load(os.path.join(ROOT, "tests", "golden", "ref_kernels_golden.npz"))
+    want_u, want_v = (str(x) for x in golden["rub_settings_sha"])
+    sha = lambda name: hashlib.sha256(np.fromfile(out / name, "<f4").tobytes()).hexdigest()
+    assert sha("flow-u-584-388.raw") == want_u and sha("flow-v-584-388.raw") == want_v
+
+
+def test_cli_unwritable_output_is_exit_code_255(flow2d, tmp_path):
+    """The reference ends with exit(-1) -- status 255 -- when the colour-wheel image or the magnitude raw cannot be
+    written (src/utils/io_utils.cpp:47-51,93-97): an output directory that does not exist does that, after the flow has
+    been computed."""
+    d = os.path.join(ROOT, "tests", "data")
+    rc = subprocess.call([flow2d.CLI_PATH, "--u8", d + "/rub1.raw", d + "/rub2.raw", "584", "388", "x_",
+                          str(tmp_path / "no" / "such" / "dir") + "/", "3.5", "0.45"], stdout=subprocess.DEVNULL,
+                         stderr=subprocess.DEVNULL)
+    assert rc == 255

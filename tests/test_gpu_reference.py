@@ -189,3 +189,42 @@ def test_reference_kernels_with_fma_contraction_stay_near(flow2d, oracle, RK):
         fu, fv, _, _ = R.compute_flow(f0, f1, *p)
     rmse = lambda a, b: float(np.sqrt(np.mean((a.astype(np.float64) - b) ** 2)))
     assert rmse(u, fu) < 5e-4 and rmse(v, fv) < 5e-4
+
+
+@pytest.mark.parametrize("constancy", ["log", "gradient"])
+def test_lock_step_groups_against_the_reference_kernels(flow2d, oracle, RK, constancy):
+    """Lock-step groups of LogDerivatives (and Gradient) pairs -- tall-container groups and groups the batch object
+    forms from scattered planes, eager and replayed -- against the reference's own kernels run pair by pair through the
+    reference's ComputeFlow sequence.  256 x 128 with four levels keeps every level a multiple of the 16x8 block."""
+    c_id = flow2d.LOG_DERIVATIVES if constancy == "log" else flow2d.GRADIENT
+    w, h, G = 256, 128, 3
+    p = (4, 0.5, 3, 5, 0.0005 if constancy == "log" else 35.0, 0.001, 0.001, 5, 1.5)
+    pairs = [oracle.synthetic_pair(w, h, 1.5 * np.cos(k), -1.0 + 0.5 * k, seed=300 + k, noise=True) for k in range(2 * G)]
+    with RK.RefKernels(w, h) as R:
+        want = [R.compute_flow(f0, f1, *p, constancy=ref_constancy(flow2d, RK, c_id))[:2] for f0, f1 in pairs]
+    assert all(float(np.abs(u).max()) > 0.01 for u, _ in want)
+    c = flow2d.Context(0)
+    batch = flow2d.OpticalFlowBatch(w, h, c_id, lanes=2, group_size=G)
+    try:
+        groups = []
+        for g in range(2):
+            mine = pairs[g * G:(g + 1) * G]
+            groups.append((c.plane(w, h * G, np.vstack([q[0] for q in mine])), c.plane(w, h * G, np.vstack([q[1] for q in mine])),
+                           c.plane(w, h * G), c.plane(w, h * G)))
+        scattered = [(c.plane(w, h, f0), c.plane(w, h, f1), c.plane(w, h), c.plane(w, h)) for f0, f1 in pairs]
+        c.synchronize()
+        for graph in (False, True, True):
+            batch.use_graph(graph)
+            batch.compute_flow_batch_device(*[[q[i].ptr for q in groups] for i in range(4)], batch.params(*p))
+            batch.compute_flow_batch_device_grouped(*[[q[i].ptr for q in scattered] for i in range(4)], batch.params(*p))
+            batch.synchronize()
+            for g, (_, _, pu, pv) in enumerate(groups):
+                u, v = pu.download(), pv.download()
+                for k in range(G):
+                    assert bits_equal(u[k * h:(k + 1) * h], want[g * G + k][0]), (graph, g, k)
+                    assert bits_equal(v[k * h:(k + 1) * h], want[g * G + k][1]), (graph, g, k)
+            for k, (_, _, pu, pv) in enumerate(scattered):
+                assert bits_equal(pu.download(), want[k][0]) and bits_equal(pv.download(), want[k][1]), (graph, k)
+    finally:
+        batch.close()
+        c.close()
