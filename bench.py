@@ -244,6 +244,8 @@ def pmc_passes(args, cfg):
 
     if not shutil.which("rocprofv3"):
         return {}
+    if any(k.startswith("ROCPROF") for k in os.environ) or "rocprofiler" in os.environ.get("LD_PRELOAD", ""):
+        return {"error": "this process is itself being profiled: no nested rocprofv3 passes"}
     out_root = tempfile.mkdtemp(prefix="flow2d_pmc_", dir="/tmp")
     rows = {}
     try:
