@@ -78,29 +78,20 @@ bool OpticalFlowBatch2D::ComputeFlowBatchDeviceGrouped(size_t count, const Devic
     return ok;
 }
 
-// The copy streams, and per lane two sets of staging planes with their hand-over events (first host-entry call).
+// Per lane one set of staging planes: frame 0, frame 1, flow u, flow v, group-tall (first host-entry call).
 bool OpticalFlowBatch2D::InitHostEntry()
 {
-    if (upload_ && download_) return true;
-    if (CheckFlow2DError(flow2d_context_create(device_, &upload_), "flow2d_context_create") ||
-        CheckFlow2DError(flow2d_context_create(device_, &download_), "flow2d_context_create"))
-        return false;
     const DataSize3 size = ContainerSize();
     for (auto& lane : lanes_)
-        for (Slot& slot : lane->slots) {
-            for (DevicePtr& plane : slot.planes) {
-                void* p = nullptr;
-                size_t pitch = 0;
-                if (CheckFlow2DError(flow2d_plane_alloc(lane->context, size.width, size.height * group_size_, &p, &pitch),
-                                     "flow2d_plane_alloc") ||
-                    pitch != size.pitch)
-                    return false;
-                plane = static_cast<DevicePtr>(reinterpret_cast<uintptr_t>(p));
-            }
-            if (CheckFlow2DError(flow2d_event_create(lane->context, &slot.uploaded), "flow2d_event_create") ||
-                CheckFlow2DError(flow2d_event_create(lane->context, &slot.computed), "flow2d_event_create") ||
-                CheckFlow2DError(flow2d_event_create(lane->context, &slot.downloaded), "flow2d_event_create"))
+        for (DevicePtr& plane : lane->staging) {
+            if (plane) continue;
+            void* p = nullptr;
+            size_t pitch = 0;
+            if (CheckFlow2DError(flow2d_plane_alloc(lane->context, size.width, size.height * group_size_, &p, &pitch),
+                                 "flow2d_plane_alloc") ||
+                pitch != size.pitch)
                 return false;
+            plane = static_cast<DevicePtr>(reinterpret_cast<uintptr_t>(p));
         }
     return true;
 }
@@ -128,39 +119,31 @@ bool OpticalFlowBatch2D::ComputeFlowBatch(size_t count, Data2D* const* frames_0,
     const size_t row = size.width * sizeof(float);
     const size_t stride = GroupStrideBytes();
     bool ok = true;
+    // Upload, pyramid and download of an entry are queued on ITS LANE's stream, in that order; what overlaps are the
+    // lanes: while one lane's DMA engines move its frames or flows, the others compute.  (A first version with a
+    // dedicated upload and a dedicated download stream chained to the lanes by events ran 9 % slower: 199 against 218
+    // pairs/s at 4096^2, 228 with the copies taken out.)  The stream order also makes one staging set per lane enough.
     for (size_t entry = 0; entry * group_size_ < count; ++entry) {
         Lane& lane = *lanes_[(first_lane + entry) % lanes_.size()];
-        Slot& slot = lane.slots[lane.next_slot];
-        lane.next_slot = (lane.next_slot + 1) % kSlots;
         char* planes[4];
-        for (int i = 0; i < 4; ++i) planes[i] = reinterpret_cast<char*>(AsPlane(slot.planes[i]));
-        // stage 1, upload stream: the slot's frames are free once the pyramid that read them last is through
-        ok &= !CheckFlow2DError(flow2d_stream_wait_event(upload_, slot.computed), "flow2d_stream_wait_event");
+        for (int i = 0; i < 4; ++i) planes[i] = reinterpret_cast<char*>(AsPlane(lane.staging[i]));
         for (size_t g = 0; g < group_size_; ++g) {
             const size_t k = entry * group_size_ + g;
-            ok &= !CheckFlow2DError(flow2d_copy_h2d_2d(upload_, planes[0] + g * stride, size.pitch, frames_0[k]->DataPtr(),
-                                                       row, row, size.height), "flow2d_copy_h2d_2d");
-            ok &= !CheckFlow2DError(flow2d_copy_h2d_2d(upload_, planes[1] + g * stride, size.pitch, frames_1[k]->DataPtr(),
-                                                       row, row, size.height), "flow2d_copy_h2d_2d");
+            ok &= !CheckFlow2DError(flow2d_copy_h2d_2d(lane.context, planes[0] + g * stride, size.pitch,
+                                                       frames_0[k]->DataPtr(), row, row, size.height), "flow2d_copy_h2d_2d");
+            ok &= !CheckFlow2DError(flow2d_copy_h2d_2d(lane.context, planes[1] + g * stride, size.pitch,
+                                                       frames_1[k]->DataPtr(), row, row, size.height), "flow2d_copy_h2d_2d");
         }
-        ok &= !CheckFlow2DError(flow2d_event_record(upload_, slot.uploaded), "flow2d_event_record");
-        // stage 2, the lane: after the upload, and after the download that read the slot's flow planes last
-        ok &= !CheckFlow2DError(flow2d_stream_wait_event(lane.context, slot.uploaded), "flow2d_stream_wait_event");
-        ok &= !CheckFlow2DError(flow2d_stream_wait_event(lane.context, slot.downloaded), "flow2d_stream_wait_event");
         lane.flow.use_graph = use_graph;
         lane.flow.timing_mode = 0;
-        ok &= lane.flow.ComputeFlowDevice(slot.planes[0], slot.planes[1], slot.planes[2], slot.planes[3], params);
-        ok &= !CheckFlow2DError(flow2d_event_record(lane.context, slot.computed), "flow2d_event_record");
-        // stage 3, download stream
-        ok &= !CheckFlow2DError(flow2d_stream_wait_event(download_, slot.computed), "flow2d_stream_wait_event");
+        ok &= lane.flow.ComputeFlowDevice(lane.staging[0], lane.staging[1], lane.staging[2], lane.staging[3], params);
         for (size_t g = 0; g < group_size_; ++g) {
             const size_t k = entry * group_size_ + g;
-            ok &= !CheckFlow2DError(flow2d_copy_d2h_2d(download_, flows_u[k]->DataPtr(), row, planes[2] + g * stride,
+            ok &= !CheckFlow2DError(flow2d_copy_d2h_2d(lane.context, flows_u[k]->DataPtr(), row, planes[2] + g * stride,
                                                        size.pitch, row, size.height), "flow2d_copy_d2h_2d");
-            ok &= !CheckFlow2DError(flow2d_copy_d2h_2d(download_, flows_v[k]->DataPtr(), row, planes[3] + g * stride,
+            ok &= !CheckFlow2DError(flow2d_copy_d2h_2d(lane.context, flows_v[k]->DataPtr(), row, planes[3] + g * stride,
                                                        size.pitch, row, size.height), "flow2d_copy_d2h_2d");
         }
-        ok &= !CheckFlow2DError(flow2d_event_record(download_, slot.downloaded), "flow2d_event_record");
     }
     return ok;
 }
@@ -168,37 +151,24 @@ bool OpticalFlowBatch2D::ComputeFlowBatch(size_t count, Data2D* const* frames_0,
 bool OpticalFlowBatch2D::Synchronize()
 {
     bool ok = true;
-    if (upload_) ok &= !CheckFlow2DError(flow2d_synchronize(upload_), "flow2d_synchronize");
     for (auto& lane : lanes_)
         if (lane->context) ok &= !CheckFlow2DError(flow2d_synchronize(lane->context), "flow2d_synchronize");
-    if (download_) ok &= !CheckFlow2DError(flow2d_synchronize(download_), "flow2d_synchronize");
     return ok;
 }
 
 void OpticalFlowBatch2D::Destroy()
 {
-    if (!lanes_.empty()) (void)Synchronize();
     for (auto& lane : lanes_) {
         if (lane->context) (void)flow2d_synchronize(lane->context);
         lane->flow.Destroy();
-        for (Slot& slot : lane->slots) {
-            for (DevicePtr& plane : slot.planes) {
-                if (plane && lane->context) flow2d_plane_free(lane->context, AsPlane(plane));
-                plane = 0;
-            }
-            void** events[3] = {&slot.uploaded, &slot.computed, &slot.downloaded};
-            for (void** ev : events) {
-                if (*ev && lane->context) flow2d_event_destroy(lane->context, *ev);
-                *ev = nullptr;
-            }
+        for (DevicePtr& plane : lane->staging) {
+            if (plane && lane->context) flow2d_plane_free(lane->context, AsPlane(plane));
+            plane = 0;
         }
         if (lane->context) flow2d_context_destroy(lane->context);
         lane->context = nullptr;
     }
     lanes_.clear();
-    if (upload_) flow2d_context_destroy(upload_);
-    if (download_) flow2d_context_destroy(download_);
-    upload_ = download_ = nullptr;
 }
 
 DataSize3 OpticalFlowBatch2D::ContainerSize() const

@@ -53,19 +53,18 @@ public:
                                        OperationParameters& params, size_t first_lane = 0);
 
     // The same for HOST images -- the bracket of the reference's own timer, uploads and downloads included
-    // (optical_flow_2d.cpp:173-179,214-215,544-554) -- as a three-stage pipeline: an upload stream copies pair k + 1 into
-    // a lane's staging planes while the lanes compute pair k (and the pairs before it) and a download stream copies
-    // pair k - 1 out; events chain the stages, the host waits for nothing.  Every lane owns two sets of staging planes
-    // (frames in, flow out), so up to 2 x lanes pairs are between upload and download at any time.  frames_*[k] are
-    // read, flows_*[k] (pre-allocated, ContainerSize() wide and high) written; all four must stay alive and untouched
-    // until Synchronize().  Images in page-locked memory (Data2D(w, h, HostMemory::Pinned)) move by DMA at the PCIe rate
-    // and overlap the pyramids; pageable images are staged by the runtime and stall the host (same results).  With
+    // (optical_flow_2d.cpp:173-179,214-215,544-554): entry k's frames are copied into its lane's staging planes, its
+    // pyramid runs, and its flows are copied out, all queued on the lane's stream; the lanes overlap each other, so one
+    // lane's DMA transfers run beside the others' kernels and the host waits for nothing.  frames_*[k] are read,
+    // flows_*[k] (pre-allocated, ContainerSize() wide and high) written; all four must stay alive and untouched until
+    // Synchronize().  Images in page-locked memory (Data2D(w, h, HostMemory::Pinned)) move by DMA at the PCIe rate
+    // without blocking the host; pageable images are staged by the runtime and stall it (same results).  With
     // group_size > 1 consecutive pairs form the lock-step groups, so count must be a multiple of it.  Results are those
     // of OpticalFlow2D::ComputeFlow per pair, bit for bit.
     bool ComputeFlowBatch(size_t count, Data2D* const* frames_0, Data2D* const* frames_1, Data2D* const* flows_u,
                           Data2D* const* flows_v, OperationParameters& params, size_t first_lane = 0);
 
-    bool Synchronize();  // waits for every lane's stream and for the upload / download streams
+    bool Synchronize();  // waits for every lane's stream
     void Destroy();
 
     bool use_graph = true;
@@ -78,23 +77,13 @@ public:
     flow2d_context* LaneContext(size_t lane) const;
 
 private:
-    static constexpr int kSlots = 2;
-    struct Slot {  // one set of staging planes of the host entry and the events that hand it from stage to stage
-        DevicePtr planes[4] = {0, 0, 0, 0};  // frame 0, frame 1, flow u, flow v (group_size containers tall)
-        void* uploaded = nullptr;            // recorded on the upload stream behind the slot's two frame copies
-        void* computed = nullptr;            // recorded on the lane's stream behind the slot's pyramid
-        void* downloaded = nullptr;          // recorded on the download stream behind the slot's two flow copies
-    };
     struct Lane {
         flow2d_context* context = nullptr;
         OpticalFlow2D flow;
-        Slot slots[kSlots];
-        size_t next_slot = 0;
+        DevicePtr staging[4] = {0, 0, 0, 0};  // host entry: frame 0, frame 1, flow u, flow v (group_size containers tall)
     };
     bool InitHostEntry();
     std::vector<std::unique_ptr<Lane>> lanes_;
     size_t group_size_ = 1;
     int device_ = 0;
-    flow2d_context* upload_ = nullptr;    // created by the first ComputeFlowBatch
-    flow2d_context* download_ = nullptr;
 };

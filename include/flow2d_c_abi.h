@@ -139,7 +139,7 @@ FLOW2D_API int flow2d_event_elapsed_ms(flow2d_context* ctx, void* start_event, v
 FLOW2D_API int flow2d_event_destroy(flow2d_context* ctx, void* event);
 /* Everything queued on `ctx` after this call waits until the work recorded into `event` (by flow2d_event_record on any
  * context of the same device) has finished; the host does not wait.  An event never recorded counts as finished.  This
- * is what chains an upload stream, the lanes' compute streams and a download stream into a pipeline (no reference
+ * is what chains work on several contexts -- copy streams, compute streams -- into a pipeline (no reference
  * counterpart: one NULL stream, host-synchronous copies, src/utils/cuda_utils.cpp:66-105). */
 FLOW2D_API int flow2d_stream_wait_event(flow2d_context* ctx, void* event);
 

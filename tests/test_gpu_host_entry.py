@@ -9,8 +9,8 @@ pytestmark = pytest.mark.gpu
 @pytest.mark.parametrize("pinned", [True, False])
 @pytest.mark.parametrize("lanes,constancy,sigma", [(3, 0, 1.5), (2, 1, 0.0)])
 def test_host_entry_pipeline_matches_the_oracle(flow2d, oracle, pinned, lanes, constancy, sigma):
-    """11 distinct pairs through `lanes` lanes with two staging slots each: every slot is reused, uploads run ahead of
-    the pyramids and downloads behind them; graph replay and eager; a second call continues on the same slots."""
+    """11 distinct pairs through `lanes` lanes: every lane's staging planes are reused several times, upload, pyramid and
+    download of a pair queued on the lane's stream; graph replay and eager; a second call continues on the same lanes."""
     w, h, n = 208, 144, 11
     p = (4, 0.5, 2, 5, 35.0, 0.001, 0.001, 5, sigma)
     pairs = [oracle.synthetic_pair(w, h, 1.0 + 0.3 * k, -0.25 * k, seed=70 + k, noise=True) for k in range(n)]
