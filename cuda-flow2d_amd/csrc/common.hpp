@@ -93,6 +93,26 @@ __device__ __forceinline__ size_t batch_offset(const BatchArg& b)
     return static_cast<size_t>(blockIdx.z / b.planes) * static_cast<size_t>(b.stride);
 }
 
+// XCD-aware tile order of a one-dimensional grid (stencil kernels whose workgroups re-read their neighbours' rows and
+// columns).  The hardware deals workgroups to the eight XCDs in turn -- workgroup id % 8 -- and every XCD has an L2 of
+// its own, so with a plain 2-D grid the x neighbours of a tile run on OTHER XCDs and every halo column is fetched from
+// HBM again (64-byte sectors of the neighbour's 256-byte row: 1.7x the algorithmic bytes measured on the sweep kernels).
+// Here XCD k owns the horizontal band of tile rows [k * rows_per_xcd, (k + 1) * rows_per_xcd) and walks it row-major:
+// both the x and the y neighbours of a tile are workgroups of the same XCD, a few ids apart.  Which XCD gets id % 8 == k
+// is the hardware's business and only affects speed.
+struct XcdTiles {
+    unsigned tiles_x, tiles_y, rows_per_xcd;
+};
+inline XcdTiles xcd_tiles(unsigned tiles_x, unsigned tiles_y) { return XcdTiles{tiles_x, tiles_y, (tiles_y + 7u) / 8u}; }
+inline unsigned xcd_grid(const XcdTiles& t) { return 8u * t.rows_per_xcd * t.tiles_x; }
+__device__ __forceinline__ bool xcd_tile(const XcdTiles& t, unsigned id, unsigned& tile_x, unsigned& tile_y)
+{
+    const unsigned xcd = id & 7u, j = id >> 3;
+    tile_y = xcd * t.rows_per_xcd + j / t.tiles_x;
+    tile_x = j % t.tiles_x;
+    return tile_y < t.tiles_y;  // the last band may be short: its surplus workgroups leave at once
+}
+
 // Reflect-without-repeat index of the solver / median halos: -k -> k, n-1+k -> n-1-k.
 __device__ __forceinline__ int mirror_index(int i, int n)
 {

@@ -6,8 +6,11 @@
 //
 // Mapping: one wave = 64 consecutive pixels of one image row, so each of the 8 input planes is
 // read as contiguous 256-byte row segments; the x+-1 / y+-1 neighbours of a wave come from the same
-// or the adjacent rows' segments and are L1/L2 hits (HBM sees each plane once: 40 B per pixel-sweep,
-// 32 B per pixel for phi/ksi).  Arithmetic keeps the reference's order of operations; the file is
+// or the adjacent rows' segments.  For those to be L2 hits the neighbouring workgroups must run on the
+// same XCD (each XCD has an L2 of its own): the grid is one-dimensional and XCD-aware (common.hpp,
+// XcdTiles: every XCD walks a horizontal band of the level row-major), so HBM sees each plane about
+// once: 40 B per pixel-sweep, 32 B per pixel for phi/ksi.  With the plain 2-D grid of rounds 1-2 the x
+// neighbours of a tile sat on other XCDs and the kernels moved 1.69x their algorithmic bytes.  Arithmetic keeps the reference's order of operations; the file is
 // built with -ffp-contract=off so no multiply-add is fused.
 #include "common.hpp"
 #include "solver_math.hpp"
@@ -49,11 +52,13 @@ __device__ __forceinline__ void image_derivatives(const float* __restrict__ f0, 
 __global__ __launch_bounds__(256) void phi_ksi_kernel(const float* __restrict__ f0, const float* __restrict__ f1,
                                                       const float* __restrict__ u, const float* __restrict__ v,
                                                       const float* __restrict__ du, const float* __restrict__ dv,
-                                                      int w, int h, int pitch, float hx, float hy, float e_smooth,
+                                                      XcdTiles tiles, int w, int h, int pitch, float hx, float hy, float e_smooth,
                                                       float e_data, float* __restrict__ phi, float* __restrict__ ksi)
 {
-    const int x = blockIdx.x * kBlockX + threadIdx.x;
-    const int y = blockIdx.y * kBlockY + threadIdx.y;
+    unsigned tile_x, tile_y;
+    if (!xcd_tile(tiles, blockIdx.x, tile_x, tile_y)) return;
+    const int x = tile_x * kBlockX + threadIdx.x;
+    const int y = tile_y * kBlockY + threadIdx.y;
     if (x >= w || y >= h) return;
     const Neighbourhood n = neighbourhood(x, y, w, h, pitch);
 
@@ -116,11 +121,13 @@ __global__ __launch_bounds__(256) void sweep_grey_kernel(const float* __restrict
                                                          const float* __restrict__ u, const float* __restrict__ v,
                                                          const float* __restrict__ du, const float* __restrict__ dv,
                                                          const float* __restrict__ phi, const float* __restrict__ ksi,
-                                                         int w, int h, int pitch, float hx, float hy, float alpha,
+                                                         XcdTiles tiles, int w, int h, int pitch, float hx, float hy, float alpha,
                                                          float* __restrict__ tdu, float* __restrict__ tdv)
 {
-    const int x = blockIdx.x * kBlockX + threadIdx.x;
-    const int y = blockIdx.y * kBlockY + threadIdx.y;
+    unsigned tile_x, tile_y;
+    if (!xcd_tile(tiles, blockIdx.x, tile_x, tile_y)) return;
+    const int x = tile_x * kBlockX + threadIdx.x;
+    const int y = tile_y * kBlockY + threadIdx.y;
     if (x >= w || y >= h) return;
     const Neighbourhood n = neighbourhood(x, y, w, h, pitch);
     float fx, fy, ft;
@@ -142,7 +149,7 @@ __global__ __launch_bounds__(512) void sweep_grad_kernel(const float* __restrict
                                                          const float* __restrict__ u, const float* __restrict__ v,
                                                          const float* __restrict__ du, const float* __restrict__ dv,
                                                          const float* __restrict__ phi, const float* __restrict__ ksi,
-                                                         int w, int h, int pitch, float hx, float hy, float alpha,
+                                                         XcdTiles tiles, int w, int h, int pitch, float hx, float hy, float alpha,
                                                          float* __restrict__ tdu, float* __restrict__ tdv)
 {
     __shared__ float s_fx[kGradTileY][kBlockX];
@@ -150,8 +157,10 @@ __global__ __launch_bounds__(512) void sweep_grad_kernel(const float* __restrict
     __shared__ float s_ft[kGradTileY][kBlockX];
 
     const int tx = threadIdx.x, ty = threadIdx.y;
-    const int x = blockIdx.x * kBlockX + tx;
-    const int y = blockIdx.y * kGradTileY + ty;
+    unsigned tile_x, tile_y;
+    if (!xcd_tile(tiles, blockIdx.x, tile_x, tile_y)) return;
+    const int x = tile_x * kBlockX + tx;
+    const int y = tile_y * kGradTileY + ty;
     const bool inside = x < w && y < h;
     Neighbourhood n{};
     if (inside) {
@@ -209,7 +218,7 @@ __global__ __launch_bounds__(512) void sweep_log_kernel(const float* __restrict_
                                                         const float* __restrict__ u, const float* __restrict__ v,
                                                         const float* __restrict__ du, const float* __restrict__ dv,
                                                         const float* __restrict__ phi, const float* __restrict__ ksi,
-                                                        int w, int h, int pitch, float hx, float hy, float alpha,
+                                                        XcdTiles tiles, int w, int h, int pitch, float hx, float hy, float alpha,
                                                         float* __restrict__ tdu, float* __restrict__ tdv)
 {
     __shared__ float s_fx[kGradTileY][kBlockX];
@@ -217,8 +226,10 @@ __global__ __launch_bounds__(512) void sweep_log_kernel(const float* __restrict_
     __shared__ float s_ft[kGradTileY][kBlockX];
 
     const int tx = threadIdx.x, ty = threadIdx.y;
-    const int x = blockIdx.x * kBlockX + tx;
-    const int y = blockIdx.y * kGradTileY + ty;
+    unsigned tile_x, tile_y;
+    if (!xcd_tile(tiles, blockIdx.x, tile_x, tile_y)) return;
+    const int x = tile_x * kBlockX + tx;
+    const int y = tile_y * kGradTileY + ty;
     const bool inside = x < w && y < h;
     Neighbourhood n{};
     if (inside) {
@@ -280,11 +291,13 @@ __device__ __forceinline__ void untiled_gradient_tensor(const float* __restrict_
 __global__ __launch_bounds__(256) void sweep_grad_untiled_kernel(
     const float* __restrict__ f0, const float* __restrict__ f1, const float* __restrict__ u, const float* __restrict__ v,
     const float* __restrict__ du, const float* __restrict__ dv, const float* __restrict__ phi,
-    const float* __restrict__ ksi, int w, int h, int pitch, float hx, float hy, float alpha, float* __restrict__ tdu,
+    const float* __restrict__ ksi, XcdTiles tiles, int w, int h, int pitch, float hx, float hy, float alpha, float* __restrict__ tdu,
     float* __restrict__ tdv)
 {
-    const int x = blockIdx.x * kBlockX + threadIdx.x;
-    const int y = blockIdx.y * kBlockY + threadIdx.y;
+    unsigned tile_x, tile_y;
+    if (!xcd_tile(tiles, blockIdx.x, tile_x, tile_y)) return;
+    const int x = tile_x * kBlockX + threadIdx.x;
+    const int y = tile_y * kBlockY + threadIdx.y;
     if (x >= w || y >= h) return;
     float J11, J22, J12, J13, J23;
     untiled_gradient_tensor(f0, f1, x, y, w, h, pitch, hx, hy, J11, J22, J12, J13, J23);
@@ -295,11 +308,13 @@ __global__ __launch_bounds__(256) void sweep_grad_untiled_kernel(
 __global__ __launch_bounds__(256) void sor_grad_untiled_kernel(const float* __restrict__ f0, const float* __restrict__ f1,
                                                                const float* __restrict__ u, const float* __restrict__ v,
                                                                float* du, float* dv, const float* __restrict__ phi,
-                                                               const float* __restrict__ ksi, int w, int h, int pitch,
+                                                               const float* __restrict__ ksi, XcdTiles tiles, int w, int h, int pitch,
                                                                float hx, float hy, float alpha, float omega, int colour)
 {
-    const int x = blockIdx.x * kBlockX + threadIdx.x;
-    const int y = blockIdx.y * kBlockY + threadIdx.y;
+    unsigned tile_x, tile_y;
+    if (!xcd_tile(tiles, blockIdx.x, tile_x, tile_y)) return;
+    const int x = tile_x * kBlockX + threadIdx.x;
+    const int y = tile_y * kBlockY + threadIdx.y;
     if (x >= w || y >= h || ((x + y) & 1) != colour) return;
     float J11, J22, J12, J13, J23;
     untiled_gradient_tensor(f0, f1, x, y, w, h, pitch, hx, hy, J11, J22, J12, J13, J23);
@@ -312,11 +327,13 @@ __global__ __launch_bounds__(256) void sor_grad_untiled_kernel(const float* __re
 __global__ __launch_bounds__(256) void sor_grey_kernel(const float* __restrict__ f0, const float* __restrict__ f1,
                                                        const float* __restrict__ u, const float* __restrict__ v,
                                                        float* du, float* dv, const float* __restrict__ phi,
-                                                       const float* __restrict__ ksi, int w, int h, int pitch,
+                                                       const float* __restrict__ ksi, XcdTiles tiles, int w, int h, int pitch,
                                                        float hx, float hy, float alpha, float omega, int colour)
 {
-    const int x = blockIdx.x * kBlockX + threadIdx.x;
-    const int y = blockIdx.y * kBlockY + threadIdx.y;
+    unsigned tile_x, tile_y;
+    if (!xcd_tile(tiles, blockIdx.x, tile_x, tile_y)) return;
+    const int x = tile_x * kBlockX + threadIdx.x;
+    const int y = tile_y * kBlockY + threadIdx.y;
     if (x >= w || y >= h || ((x + y) & 1) != colour) return;
     const Neighbourhood n = neighbourhood(x, y, w, h, pitch);
     float fx, fy, ft;
@@ -328,15 +345,17 @@ __global__ __launch_bounds__(256) void sor_grey_kernel(const float* __restrict__
 __global__ __launch_bounds__(512) void sor_grad_kernel(const float* __restrict__ f0, const float* __restrict__ f1,
                                                        const float* __restrict__ u, const float* __restrict__ v,
                                                        float* du, float* dv, const float* __restrict__ phi,
-                                                       const float* __restrict__ ksi, int w, int h, int pitch,
+                                                       const float* __restrict__ ksi, XcdTiles tiles, int w, int h, int pitch,
                                                        float hx, float hy, float alpha, float omega, int colour)
 {
     __shared__ float s_fx[kGradTileY][kBlockX];
     __shared__ float s_fy[kGradTileY][kBlockX];
     __shared__ float s_ft[kGradTileY][kBlockX];
     const int tx = threadIdx.x, ty = threadIdx.y;
-    const int x = blockIdx.x * kBlockX + tx;
-    const int y = blockIdx.y * kGradTileY + ty;
+    unsigned tile_x, tile_y;
+    if (!xcd_tile(tiles, blockIdx.x, tile_x, tile_y)) return;
+    const int x = tile_x * kBlockX + tx;
+    const int y = tile_y * kGradTileY + ty;
     const bool inside = x < w && y < h;
     Neighbourhood n{};
     if (inside) {
@@ -387,8 +406,9 @@ int launch_phi_ksi(flow2d_context* ctx, const float* f0, const float* f1, const 
         ctx->batch_count = n;
         return st;
     }
-    const dim3 grid(div_up(w, kBlockX), div_up(h, kBlockY));
-    phi_ksi_kernel<<<grid, dim3(kBlockX, kBlockY), 0, ctx->stream>>>(f0, f1, u, v, du, dv, (int)w, (int)h,
+    const XcdTiles tiles = xcd_tiles(div_up(w, kBlockX), div_up(h, kBlockY));
+        const dim3 grid(xcd_grid(tiles));
+    phi_ksi_kernel<<<grid, dim3(kBlockX, kBlockY), 0, ctx->stream>>>(f0, f1, u, v, du, dv, tiles, (int)w, (int)h,
                                                                      (int)(pitch_bytes / 4), hx, hy, e_smooth, e_data,
                                                                      phi, ksi);
     FLOW2D_CHECK_LAUNCH();
@@ -411,21 +431,25 @@ int launch_sweep(flow2d_context* ctx, int constancy, const float* f0, const floa
         return st;
     }
     if (constancy == FLOW2D_CONSTANCY_GRADIENT) {
-        const dim3 grid(div_up(w, kBlockX), div_up(h, kGradTileY));
+        const XcdTiles tiles = xcd_tiles(div_up(w, kBlockX), div_up(h, kGradTileY));
+        const dim3 grid(xcd_grid(tiles));
         sweep_grad_kernel<<<grid, dim3(kBlockX, kGradTileY), 0, ctx->stream>>>(
-            f0, f1, u, v, du, dv, phi, ksi, (int)w, (int)h, (int)(pitch_bytes / 4), hx, hy, alpha, tdu, tdv);
+            f0, f1, u, v, du, dv, phi, ksi, tiles, (int)w, (int)h, (int)(pitch_bytes / 4), hx, hy, alpha, tdu, tdv);
     } else if (constancy == FLOW2D_CONSTANCY_LOG_DERIVATIVES) {
-        const dim3 grid(div_up(w, kBlockX), div_up(h, kGradTileY));
+        const XcdTiles tiles = xcd_tiles(div_up(w, kBlockX), div_up(h, kGradTileY));
+        const dim3 grid(xcd_grid(tiles));
         sweep_log_kernel<<<grid, dim3(kBlockX, kGradTileY), 0, ctx->stream>>>(
-            f0, f1, u, v, du, dv, phi, ksi, (int)w, (int)h, (int)(pitch_bytes / 4), hx, hy, alpha, tdu, tdv);
+            f0, f1, u, v, du, dv, phi, ksi, tiles, (int)w, (int)h, (int)(pitch_bytes / 4), hx, hy, alpha, tdu, tdv);
     } else if (constancy == FLOW2D_CONSTANCY_GRADIENT_UNTILED) {
-        const dim3 grid(div_up(w, kBlockX), div_up(h, kBlockY));
+        const XcdTiles tiles = xcd_tiles(div_up(w, kBlockX), div_up(h, kBlockY));
+        const dim3 grid(xcd_grid(tiles));
         sweep_grad_untiled_kernel<<<grid, dim3(kBlockX, kBlockY), 0, ctx->stream>>>(
-            f0, f1, u, v, du, dv, phi, ksi, (int)w, (int)h, (int)(pitch_bytes / 4), hx, hy, alpha, tdu, tdv);
+            f0, f1, u, v, du, dv, phi, ksi, tiles, (int)w, (int)h, (int)(pitch_bytes / 4), hx, hy, alpha, tdu, tdv);
     } else {
-        const dim3 grid(div_up(w, kBlockX), div_up(h, kBlockY));
+        const XcdTiles tiles = xcd_tiles(div_up(w, kBlockX), div_up(h, kBlockY));
+        const dim3 grid(xcd_grid(tiles));
         sweep_grey_kernel<<<grid, dim3(kBlockX, kBlockY), 0, ctx->stream>>>(
-            f0, f1, u, v, du, dv, phi, ksi, (int)w, (int)h, (int)(pitch_bytes / 4), hx, hy, alpha, tdu, tdv);
+            f0, f1, u, v, du, dv, phi, ksi, tiles, (int)w, (int)h, (int)(pitch_bytes / 4), hx, hy, alpha, tdu, tdv);
     }
     FLOW2D_CHECK_LAUNCH();
     return FLOW2D_OK;
@@ -449,17 +473,20 @@ int launch_sor_iteration(flow2d_context* ctx, int constancy, const float* f0, co
     }
     for (int colour = 0; colour < 2; ++colour) {
         if (constancy == FLOW2D_CONSTANCY_GRADIENT) {
-            const dim3 grid(div_up(w, kBlockX), div_up(h, kGradTileY));
+            const XcdTiles tiles = xcd_tiles(div_up(w, kBlockX), div_up(h, kGradTileY));
+        const dim3 grid(xcd_grid(tiles));
             sor_grad_kernel<<<grid, dim3(kBlockX, kGradTileY), 0, ctx->stream>>>(
-                f0, f1, u, v, du, dv, phi, ksi, (int)w, (int)h, (int)(pitch_bytes / 4), hx, hy, alpha, omega, colour);
+                f0, f1, u, v, du, dv, phi, ksi, tiles, (int)w, (int)h, (int)(pitch_bytes / 4), hx, hy, alpha, omega, colour);
         } else if (constancy == FLOW2D_CONSTANCY_GRADIENT_UNTILED) {
-            const dim3 grid(div_up(w, kBlockX), div_up(h, kBlockY));
+            const XcdTiles tiles = xcd_tiles(div_up(w, kBlockX), div_up(h, kBlockY));
+        const dim3 grid(xcd_grid(tiles));
             sor_grad_untiled_kernel<<<grid, dim3(kBlockX, kBlockY), 0, ctx->stream>>>(
-                f0, f1, u, v, du, dv, phi, ksi, (int)w, (int)h, (int)(pitch_bytes / 4), hx, hy, alpha, omega, colour);
+                f0, f1, u, v, du, dv, phi, ksi, tiles, (int)w, (int)h, (int)(pitch_bytes / 4), hx, hy, alpha, omega, colour);
         } else {
-            const dim3 grid(div_up(w, kBlockX), div_up(h, kBlockY));
+            const XcdTiles tiles = xcd_tiles(div_up(w, kBlockX), div_up(h, kBlockY));
+        const dim3 grid(xcd_grid(tiles));
             sor_grey_kernel<<<grid, dim3(kBlockX, kBlockY), 0, ctx->stream>>>(
-                f0, f1, u, v, du, dv, phi, ksi, (int)w, (int)h, (int)(pitch_bytes / 4), hx, hy, alpha, omega, colour);
+                f0, f1, u, v, du, dv, phi, ksi, tiles, (int)w, (int)h, (int)(pitch_bytes / 4), hx, hy, alpha, omega, colour);
         }
         FLOW2D_CHECK_LAUNCH();
     }
