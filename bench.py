@@ -102,31 +102,38 @@ def pair_shift(workload, cfg, k):
     return cfg["dx"], cfg["dy"]
 
 
-def cpu_baseline(cfg, budget_s=20.0):
-    """The CPU oracle (oracle/flow2d_oracle.c, OpenMP) timed on this box's host cores on a BOUNDED sample of
-    the same workload: the same pyramid/solver parameters on a centre crop sized so the run stays within
-    ~budget_s seconds of CPU work.  Same metric definition as `value`.  Rank 0, N = 1 only."""
+def cpu_baseline(cfg, budget_s=20.0, full_run=None):
+    """The CPU oracle (oracle/flow2d_oracle.c, OpenMP) timed on this box's host cores, same metric definition as `value`.
+    Sample: the WHOLE workload pair when the output check has just run the oracle on it (full_run = (wall seconds,
+    finest-level solve seconds): at 4096^2 about 5 s on 16 threads), otherwise the same pyramid / solver parameters on
+    the largest power-of-two centre crop that stays within ~budget_s seconds of CPU work.  Rank 0, N = 1 only."""
     from oracle import oracle as O
 
     O.lib()
     threads = O.max_threads()
-    # calibrate on a small crop, then pick the largest power-of-two crop inside the CPU-seconds budget
     probe = 256
     f0, f1 = synthetic_pair(probe, probe, cfg["dx"], cfg["dy"])
     t0 = time.perf_counter()
     O.compute_flow(f0, f1, cfg["levels"], cfg["scale"], cfg["outer"], cfg["inner"], cfg["alpha"], 0.001, 0.001,
                    cfg["median"], cfg["sigma"], cfg["constancy"])
     t_probe = time.perf_counter() - t0
-    per_px_cpu_s = t_probe * threads / (probe * probe)
-    side = probe
-    while side * 2 <= min(cfg["w"], cfg["h"]) and per_px_cpu_s * (side * 2) ** 2 <= budget_s:
-        side *= 2
-    f0, f1 = synthetic_pair(side, side, cfg["dx"], cfg["dy"])
-    t0 = time.perf_counter()
-    _, _, t_finest = O.compute_flow(f0, f1, cfg["levels"], cfg["scale"], cfg["outer"], cfg["inner"], cfg["alpha"],
-                                    0.001, 0.001, cfg["median"], cfg["sigma"], cfg["constancy"])
-    t = time.perf_counter() - t0
-    px_iters = side * side * cfg["outer"] * cfg["inner"]
+    if full_run is not None:
+        side_w, side_h, (t, t_finest) = cfg["w"], cfg["h"], full_run
+        what = "the workload's whole %dx%d pair" % (side_w, side_h)
+    else:
+        # calibrate on the small crop, then pick the largest power-of-two crop inside the CPU-seconds budget
+        per_px_cpu_s = t_probe * threads / (probe * probe)
+        side = probe
+        while side * 2 <= min(cfg["w"], cfg["h"]) and per_px_cpu_s * (side * 2) ** 2 <= budget_s:
+            side *= 2
+        f0, f1 = synthetic_pair(side, side, cfg["dx"], cfg["dy"])
+        t0 = time.perf_counter()
+        _, _, t_finest = O.compute_flow(f0, f1, cfg["levels"], cfg["scale"], cfg["outer"], cfg["inner"], cfg["alpha"],
+                                        0.001, 0.001, cfg["median"], cfg["sigma"], cfg["constancy"])
+        t = time.perf_counter() - t0
+        side_w = side_h = side
+        what = "%dx%d crop of the workload's synthetic pair" % (side, side)
+    px_iters = side_w * side_h * cfg["outer"] * cfg["inner"]
     # the same code on ONE thread (SURVEY 8d asks for both), on the small calibration crop
     O.set_threads(1)
     f0s, f1s = synthetic_pair(probe, probe, cfg["dx"], cfg["dy"])
@@ -140,8 +147,9 @@ def cpu_baseline(cfg, budget_s=20.0):
         "unit": "Mpixel*iters/s",
         "cores": threads,
         "kind": "port",
-        "sample": "%dx%d crop of the workload's synthetic pair, same levels/outer/inner/constancy, one full "
-                  "pyramid, %.2f s wall on %d OpenMP threads" % (side, side, t, threads),
+        "sample": "%s, same levels/outer/inner/constancy, one full pyramid, %.2f s wall on %d OpenMP threads" %
+                  (what, t, threads),
+        "pairs_per_s": round(1.0 / t, 4) if full_run is not None else None,
         "finest_level_solve_mpix_iters_per_s": round(px_iters / t_finest / 1e6, 2) if t_finest > 0 else None,
         "single_thread": {"value": round(probe * probe * cfg["outer"] * cfg["inner"] / t_single / 1e6, 2),
                           "sample": "%dx%d crop, %.2f s wall on 1 thread" % (probe, probe, t_single)},
@@ -586,11 +594,13 @@ def oracle_check(job):
     _, _, pu, pv, _ = job.sets[0]
     u, v = pu.download()[:h], pv.download()[:h]
     t0 = time.perf_counter()
-    ou, ov, _ = O.compute_flow(job.first_pair[0], job.first_pair[1], cfg["levels"], cfg["scale"], cfg["outer"], cfg["inner"],
-                               cfg["alpha"], 0.001, 0.001, cfg["median"], cfg["sigma"], cfg["constancy"])
+    ou, ov, t_finest = O.compute_flow(job.first_pair[0], job.first_pair[1], cfg["levels"], cfg["scale"], cfg["outer"],
+                                      cfg["inner"], cfg["alpha"], 0.001, 0.001, cfg["median"], cfg["sigma"], cfg["constancy"])
+    seconds = time.perf_counter() - t0
     return {"first_pair_equals_cpu_oracle": bool(np.array_equal(u, ou) and np.array_equal(v, ov)),
-            "pixels_compared": int(2 * u.size), "oracle_seconds": round(time.perf_counter() - t0, 2),
-            "max_abs_difference": float(max(np.abs(u - ou).max(), np.abs(v - ov).max()))}
+            "pixels_compared": int(2 * u.size), "oracle_seconds": round(seconds, 2),
+            "max_abs_difference": float(max(np.abs(u - ou).max(), np.abs(v - ov).max())),
+            "_timing": (seconds, t_finest)}
 
 
 def roofline_sample(job, passes=3):
@@ -803,10 +813,20 @@ def main():
     w, h = cfg["w"], cfg["h"]
     job = Job(flow2d, batch, args.workload, cfg, args, rank, local_rank, world)
     free_b, total_b = job.ctx.mem_info()
+    plane_b = job.runner.pitch * h * (job.group if job.step_group == 1 else job.step_group)  # a (group-tall) container
+    memory_parts = {
+        "container_mib": round(job.runner.pitch * h / 2 ** 20, 1),
+        "plane_pools_gib": round(job.n_lanes * 14 * plane_b / 2 ** 30, 3),  # per lane: the 12 containers + 2 packed planes
+        "caller_planes_gib": round(sum(q.pitch * q.height for q in {q for s in job.sets for q in s[:4]}) / 2 ** 30, 3),
+        "what": "%d lanes x 14 planes of %d container(s) each, plus the bench's own frame / flow planes (every lane works "
+                "on planes of its own)" % (job.n_lanes, job.group if job.step_group == 1 else job.step_group),
+    }
     elapsed = timed_region(job, batch, torch, args.steps, args.warmup)   # <- the number
     check = output_check(job)
+    oracle_timing = None
     if rank == 0 and not args.no_oracle_check:
         check["oracle"] = oracle_check(job)
+        oracle_timing = check["oracle"].pop("_timing")
         check["ok"] = check["ok"] and check["oracle"]["first_pair_equals_cpu_oracle"]
     host_entry = host_entry_leg(job, batch, torch, max(5, args.steps)) if not args.no_host_entry_leg else None
     if host_entry is not None and not host_entry["flows_bit_identical_to_device_resident_run"]:
@@ -926,10 +946,11 @@ def main():
             "roofline": roof,
             "output_check": check,
             "batch": batch_result,
-            "device_memory": {"used_gib": round((total_b - free_b) / 2 ** 30, 3), "total_gib": round(total_b / 2 ** 30, 1)},
+            "device_memory": dict({"used_gib": round((total_b - free_b) / 2 ** 30, 3), "total_gib": round(total_b / 2 ** 30, 1)},
+                                  **memory_parts),
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(cfg)
+            out["cpu_baseline"] = cpu_baseline(cfg, full_run=oracle_timing)
         else:
             out["cpu_baseline"] = None
         if world == 1 and not args.no_reference_baseline:

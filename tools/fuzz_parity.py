@@ -1,5 +1,6 @@
 """Developer tool: random whole-pipeline configurations, product (single pairs and lock-step groups) against the CPU
-oracle, bit for bit.  usage (GPU box): python tools/fuzz_parity.py [cases] [seed]"""
+oracle, bit for bit.  usage (GPU box): python tools/fuzz_parity.py [cases] [seed] [solver algorithm: 0 auto, 2 fused strips
+on every level, ...]"""
 import importlib
 import os
 import sys
@@ -15,6 +16,7 @@ from oracle import oracle as O
 def main():
     cases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
     rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+    algorithm = int(sys.argv[3]) if len(sys.argv) > 3 else 0
     ctx = F.Context(0)
     bad = 0
     t0 = time.time()
@@ -33,7 +35,7 @@ def main():
                       ctx.plane(w, h * G).fill_bytes(0x7f), ctx.plane(w, h * G).fill_bytes(0x7f)]
             batch.use_graph(bool(rng.integers(2)))
             try:
-                batch.compute_flow_batch_device(*[[q.ptr] for q in planes], batch.params(*p))
+                batch.compute_flow_batch_device(*[[q.ptr] for q in planes], batch.params(*p, algorithm))
             except F.Flow2DError as e:
                 print("case %d refused (%s): %s" % (n, e, (w, h, constancy, p, G)))
                 continue
