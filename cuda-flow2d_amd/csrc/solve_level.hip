@@ -59,10 +59,15 @@ hipError_t mark(flow2d_context* ctx, flow2d_timing_slot* slot)
 }
 }  // namespace
 
-// largest level (pixels) AUTO gives to the tiled kernel; FLOW2D_TILED_MAX_PIXELS overrides (developer knob)
-static const size_t kTiledMaxPixels = std::getenv("FLOW2D_TILED_MAX_PIXELS")
-                                          ? static_cast<size_t>(std::atoll(std::getenv("FLOW2D_TILED_MAX_PIXELS")))
-                                          : static_cast<size_t>(896) * 896;
+// largest level (pixels) AUTO gives to the tiled kernel; FLOW2D_TILED_MAX_PIXELS overrides (developer knob).  Re-measured
+// against the round-3 strips (level solve 10 x 5, tiles / strips, ms): Grey 640^2 0.20 / 0.22, 768^2 0.26 / 0.23,
+// 896^2 0.34 / 0.32; Gradient 768^2 0.29 / 0.30, 896^2 0.39 / 0.40, 1024^2 0.40 / 0.45, 1920 x 1080 0.76 / 0.59.
+static size_t tiled_max_pixels(int data_constancy)
+{
+    static const long long forced = std::getenv("FLOW2D_TILED_MAX_PIXELS") ? std::atoll(std::getenv("FLOW2D_TILED_MAX_PIXELS")) : -1;
+    if (forced >= 0) return static_cast<size_t>(forced);
+    return data_constancy == FLOW2D_CONSTANCY_GREY ? static_cast<size_t>(704) * 704 : static_cast<size_t>(1100) * 1100;
+}
 
 extern "C" {
 
@@ -73,12 +78,12 @@ int flow2d_solver_algorithm_for(int requested, size_t width, size_t height, size
 {
     if (requested < FLOW2D_SOLVER_AUTO || requested > FLOW2D_SOLVER_TILED) return -1;
     if (requested == FLOW2D_SOLVER_AUTO) {
-        // Up to kTiledMaxPixels (896 x 896) the outer iteration runs on small LDS tiles (solve_tile.hip): a strip wave
+        // Up to tiled_max_pixels (704^2 Grey, 1100^2 for the gradient terms) the outer iteration runs on small LDS tiles (solve_tile.hip): a strip wave
         // needs (rows + halo) x ~1.1 us whatever the level size, tiles spread a small level over the whole chip
         // (level solve 10 x 5 at 256^2: 0.07 against 0.13 ms, at 512^2 0.12 against 0.20, at 800^2 0.27 against 0.29;
         // at 1024^2 the strips win for the gradient term).  That includes the coarsest levels: ten launches of a few
         // 8 x 8 tiles take 0.05 ms at 16 x 16 ... 64 x 32, the single-workgroup kernel 0.06 ... 0.11 ms.
-        if (inner >= 2 && width * height <= kTiledMaxPixels && flow2d::tiled_supports(data_constancy, inner))
+        if (inner >= 2 && width * height <= tiled_max_pixels(data_constancy) && flow2d::tiled_supports(data_constancy, inner))
             return FLOW2D_SOLVER_TILED;
         // Where the tiled kernel does not apply (solve_2d_log, a single sweep per outer iteration), levels up to 64 x 32
         // run whole in one launch on one CU (solve_small.hip; 0.06-0.10 ms against 0.16-0.19 ms for 60 per-sweep launches;

@@ -100,25 +100,9 @@ __device__ __forceinline__ float log1p_frame(float value) { return logf(value + 
 // ---- two-wide forms: the u and v equations share their weights, so the pair (u, v) goes through
 // v_pk_add_f32 / v_pk_mul_f32 (one VALU issue for both fields).  Component by component these are the
 // scalar expressions above, in the same order; nothing is contracted into an FMA.
-#ifdef FLOW2D_SCALAR_PAIRS
-// developer variant: the pair as two independent floats (no 64-bit register tuples, no packed instructions)
-struct v2f {
-    float x, y;
-};
-__device__ __forceinline__ v2f operator+(v2f a, v2f b) { return v2f{a.x + b.x, a.y + b.y}; }
-__device__ __forceinline__ v2f operator-(v2f a, v2f b) { return v2f{a.x - b.x, a.y - b.y}; }
-__device__ __forceinline__ v2f operator*(v2f a, v2f b) { return v2f{a.x * b.x, a.y * b.y}; }
-__device__ __forceinline__ v2f operator+(v2f a, float b) { return v2f{a.x + b, a.y + b}; }
-__device__ __forceinline__ v2f operator*(v2f a, float b) { return v2f{a.x * b, a.y * b}; }
-__device__ __forceinline__ v2f operator*(float a, v2f b) { return v2f{a * b.x, a * b.y}; }
-__device__ __forceinline__ v2f operator/(v2f a, float b) { return v2f{a.x / b, a.y / b}; }
-__device__ __forceinline__ v2f dup_x(v2f a) { return v2f{a.x, a.x}; }
-__device__ __forceinline__ v2f dup_y(v2f a) { return v2f{a.y, a.y}; }
-#else
 typedef float v2f __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ v2f dup_x(v2f a) { return a.xx; }
 __device__ __forceinline__ v2f dup_y(v2f a) { return a.yy; }
-#endif
 
 // (aP - aM + bP - bM) per component, solve_2d.cu:141-157
 __device__ __forceinline__ v2f diff4_num2(v2f aP, v2f aM, v2f bP, v2f bM) { return aP - aM + bP - bM; }
