@@ -733,12 +733,6 @@ FusedPlan fused_plan(const flow2d_context* ctx, size_t w, size_t h, size_t inner
     return plan;
 }
 
-// (kept for callers that want one number: the uniform strip height, or the interior height of a border-aware plan)
-int fused_rows_per_strip(const flow2d_context* ctx, size_t w, size_t h, size_t inner)
-{
-    return fused_plan(ctx, w, h, inner).rows_interior;
-}
-
 // One outer iteration: reads du/dv (previous outer iteration), writes out_du/out_dv (after `inner` sweeps).
 int launch_fused_outer(flow2d_context* ctx, int constancy, const float* f0, const float* f1, const float* u,
                        const float* v, const float* du, const float* dv, size_t w, size_t h, size_t pitch_bytes,
