@@ -12,7 +12,7 @@ S=$T/solve_fused-hip-amdgcn-amd-amdhsa-gfx950.s
 for k in 0 1; do
     echo "== fused_outer_kernel<5, $k, true, false>: blocks inside loops"
     awk -v pat="fused_outer_kernelILi5ELi${k}ELb1ELb0" '$0 ~ "^_ZN.*"pat {p=1} p&&/^\.Lfunc_end/{exit} p' "$S" |
-    awk '/^\.LBB/{lbl=$1; inloop[lbl]=($0 ~ /in Loop|Loop Header/)} /scratch_/{c[lbl]++} /v_div_scale/{d[lbl]++} /ds_read|ds_write/{l[lbl]++} /^\tv_/{v[lbl]++} {n[lbl]++}
+    awk '/^\.LBB|^; %bb\./{lbl=($1==";" ? $2 : $1); getline nxt; inloop[lbl]=(($0 nxt) ~ /in Loop|Loop Header/); $0=nxt} /scratch_/{c[lbl]++} /v_div_scale/{d[lbl]++} /ds_read|ds_write/{l[lbl]++} /^\tv_/{v[lbl]++} {n[lbl]++}
          END{for(k in n) if (inloop[k] && n[k] > 100) printf "%-10s instr %4d valu %4d scratch %2d lds %2d div_scale %2d\n", k, n[k], v[k], c[k]+0, l[k]+0, d[k]+0}' | sort -t_ -k2 -n
 done
 echo "ISA kept in $S"
