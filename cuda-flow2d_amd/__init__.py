@@ -117,6 +117,7 @@ def hip_lib():
         L.flow2d_median_2d_pair.argtypes = [vp, vp, vp, sz, sz, sz, sz, vp, vp]
         L.flow2d_resample_x_pair.argtypes = [vp, vp, vp, vp, vp, sz, sz, sz, sz]
         L.flow2d_resample_y_pair.argtypes = [vp, vp, vp, vp, vp, sz, sz, sz, sz]
+        L.flow2d_resample_xy_pair.argtypes = [vp, vp, vp, vp, vp, sz, sz, sz, sz, sz]
         L.flow2d_resample_x_levels.argtypes = [vp, vp, vp, vp, vp, sz, sz, sz, sz, C.POINTER(sz), C.POINTER(sz)]
         L.flow2d_compute_phi_ksi.argtypes = [vp] * 7 + [sz, sz, sz, f, f, f, f, vp, vp]
         L.flow2d_solve_2d.argtypes = [vp] * 9 + [sz, sz, sz, f, f, f, vp, vp]
@@ -309,6 +310,12 @@ class Context:
     def resample_y(self, src, dst, out_w, out_h, in_h):
         _check(hip_lib().flow2d_resample_y(self.handle, src.ptr, dst.ptr, out_w, out_h, in_h, src.pitch),
                "flow2d_resample_y")
+
+    def resample_xy(self, src, dst, in_w, in_h, out_w, out_h, src_b=None, dst_b=None):
+        """Both resample passes in one launch (no temp plane); optional second plane."""
+        _check(hip_lib().flow2d_resample_xy_pair(self.handle, src.ptr, dst.ptr, src_b.ptr if src_b else None,
+                                                 dst_b.ptr if dst_b else None, in_w, in_h, out_w, out_h, src.pitch),
+               "flow2d_resample_xy_pair")
 
     def resample_x_levels(self, src, packed, in_w, h, widths, columns, src_b=None, packed_b=None):
         """x pass for several output widths in one trip over `src`; level l lands in columns[l] .. of `packed`."""

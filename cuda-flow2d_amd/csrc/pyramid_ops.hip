@@ -275,6 +275,61 @@ __global__ __launch_bounds__(256) void resample_kernel(const float* __restrict__
     out[static_cast<size_t>(y) * pitch + x] = value * normalization;
 }
 
+// Both passes in one launch, for up-sampling (the flow of the previous pyramid level, optical_flow_2d.cpp:320-345): every
+// output evaluates the x pass for the one or two input rows of its y cells -- the same left-to-right cell sum, the same
+// normalisation, rounded to float like the temp plane the reference stores it in -- and then the y pass over those
+// values.  Same operations in the same order as resample_kernel<true> into a temp followed by resample_kernel<false>,
+// hence the same bits; the temp plane (as large as the output in x) is neither written nor read: 160 instead of 288 MB
+// for the two flow planes at 2048^2 -> 4096^2.
+__device__ __forceinline__ float resample_cells(const float* __restrict__ base, size_t stride, int in_n, int out_n, unsigned g)
+{
+    const float delta = static_cast<float>(in_n) / static_cast<float>(out_n);
+    const float normalization = static_cast<float>(out_n) / static_cast<float>(in_n);
+    const float left_f = static_cast<float>(g) * delta;
+    const float right_f = static_cast<float>(g + 1u) * delta;
+    const int left_i = static_cast<int>(floorf(left_f));
+    const int right_i = min(in_n, static_cast<int>(ceilf(right_f)));
+    const int cells = right_i - left_i;
+    float value = 0.f;
+    for (int j = 0; j < cells; ++j) {
+        float frac = 1.f;
+        if (j == 0) frac = static_cast<float>(left_i + 1) - left_f;
+        if (j == cells - 1) frac = right_f - static_cast<float>(left_i + j);
+        if (cells == 1) frac = delta;
+        value += base[static_cast<size_t>(left_i + j) * stride] * frac;
+    }
+    return value * normalization;
+}
+
+__global__ __launch_bounds__(256) void resample_xy_kernel(const float* __restrict__ in_a, float* __restrict__ out_a,
+                                                          const float* __restrict__ in_b, float* __restrict__ out_b,
+                                                          int out_w, int out_h, int in_w, int in_h, int pitch, BatchArg batch)
+{
+    const float* __restrict__ in = (batch_plane(batch) ? in_b : in_a) + batch_offset(batch);
+    float* __restrict__ out = (batch_plane(batch) ? out_b : out_a) + batch_offset(batch);
+    const int x = blockIdx.x * kBlockX + threadIdx.x;
+    const int y = blockIdx.y * kBlockY + threadIdx.y;
+    if (x >= out_w || y >= out_h) return;
+    // the y pass of resample_2d.cu:77-118 over x-pass values computed on the spot
+    const float delta = static_cast<float>(in_h) / static_cast<float>(out_h);
+    const float normalization = static_cast<float>(out_h) / static_cast<float>(in_h);
+    const float top_f = static_cast<float>(static_cast<unsigned>(y)) * delta;
+    const float bottom_f = static_cast<float>(static_cast<unsigned>(y) + 1u) * delta;
+    const int top_i = static_cast<int>(floorf(top_f));
+    const int bottom_i = min(in_h, static_cast<int>(ceilf(bottom_f)));
+    const int cells = bottom_i - top_i;
+    float value = 0.f;
+    for (int j = 0; j < cells; ++j) {
+        float frac = 1.f;
+        if (j == 0) frac = static_cast<float>(top_i + 1) - top_f;
+        if (j == cells - 1) frac = bottom_f - static_cast<float>(top_i + j);
+        if (cells == 1) frac = delta;
+        const float x_pass = resample_cells(in + static_cast<size_t>(top_i + j) * pitch, 1, in_w, out_w, static_cast<unsigned>(x));
+        value += x_pass * frac;
+    }
+    out[static_cast<size_t>(y) * pitch + x] = value * normalization;
+}
+
 // Down-sampling along x with a large ratio (the frames are resampled from FULL resolution at every level,
 // optical_flow_2d.cpp:284-303): with one output per lane the lanes of a wave read 64 different cache
 // lines per load.  Here each wave (one image row, 64 outputs) stages the contiguous input span of its
@@ -730,6 +785,29 @@ int flow2d_resample_y_pair(flow2d_context* ctx, const float* input_a, float* out
     if (!input_b || !output_b) return FLOW2D_ERR_INVALID_ARGUMENT;
     return launch_resample(ctx, false, input_a, output_a, input_b, output_b, out_width, out_height, in_height,
                            pitch_bytes);
+}
+
+int flow2d_resample_xy_pair(flow2d_context* ctx, const float* input_a, float* output_a, const float* input_b,
+                            float* output_b, size_t in_width, size_t in_height, size_t out_width, size_t out_height,
+                            size_t pitch_bytes)
+{
+    FLOW2D_ENTER(ctx);
+    if (!flow2d::plane_args_ok(input_a, in_width, in_height, pitch_bytes) ||
+        !flow2d::plane_args_ok(output_a, out_width, out_height, pitch_bytes) || input_a == output_a)
+        return FLOW2D_ERR_INVALID_ARGUMENT;
+    const bool pair = input_b || output_b;
+    if (pair && (!flow2d::plane_args_ok(input_b, in_width, in_height, pitch_bytes) ||
+                 !flow2d::plane_args_ok(output_b, out_width, out_height, pitch_bytes) || input_b == output_b ||
+                 output_b == output_a || output_b == input_a || output_a == input_b))
+        return FLOW2D_ERR_INVALID_ARGUMENT;
+    const unsigned planes = pair ? 2 : 1;
+    dim3 grid = grid_for(out_width, out_height);
+    grid.z = flow2d::batch_z(ctx, planes);
+    resample_xy_kernel<<<grid, dim3(kBlockX, kBlockY), 0, ctx->stream>>>(
+        input_a, output_a, input_b, output_b, (int)out_width, (int)out_height, (int)in_width, (int)in_height,
+        (int)(pitch_bytes / 4), flow2d::batch_arg(ctx, planes));
+    FLOW2D_CHECK_LAUNCH();
+    return FLOW2D_OK;
 }
 
 int flow2d_registration_2d(flow2d_context* ctx, const float* frame_0, const float* frame_1, const float* flow_u,

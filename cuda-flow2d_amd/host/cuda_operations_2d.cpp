@@ -179,8 +179,17 @@ void CudaOperationResample2D::Execute(OperationParameters& params)
     }
     // optional second plane set (not in the reference's bag): two planes of the same geometry per launch
     DevicePtr dev_input_b = 0, dev_output_b = 0, dev_temp_b = 0;
-    if (params.Read<DevicePtr>("dev_input_b", dev_input_b) && params.Read<DevicePtr>("dev_output_b", dev_output_b) &&
-        params.Read<DevicePtr>("dev_temp_b", dev_temp_b)) {
+    const bool pair = params.Read<DevicePtr>("dev_input_b", dev_input_b) && params.Read<DevicePtr>("dev_output_b", dev_output_b) &&
+                      params.Read<DevicePtr>("dev_temp_b", dev_temp_b);
+    // up-sampling in both directions (the flow of the previous level): both passes in one launch, the temp plane unused
+    if (resample_size.width >= data_size.width && resample_size.height >= data_size.height) {
+        Failed(flow2d_resample_xy_pair(context_, AsPlane(dev_input), AsPlane(dev_output), pair ? AsPlane(dev_input_b) : nullptr,
+                                       pair ? AsPlane(dev_output_b) : nullptr, data_size.width, data_size.height,
+                                       resample_size.width, resample_size.height, dev_container_size_.pitch),
+               "flow2d_resample_xy_pair");
+        return;
+    }
+    if (pair) {
         if (Failed(flow2d_resample_x_pair(context_, AsPlane(dev_input), AsPlane(dev_temp), AsPlane(dev_input_b),
                                           AsPlane(dev_temp_b), resample_size.width, data_size.height, data_size.width,
                                           dev_container_size_.pitch),

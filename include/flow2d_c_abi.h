@@ -213,6 +213,15 @@ FLOW2D_API int flow2d_resample_y_pair(flow2d_context* ctx, const float* input_a,
                                       const float* input_b, float* output_b, size_t out_width, size_t out_height,
                                       size_t in_height, size_t pitch_bytes);
 
+/* resample_x into a temp plane followed by resample_y (CudaOperationResample2D::Execute,
+ * src/cuda_operations/2d/cuda_operation_resample_2d.cpp:99-152) as ONE launch without the temp plane: every output evaluates
+ * the x pass for the input rows of its y cells (same cell sums, rounded to float like the temp) and then the y pass.
+ * Bit-identical to the two calls; meant for up-sampling (the flow of the previous pyramid level: one or two cells per
+ * direction), correct for any ratio.  input_b / output_b: optional second plane (both or neither). */
+FLOW2D_API int flow2d_resample_xy_pair(flow2d_context* ctx, const float* input_a, float* output_a, const float* input_b,
+                                       float* output_b, size_t in_width, size_t in_height, size_t out_width,
+                                       size_t out_height, size_t pitch_bytes);
+
 /* The x pass of resample_2d.cu:34-75 for SEVERAL output widths in one trip over the input.  The reference resamples
  * both frames from full resolution at every pyramid level (optical_flow_2d.cpp:284-303), i.e. reads each frame once per
  * level; here every input row is read once, kept in LDS, and the x-resampled rows of all `level_count` widths are written

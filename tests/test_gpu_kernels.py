@@ -70,6 +70,32 @@ def test_resample(ctx, oracle, w, h, ow, oh):
     assert np.array_equal(dst.download(ow, oh), want)
 
 
+@pytest.mark.parametrize("w,h,ow,oh", [(37, 20, 100, 70), (33, 17, 34, 18), (50, 35, 100, 70), (64, 64, 64, 64), (2, 3, 257, 130),
+                                       (512, 270, 1024, 540), (231, 130, 461, 260), (100, 70, 37, 20), (300, 40, 150, 80),
+                                       (1000, 37, 77, 90)])
+def test_resample_xy(ctx, oracle, w, h, ow, oh):
+    """Both passes in one launch (no temp plane): the bits of the x pass into a temp followed by the y pass, for one plane
+    and for two, up-sampling (what the operator routes here) and any other ratio."""
+    cw, ch = max(w, ow) + 3, max(h, oh) + 2
+    f0, f1, *_ = level_fields(oracle, w, h, 3)
+    a, b = up(ctx, f0, cw, ch), up(ctx, f1, cw, ch)
+    da, db = ctx.plane(cw, ch).fill_bytes(0x7f), ctx.plane(cw, ch).fill_bytes(0x7f)
+    ctx.resample_xy(a, da, w, h, ow, oh, b, db)
+    want_a = oracle.resample(in_container(f0, cw, ch), w, h, ow, oh)[:oh, :ow]
+    want_b = oracle.resample(in_container(f1, cw, ch), w, h, ow, oh)[:oh, :ow]
+    assert np.array_equal(da.download(ow, oh), want_a)
+    assert np.array_equal(db.download(ow, oh), want_b)
+    got = da.download()
+    assert np.all(got[oh:, :].view(np.uint32) == 0x7f7f7f7f) and np.all(got[:, ow:].view(np.uint32) == 0x7f7f7f7f)
+    single = ctx.plane(cw, ch).fill_bytes(0x7f)
+    ctx.resample_xy(a, single, w, h, ow, oh)
+    assert np.array_equal(single.download(ow, oh), want_a)
+    tmp, two = ctx.plane(cw, ch), ctx.plane(cw, ch)
+    ctx.resample_x(a, tmp, ow, h, w)
+    ctx.resample_y(tmp, two, ow, oh, h)
+    assert np.array_equal(two.download(ow, oh), want_a)
+
+
 @pytest.mark.parametrize("w,h,scale,levels", [(8192, 5, 0.5, 11), (4096, 24, 0.5, 7), (1920, 17, 0.5, 7), (1000, 33, 0.45, 5), (257, 40, 0.3, 3),
                                               (640, 12, 0.5, 2), (100, 70, 0.33, 3)])
 def test_resample_x_levels(ctx, flow2d, oracle, w, h, scale, levels):
