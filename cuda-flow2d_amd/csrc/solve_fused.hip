@@ -128,6 +128,30 @@ __device__ __forceinline__ float div3(float n, float d, float y)
     return __builtin_fmaf(r, y, q0);
 }
 
+// 1.0f / d in three instructions: the hardware approximation and one fma pair.  RN(1 / d) for EVERY normal d whose
+// reciprocal is normal -- all 2 113 929 217 bit patterns of [2^-126, 2^126] tried on the device
+// (tools/ubench/rcp_sqrt_exhaustive.hip; the compiler's correctly rounded division is eleven, five of them quarter-rate).
+__device__ __forceinline__ float rcp3(float d)
+{
+    const float y0 = __builtin_amdgcn_rcpf(d);
+    const float e = __builtin_fmaf(-d, y0, 1.0f);
+    return __builtin_fmaf(e, y0, y0);
+}
+
+// 1.f / (2.f * sqrtf(s)) in nine instructions instead of 28: the hardware root corrected by its residual times half the
+// hardware reciprocal root is RN(sqrt(s)), and rcp3 of twice that (exact) is the quotient -- for every s whose
+// 2 sqrt(s) lies within the guarded denominator range (every bit pattern tried, same ubench).  twice_root goes to the
+// guard: a zero, an infinity, a NaN or a negative argument leave a NaN or an out-of-range value there.
+__device__ __forceinline__ float half_inverse_root(float s, float& twice_root)
+{
+    const float g0 = __builtin_amdgcn_sqrtf(s);
+    const float h = 0.5f * __builtin_amdgcn_rsqf(s);
+    const float r = __builtin_fmaf(-g0, g0, s);
+    const float g = __builtin_fmaf(r, h, g0);
+    twice_root = 2.f * g;
+    return rcp3(twice_root);
+}
+
 // What the proof does not cover is recorded per lane in three unsigned accumulators -- integer min / max on the operands'
 // bit patterns, vector ALU only (a comparison per division would go through the scalar unit: measured, it costs more than
 // the divisions it guards) -- and judged once, after the strip:
@@ -285,7 +309,9 @@ __device__ __forceinline__ void strip_step(Strip<INNER, GRAD>& s, const FusedArg
             dx = v2f{xnum.x / a.two_hx, xnum.y / a.two_hx};
             dy = v2f{ynum.x / a.two_hy, ynum.y / a.two_hy};
         }
-        s.phiw[s1] = phi_value(dx.x, dy.x, dx.y, dy.y, a.e_smooth);
+        float t_phi = 1.f, t_ksi = 1.f;  // 2 sqrt(.) of the two robustifiers, for the guard
+        if (FAST) s.phiw[s1] = half_inverse_root(phi_argument(dx.x, dy.x, dx.y, dy.y, a.e_smooth), t_phi);
+        else s.phiw[s1] = phi_value(dx.x, dy.x, dx.y, dy.y, a.e_smooth);
 
         const float f0c = s.f0w[s1], f1c = s.f1w[s1];
         const float f0l0 = from_left(f0c), f0r0 = from_right(f0c), f1l0 = from_left(f1c), f1r0 = from_right(f1c);
@@ -296,7 +322,12 @@ __device__ __forceinline__ void strip_step(Strip<INNER, GRAD>& s, const FusedArg
         fx = diff4s<POW2>(f0R, f0L, f1R, f1L, a.four_hx, a.inv_four_hx);
         fy = diff4s<POW2>(f0D, f0U, f1D, f1U, a.four_hy, a.inv_four_hy);
         ft = f1c - f0c;
-        ksi = ksi_value(fx, fy, ft, s.duvw[s1].x, s.duvw[s1].y, a.e_data);
+        if (FAST) {
+            ksi = half_inverse_root(ksi_argument(fx, fy, ft, s.duvw[s1].x, s.duvw[s1].y, a.e_data), t_ksi);
+            guard_denominators(s.guard, t_phi, t_ksi);
+        } else {
+            ksi = ksi_value(fx, fy, ft, s.duvw[s1].x, s.duvw[s1].y, a.e_data);
+        }
         if (GRAD == 3) {
             // first derivatives of log(I + 1) with the block rule of solve_2d_log (:519-535 over the halo of :446-503)
             const bool x_lo = (x & 15) == 0, x_hi = (x & 15) == 15, y_lo = (rp & 7) == 0, y_hi = (rp & 7) == 7;
@@ -391,7 +422,7 @@ __device__ __forceinline__ void strip_step(Strip<INNER, GRAD>& s, const FusedArg
         const v2f c_den = c_ksi * J11_22 + sumH;  // update_denominator for u and v
         v2f c_rden = v2f{0.f, 0.f};
         if (FAST) {
-            c_rden = v2f{1.0f / c_den.x, 1.0f / c_den.y};
+            c_rden = v2f{rcp3(c_den.x), rcp3(c_den.y)};
             guard_denominators(s.guard, c_den.x, c_den.y);
         }
         c.den = c_den;

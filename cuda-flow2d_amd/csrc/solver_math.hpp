@@ -15,19 +15,27 @@ __device__ __forceinline__ float diff4(float aP, float aM, float bP, float bM, f
     return (aP - aM + bP - bM) / den;
 }
 
-// smoothness diffusivity, solve_2d.cu:161-162
+// smoothness diffusivity, solve_2d.cu:161-162: phi = 1 / (2 sqrt(argument))
+__device__ __forceinline__ float phi_argument(float dux, float duy, float dvx, float dvy, float e_smooth)
+{
+    return dux * dux + duy * duy + dvx * dvx + dvy * dvy + e_smooth * e_smooth;
+}
 __device__ __forceinline__ float phi_value(float dux, float duy, float dvx, float dvy, float e_smooth)
 {
-    return 1.f / (2.f * sqrtf(dux * dux + duy * duy + dvx * dvx + dvy * dvy + e_smooth * e_smooth));
+    return 1.f / (2.f * sqrtf(phi_argument(dux, duy, dvx, dvy, e_smooth)));
 }
 
-// data-term robustifier from the brightness tensor, solve_2d.cu:176-196
-__device__ __forceinline__ float ksi_value(float fx, float fy, float ft, float du, float dv, float e_data)
+// data-term robustifier from the brightness tensor, solve_2d.cu:176-196: ksi = 1 / (2 sqrt(argument))
+__device__ __forceinline__ float ksi_argument(float fx, float fy, float ft, float du, float dv, float e_data)
 {
     const float J11 = fx * fx, J22 = fy * fy, J33 = ft * ft, J12 = fx * fy, J13 = fx * ft, J23 = fy * ft;
     float s = (J11 * du + J12 * dv + J13) * du + (J12 * du + J22 * dv + J23) * dv + (J13 * du + J23 * dv + J33);
     s = static_cast<float>(s > 0) * s;
-    return 1.f / (2.f * sqrtf(s + e_data * e_data));
+    return s + e_data * e_data;
+}
+__device__ __forceinline__ float ksi_value(float fx, float fy, float ft, float du, float dv, float e_data)
+{
+    return 1.f / (2.f * sqrtf(ksi_argument(fx, fy, ft, du, dv, e_data)));
 }
 
 // face diffusivity, solve_2d.cu:343-346

@@ -1,4 +1,6 @@
-"""The fused strip kernel's two round-3 mechanisms against the oracle, bit for bit:
+"""The fused strip kernel's round-3 mechanisms against the oracle, bit for bit:
+  * the short reciprocal (v_rcp + one fma pair) and the short 1 / (2 sqrt(s)) of the coefficient stage, whose arguments
+    the same guard watches (2 sqrt(s) and the denominators within [2^-30, 2^40]);
   * the three-step division (y = RN(1/den) once per pixel, q0 = n y, r = fma(-q0, den, n), q = fma(r, y, q0)) with its
     run-time guard and the repeat-with-plain-division fallback, on operands chosen to trip every guard;
   * the border-aware strip plan (shorter strips on the image borders, one-dimensional grid over the working blocks) on
@@ -15,12 +17,13 @@ def up(ctx, a, cw, ch):
     return ctx.plane(cw, ch, in_container(a, cw, ch))
 
 
-def fused_vs_oracle(ctx, oracle, f0, f1, u, v, w, h, cw, ch, hx, hy, alpha, outer, inner, constancy, algorithm=2):
+def fused_vs_oracle(ctx, oracle, f0, f1, u, v, w, h, cw, ch, hx, hy, alpha, outer, inner, constancy, algorithm=2,
+                    e_smooth=0.001, e_data=0.001):
     d = [up(ctx, a, cw, ch) for a in (f0, f1, u, v)]
     du, dv, phi, ksi, tdu, tdv = (ctx.plane(cw, ch).fill_bytes(0x7f) for _ in range(6))
-    rdu, rdv = ctx.solve_level(*d, du, dv, phi, ksi, tdu, tdv, w, h, hx, hy, alpha, 0.001, 0.001, outer, inner, constancy,
+    rdu, rdv = ctx.solve_level(*d, du, dv, phi, ksi, tdu, tdv, w, h, hx, hy, alpha, e_smooth, e_data, outer, inner, constancy,
                                algorithm)
-    odu, odv, _, _ = oracle.solve_level(f0, f1, u, v, w, h, hx, hy, alpha, 0.001, 0.001, outer, inner, constancy)
+    odu, odv, _, _ = oracle.solve_level(f0, f1, u, v, w, h, hx, hy, alpha, e_smooth, e_data, outer, inner, constancy)
     return rdu.download(w, h), rdv.download(w, h), odu, odv
 
 
@@ -141,4 +144,59 @@ def test_negative_zero_in_the_flow_falls_back(ctx, oracle):
     before = ctx.fused_fallbacks()
     a, b, odu, odv = fused_vs_oracle(ctx, oracle, f0, f1, u, v, w, h, w, h, np.float32(1.0), np.float32(1.0), 35.0, 2, 5, 0)
     assert np.array_equal(bits(a), bits(odu)) and np.array_equal(bits(b), bits(odv))
+    assert ctx.fused_fallbacks() > before
+
+
+@pytest.mark.parametrize("constancy", [0, 1])
+@pytest.mark.parametrize("e_smooth,e_data,scale,trips", [
+    (1e-8, 1e-8, 1.0, False),     # 2 sqrt(s) down to 2e-8 = 2^-25.6: still inside the range
+    (1e-20, 0.001, 1.0, True),    # e_smooth^2 = 1e-40 is a denormal: s of a flat flow region is, too
+    (0.001, 1e-20, 1.0, True),    # the same for the data term where the frames agree
+    (0.001, 0.001, 1e16, True),   # frames of magnitude 1e18: the data term's argument is far above 2^78
+])
+def test_robustifier_arguments_outside_the_proven_range_fall_back(ctx, oracle, constancy, e_smooth, e_data, scale, trips):
+    """phi and ksi are 1 / (2 sqrt(s)) through the hardware root and reciprocal plus residual steps, proven for every s
+    with 2 sqrt(s) in [2^-30, 2^40] (tools/ubench/rcp_sqrt_exhaustive.hip).  Regularisers so small that s is a denormal
+    on flat regions, or frames so large that s overflows the range, trip the guard; either way every bit is the oracle's."""
+    w, h = 640, 200
+    f0, f1, u, v, _, _ = level_fields(oracle, w, h, 41)
+    f0, f1 = (f0 * np.float32(scale)).astype(np.float32), (f1 * np.float32(scale)).astype(np.float32)
+    u, v = u.copy(), v.copy()
+    u[40:120, 100:500] = 0.25  # a flat flow region: the smoothness argument is e_smooth^2 there
+    v[40:120, 100:500] = -0.5
+    f1[60:100, 200:400] = f0[60:100, 200:400]  # frames agree, no gradient mismatch: ft = 0
+    before = ctx.fused_fallbacks()
+    a, b, odu, odv = fused_vs_oracle(ctx, oracle, f0, f1, u, v, w, h, w, h, np.float32(1.0), np.float32(1.0), 35.0, 2, 5,
+                                     constancy, e_smooth=e_smooth, e_data=e_data)
+    same = np.array_equal(np.isnan(a), np.isnan(odu)) and np.array_equal(np.isnan(b), np.isnan(odv))
+    fin_a, fin_b = ~np.isnan(odu), ~np.isnan(odv)
+    assert same and np.array_equal(bits(a[fin_a]), bits(odu[fin_a])) and np.array_equal(bits(b[fin_b]), bits(odv[fin_b]))
+    if trips:
+        assert ctx.fused_fallbacks() > before
+
+
+def test_zero_regularisers_match_the_per_sweep_kernels(ctx, flow2d, oracle):
+    """e_smooth = e_data = 0 on a flat flow over agreeing frames: both arguments are exactly 0, the reference's phi and
+    ksi are infinite and the sweeps produce NaNs.  The short forms give NaN for a zero argument, which trips the guard;
+    the repeat with the plain expressions delivers what the per-sweep kernels deliver."""
+    w, h = 640, 200
+    f0, f1, u, v, _, _ = level_fields(oracle, w, h, 43)
+    u, v = u.copy(), v.copy()
+    u[40:120, 100:500] = 0.25
+    v[40:120, 100:500] = -0.5
+    f1 = f1.copy()
+    f1[60:100, 200:400] = f0[60:100, 200:400]
+    d = [up(ctx, a, w, h) for a in (f0, f1, u, v)]
+    res = []
+    before = ctx.fused_fallbacks()
+    for algorithm in (flow2d.SOLVER_FUSED, flow2d.SOLVER_PER_SWEEP):
+        du, dv, phi, ksi, tdu, tdv = (ctx.plane(w, h).fill_bytes(0) for _ in range(6))
+        rdu, rdv = ctx.solve_level(*d, du, dv, phi, ksi, tdu, tdv, w, h, 1.0, 1.0, 35.0, 0.0, 0.0, 2, 5, 0, algorithm)
+        res.append((rdu.download(w, h), rdv.download(w, h)))
+    assert not np.isfinite(res[1][0]).all()
+    for k in range(2):
+        x, y = res[0][k], res[1][k]
+        assert np.array_equal(np.isnan(x), np.isnan(y)) and np.array_equal(np.isinf(x), np.isinf(y))
+        fin = np.isfinite(y)
+        assert np.array_equal(bits(x[fin]), bits(y[fin]))
     assert ctx.fused_fallbacks() > before
