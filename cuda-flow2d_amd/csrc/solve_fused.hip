@@ -80,6 +80,7 @@ struct FusedArgs {
     float inv_two_hx, inv_two_hy, inv_four_hx, inv_four_hy;  // their reciprocals (exact when h is a power of two)
     float hx_1, hy_1;                                // float(1.0 / (2.0 * h)), solve_2d.cu:868-869
     float hx_2, hy_2;                                // alpha / (h * h), solve_2d.cu:337-340
+    int blocks, blocks_per_xcd;       // working blocks of the plan; ceil(blocks / 8), or 0 for the plain block order
     unsigned long long batch_stride;  // floats between the instances of a batched launch (blockIdx.z)
     unsigned int* fallback_count;     // waves that repeated their strip with the plain division (diagnostics; may be null)
 };
@@ -196,6 +197,33 @@ __device__ __forceinline__ bool guard_tripped(const DivGuard& g)
     return g.tiny < kTinyLimit || g.den > kDenSpan || g.out > kOutLimit;
 }
 
+// (w.x * d.x, w.x * d.y) and (w.y * d.x, w.y * d.y): v_pk_mul_f32 reading ONE half of w for both products (op_sel).  The
+// compiler builds dup_x(w) * d from a register pair it first assembles with moves -- five v_mov_b32 per sweep for the four
+// face weights, in every sweep anew; the products are the same.
+__device__ __forceinline__ v2f mul_by_x(v2f w, v2f d)
+{
+    v2f r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]" : "=v"(r) : "v"(w), "v"(d));
+    return r;
+}
+__device__ __forceinline__ v2f mul_by_y(v2f w, v2f d)
+{
+    v2f r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,0]" : "=v"(r) : "v"(w), "v"(d));
+    return r;
+}
+// keeps the vectoriser from pairing two scalar operations into a packed one (an empty statement: no instruction)
+__device__ __forceinline__ float scalar_only(float v)
+{
+    asm("" : "+v"(v));
+    return v;
+}
+// sum_flux2 (solver_math.hpp) over the four neighbour differences, same order of additions
+__device__ __forceinline__ v2f flux_of_differences(v2f wx, v2f wy, v2f dR, v2f dL, v2f dD, v2f dU)
+{
+    return mul_by_x(wx, dR) + mul_by_y(wx, dL) + mul_by_x(wy, dD) + mul_by_y(wy, dU);
+}
+
 __device__ __forceinline__ v2f from_left2(v2f v) { return v2f{from_left(v.x), from_left(v.y)}; }
 __device__ __forceinline__ v2f from_right2(v2f v) { return v2f{from_right(v.x), from_right(v.y)}; }
 __device__ __forceinline__ v2f pick2(bool c, v2f a, v2f b) { return v2f{c ? a.x : b.x, c ? a.y : b.y}; }
@@ -292,15 +320,25 @@ __device__ __forceinline__ void strip_step(Strip<INNER, GRAD>& s, const FusedArg
     float fx = 0.f, fy = 0.f, ft = 0.f, ksi = 0.f;
     if (run_P) {
         const bool top = EDGE && (rp == 0), bot = EDGE && (rp == h - 1);
-        // cross-lane reads happen with every lane active; the border substitution is a select afterwards
-        const v2f uv_l0 = from_left2(s.uvw[s1]), uv_r0 = from_right2(s.uvw[s1]);
-        const v2f duv_l0 = from_left2(s.duvw[s1]), duv_r0 = from_right2(s.duvw[s1]);
-        const v2f uvL = pick2(at_l, uv_r0, uv_l0), uvR = pick2(at_r, uv_l0, uv_r0);
-        const v2f duvL = pick2(at_l, duv_r0, duv_l0), duvR = pick2(at_r, duv_l0, duv_r0);
-        const v2f uvU = pick2(top, s.uvw[s0], s.uvw[s2]), uvD = pick2(bot, s.uvw[s2], s.uvw[s0]);
-        const v2f duvU = pick2(top, s.duvw[s0], s.duvw[s2]), duvD = pick2(bot, s.duvw[s2], s.duvw[s0]);
-        const v2f xnum = diff4_num2(uvR, uvL, duvR, duvL);  // numerators of (dux, dvx)
-        const v2f ynum = diff4_num2(uvD, uvU, duvD, duvU);  // numerators of (duy, dvy)
+        v2f xnum, ynum;  // numerators of (dux, dvx) and (duy, dvy): aP - aM + bP - bM, solve_2d.cu:141-157
+        if (!EDGE) {
+            // no border in this strip: the lane shifts ride as DPP operands of scalar subtractions / additions (three of
+            // the four x neighbours of a component; a packed operation needs all of them moved into registers first)
+            const v2f uvc = s.uvw[s1], duvc = s.duvw[s1];
+            xnum = v2f{scalar_only(scalar_only(scalar_only(from_right(uvc.x) - from_left(uvc.x)) + from_right(duvc.x)) - from_left(duvc.x)),
+                       scalar_only(scalar_only(scalar_only(from_right(uvc.y) - from_left(uvc.y)) + from_right(duvc.y)) - from_left(duvc.y))};
+            ynum = diff4_num2(s.uvw[s0], s.uvw[s2], s.duvw[s0], s.duvw[s2]);
+        } else {
+            // cross-lane reads happen with every lane active; the border substitution is a select afterwards
+            const v2f uv_l0 = from_left2(s.uvw[s1]), uv_r0 = from_right2(s.uvw[s1]);
+            const v2f duv_l0 = from_left2(s.duvw[s1]), duv_r0 = from_right2(s.duvw[s1]);
+            const v2f uvL = pick2(at_l, uv_r0, uv_l0), uvR = pick2(at_r, uv_l0, uv_r0);
+            const v2f duvL = pick2(at_l, duv_r0, duv_l0), duvR = pick2(at_r, duv_l0, duv_r0);
+            const v2f uvU = pick2(top, s.uvw[s0], s.uvw[s2]), uvD = pick2(bot, s.uvw[s2], s.uvw[s0]);
+            const v2f duvU = pick2(top, s.duvw[s0], s.duvw[s2]), duvD = pick2(bot, s.duvw[s2], s.duvw[s0]);
+            xnum = diff4_num2(uvR, uvL, duvR, duvL);
+            ynum = diff4_num2(uvD, uvU, duvD, duvU);
+        }
         v2f dx, dy;
         if (POW2) {
             dx = xnum * a.inv_two_hx;
@@ -314,12 +352,17 @@ __device__ __forceinline__ void strip_step(Strip<INNER, GRAD>& s, const FusedArg
         else s.phiw[s1] = phi_value(dx.x, dy.x, dx.y, dy.y, a.e_smooth);
 
         const float f0c = s.f0w[s1], f1c = s.f1w[s1];
-        const float f0l0 = from_left(f0c), f0r0 = from_right(f0c), f1l0 = from_left(f1c), f1r0 = from_right(f1c);
-        const float f0L = at_l ? f0r0 : f0l0, f0R = at_r ? f0l0 : f0r0;
-        const float f1L = at_l ? f1r0 : f1l0, f1R = at_r ? f1l0 : f1r0;
+        if (!EDGE) {
+            const float fx_num = scalar_only(scalar_only(scalar_only(from_right(f0c) - from_left(f0c)) + from_right(f1c)) - from_left(f1c));
+            fx = div_spacing<POW2>(fx_num, a.four_hx, a.inv_four_hx);
+        } else {
+            const float f0l0 = from_left(f0c), f0r0 = from_right(f0c), f1l0 = from_left(f1c), f1r0 = from_right(f1c);
+            const float f0L = at_l ? f0r0 : f0l0, f0R = at_r ? f0l0 : f0r0;
+            const float f1L = at_l ? f1r0 : f1l0, f1R = at_r ? f1l0 : f1r0;
+            fx = diff4s<POW2>(f0R, f0L, f1R, f1L, a.four_hx, a.inv_four_hx);
+        }
         const float f0U = top ? s.f0w[s0] : s.f0w[s2], f0D = bot ? s.f0w[s2] : s.f0w[s0];
         const float f1U = top ? s.f1w[s0] : s.f1w[s2], f1D = bot ? s.f1w[s2] : s.f1w[s0];
-        fx = diff4s<POW2>(f0R, f0L, f1R, f1L, a.four_hx, a.inv_four_hx);
         fy = diff4s<POW2>(f0D, f0U, f1D, f1U, a.four_hy, a.inv_four_hy);
         ft = f1c - f0c;
         if (FAST) {
@@ -371,7 +414,11 @@ __device__ __forceinline__ void strip_step(Strip<INNER, GRAD>& s, const FusedArg
         const float ym = EDGE ? static_cast<float>(rw > 0) * hy_2 : hy_2;
         // face_phi * (xp, xm), solve_2d.cu:337-346: xp = [x < w-1] * alpha / hx^2, xm = [x > 0] * alpha / hx^2; an interior
         // strip has no image border, so both are the uniform alpha / hx^2 there
-        c.wx = (p_rl + pc) / 2.f * (EDGE ? v2f{at_r ? 0.f : hx_2, at_l ? 0.f : hx_2} : v2f{hx_2, hx_2});
+        if (!EDGE && GRAD != 3) {  // the neighbours as DPP operands of the two additions
+            c.wx = v2f{scalar_only(from_right(pc) + pc), scalar_only(from_left(pc) + pc)} / 2.f * v2f{hx_2, hx_2};
+        } else {
+            c.wx = (p_rl + pc) / 2.f * (EDGE ? v2f{at_r ? 0.f : hx_2, at_l ? 0.f : hx_2} : v2f{hx_2, hx_2});
+        }
         c.wy = v2f{face_phi(pD, pc) * yp, face_phi(pU, pc) * ym};
         const float sumH = sum_weights(c.wx.x, c.wx.y, c.wy.x, c.wy.y);
         const float c_ksi = s.p_ksi;
@@ -452,19 +499,25 @@ __device__ __forceinline__ void strip_step(Strip<INNER, GRAD>& s, const FusedArg
         const v2f den = c.den, rden = c.rden, J13_23 = c.J13_23;
         const float ksi = c.ksi, J12 = c.J12;
         const bool top = EDGE && (rk == 0), bot = EDGE && (rk == h - 1);
-        const v2f n_c = s.UV[k - 1][sc];
-        const v2f n_l0 = from_left2(n_c), n_r0 = from_right2(n_c);
-        v2f nL, nR, nU, nD;
+        const v2f n_c = s.UV[k - 1][sc], centre = c.uvc;
+        // neighbour minus centre, component by component for the x neighbours: a scalar subtraction takes the lane shift
+        // as a DPP operand (v_sub_f32_dpp), a packed one needs the shifted pair assembled by two v_mov_b32_dpp first.
+        // The border substitutions select among the differences -- the same values as differences of the selected.
+        const v2f d_l0 = v2f{scalar_only(from_left(n_c.x) - centre.x), scalar_only(from_left(n_c.y) - centre.y)};
+        const v2f d_r0 = v2f{scalar_only(from_right(n_c.x) - centre.x), scalar_only(from_right(n_c.y) - centre.y)};
+        const v2f d_u0 = s.UV[k - 1][su] - centre, d_d0 = s.UV[k - 1][sd] - centre;
+        v2f dL, dR, dU, dD;
         if (GRAD == 3) {  // solve_2d_log: the flow neighbours follow the block rule too (:612-633)
-            nL = pick2((x & 15) == 0, n_c, n_l0);
-            nR = pick2((x & 15) == 15, n_c, pick2(at_r, n_l0, n_r0));
-            nU = pick2((rk & 7) == 0, n_c, s.UV[k - 1][su]);
-            nD = pick2((rk & 7) == 7, n_c, pick2(bot, s.UV[k - 1][su], s.UV[k - 1][sd]));
+            const v2f d_c = n_c - centre;
+            dL = pick2((x & 15) == 0, d_c, d_l0);
+            dR = pick2((x & 15) == 15, d_c, pick2(at_r, d_l0, d_r0));
+            dU = pick2((rk & 7) == 0, d_c, d_u0);
+            dD = pick2((rk & 7) == 7, d_c, pick2(bot, d_u0, d_d0));
         } else {
-            nL = pick2(at_l, n_r0, n_l0), nR = pick2(at_r, n_l0, n_r0);
-            nU = pick2(top, s.UV[k - 1][sd], s.UV[k - 1][su]), nD = pick2(bot, s.UV[k - 1][su], s.UV[k - 1][sd]);
+            dL = pick2(at_l, d_r0, d_l0), dR = pick2(at_r, d_l0, d_r0);
+            dU = pick2(top, d_d0, d_u0), dD = pick2(bot, d_u0, d_d0);
         }
-        const v2f sums = sum_flux2(c.wx, c.wy, nR, nL, nD, nU, c.uvc);  // (sumU, sumV)
+        const v2f sums = flux_of_differences(c.wx, c.wy, dR, dL, dD, dU);  // (sumU, sumV)
         float du_new, dv_new;
         if (FAST) {  // the coupled 2x2 update of solve_2d.cu:361-367 (point_update) with the three-step division
             const float nu = ksi * (-J13_23.x - J12 * dv_in) + sums.x;
@@ -606,12 +659,17 @@ __global__ __launch_bounds__(256, 2) void fused_outer_kernel(FusedArgs a)
     int bx, by;
     const bool uniform = a.rows_interior == a.rows_edge;
     const int inner_cols = a.blocks_x - 2, inner_blocks = inner_cols * a.strips_interior;
+    int id = blockIdx.x;
+    if (a.blocks_per_xcd) {  // workgroups are dealt to the eight XCDs in turn: give every XCD a contiguous run of blocks
+        id = (id & 7) * a.blocks_per_xcd + (id >> 3);
+        if (id >= a.blocks) return;
+    }
     if (uniform) {
-        bx = blockIdx.x % a.blocks_x, by = blockIdx.x / a.blocks_x;
-    } else if (static_cast<int>(blockIdx.x) < inner_blocks) {
-        bx = 1 + blockIdx.x % inner_cols, by = blockIdx.x / inner_cols;
+        bx = id % a.blocks_x, by = id / a.blocks_x;
+    } else if (id < inner_blocks) {
+        bx = 1 + id % inner_cols, by = id / inner_cols;
     } else {
-        const int j = blockIdx.x - inner_blocks;
+        const int j = id - inner_blocks;
         bx = (j & 1) ? a.blocks_x - 1 : 0, by = j >> 1;
     }
     const int strip_x = bx * 4 + (threadIdx.x >> 6);
@@ -783,10 +841,15 @@ int launch_fused_outer(flow2d_context* ctx, int constancy, const float* f0, cons
                 e_data,
                 2.f * hx, 2.f * hy, 4.f * hx, 4.f * hy, 1.f / (2.f * hx), 1.f / (2.f * hy), 1.f / (4.f * hx), 1.f / (4.f * hy),
                 static_cast<float>(1.0 / (2.0 * hx)), static_cast<float>(1.0 / (2.0 * hy)), alpha / (hx * hx), alpha / (hy * hy),
-                static_cast<unsigned long long>(ctx->batch_stride_floats), ctx->fused_fallbacks};
+                plan.blocks, 0, static_cast<unsigned long long>(ctx->batch_stride_floats), ctx->fused_fallbacks};
+    // XCD-aware block order: x-adjacent blocks share their halo columns, y-adjacent strips their halo rows; in one XCD
+    // they meet in its L2 (reads of a 4096^2 launch 541 -> 455 MB; worth 1-3 % of the launch since the round-3 kernel
+    // is within reach of the memory system).  FLOW2D_FUSED_PLAIN_ORDER keeps the plain order (developer A/B knob).
+    static const bool plain_order = std::getenv("FLOW2D_FUSED_PLAIN_ORDER") != nullptr;
+    if (!plain_order) a.blocks_per_xcd = (plan.blocks + 7) / 8;
     const int valid = 64 - 2 * ((int)inner + 1);
     const unsigned strips_x = div_up(w, valid);
-    const dim3 grid(plan.blocks, 1, ctx->batch_count);
+    const dim3 grid(a.blocks_per_xcd ? a.blocks_per_xcd * 8 : plan.blocks, 1, ctx->batch_count);
     const bool pow2 = is_power_of_two(hx) && is_power_of_two(hy);
     int rc;
     if (constancy == FLOW2D_CONSTANCY_GRADIENT)

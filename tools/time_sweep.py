@@ -21,16 +21,18 @@ def main():
     du, dv, phi, ksi, tdu, tdv = (ctx.plane(w, h).fill_bytes(0) for _ in range(6))
     for constancy in (0, 1):
         for algo in algos:
-            for rep in range(3):
+            best = 1e9
+            for rep in range(12):  # the first calls run on a cold GPU: report the last and the best
                 e0, e1 = ctx.event(), ctx.event()
                 ctx.record(e0)
                 ctx.solve_level(*planes, du, dv, phi, ksi, tdu, tdv, w, h, 1.0, 1.0, 35.0, 0.001, 0.001, 10, inner,
                                 constancy, algo)
                 ctx.record(e1)
                 ms = ctx.elapsed_ms(e0, e1)
+                best = min(best, ms)
             bytes_ = w * h * 10 * (32 + 40 * inner)
-            print("constancy %d algo %d: level solve %.3f ms -> %.1f Mpix-iters/s, %.2f TB/s algorithmic (fallback waves so far %d)" %
-                  (constancy, algo, ms, w * h * 10 * inner / ms / 1e3, bytes_ / ms / 1e9, ctx.fused_fallbacks()))
+            print("constancy %d algo %d: level solve %.3f ms (best %.3f) -> %.1f Mpix-iters/s, %.2f TB/s algorithmic (fallback waves so far %d)" %
+                  (constancy, algo, ms, best, w * h * 10 * inner / ms / 1e3, bytes_ / ms / 1e9, ctx.fused_fallbacks()))
     ctx.close()
 
 
