@@ -59,14 +59,16 @@ hipError_t mark(flow2d_context* ctx, flow2d_timing_slot* slot)
 }
 }  // namespace
 
-// largest level (pixels) AUTO gives to the tiled kernel; FLOW2D_TILED_MAX_PIXELS overrides (developer knob).  Re-measured
-// against the round-3 strips (level solve 10 x 5, tiles / strips, ms): Grey 640^2 0.20 / 0.22, 768^2 0.26 / 0.23,
-// 896^2 0.34 / 0.32; Gradient 768^2 0.29 / 0.30, 896^2 0.39 / 0.40, 1024^2 0.40 / 0.45, 1920 x 1080 0.76 / 0.59.
+// largest level (pixels) AUTO gives to the tiled kernel; FLOW2D_TILED_MAX_PIXELS overrides (developer knob).  Measured
+// against the strips as they are at the end of round 3 (tools/time_levels.py; level solve 10 x 5, tiles / strips, ms):
+// Grey 384^2 0.111 / 0.115, 512^2 0.119 / 0.165, 640^2 0.193 / 0.170, 768^2 0.253 / 0.181, 1024^2 0.340 / 0.260;
+// Gradient 512^2 0.127 / 0.183, 640^2 0.207 / 0.182, 1024^2 0.366 / 0.280, 1920 x 1080 0.679 / 0.393.
 static size_t tiled_max_pixels(int data_constancy)
 {
     static const long long forced = std::getenv("FLOW2D_TILED_MAX_PIXELS") ? std::atoll(std::getenv("FLOW2D_TILED_MAX_PIXELS")) : -1;
     if (forced >= 0) return static_cast<size_t>(forced);
-    return data_constancy == FLOW2D_CONSTANCY_GREY ? static_cast<size_t>(704) * 704 : static_cast<size_t>(1100) * 1100;
+    (void)data_constancy;  // the same crossover for the brightness and the gradient terms
+    return static_cast<size_t>(600) * 600;
 }
 
 extern "C" {
@@ -78,10 +80,10 @@ int flow2d_solver_algorithm_for(int requested, size_t width, size_t height, size
 {
     if (requested < FLOW2D_SOLVER_AUTO || requested > FLOW2D_SOLVER_TILED) return -1;
     if (requested == FLOW2D_SOLVER_AUTO) {
-        // Up to tiled_max_pixels (704^2 Grey, 1100^2 for the gradient terms) the outer iteration runs on small LDS tiles (solve_tile.hip): a strip wave
-        // needs (rows + halo) x ~1.1 us whatever the level size, tiles spread a small level over the whole chip
-        // (level solve 10 x 5 at 256^2: 0.07 against 0.13 ms, at 512^2 0.12 against 0.20, at 800^2 0.27 against 0.29;
-        // at 1024^2 the strips win for the gradient term).  That includes the coarsest levels: ten launches of a few
+        // Up to tiled_max_pixels (600^2) the outer iteration runs on small LDS tiles (solve_tile.hip): a strip wave
+        // needs (rows + halo) x ~1 us whatever the level size, tiles spread a small level over the whole chip
+        // (level solve 10 x 5 at 256^2: 0.07 against 0.11 ms, at 512^2 0.12 against 0.17, at 640^2 0.19 against 0.17).
+        // That includes the coarsest levels: ten launches of a few
         // 8 x 8 tiles take 0.05 ms at 16 x 16 ... 64 x 32, the single-workgroup kernel 0.06 ... 0.11 ms.
         if (inner >= 2 && width * height <= tiled_max_pixels(data_constancy) && flow2d::tiled_supports(data_constancy, inner))
             return FLOW2D_SOLVER_TILED;

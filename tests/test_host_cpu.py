@@ -44,7 +44,7 @@ def test_c_abi_rejects_bad_arguments_without_a_device(flow2d):
 
 
 def test_solver_algorithm_selection_and_32bit_guard(flow2d):
-    """flow2d_solve_level's choice of algorithm, checked without a device: AUTO = LDS tiles up to 704 x 704 (Grey) or 1100 x 1100 (gradient terms) (one workgroup
+    """flow2d_solve_level's choice of algorithm, checked without a device: AUTO = LDS tiles up to 600 x 600 pixels (one workgroup
     up to 64 x 32 where the tiled kernel does not apply), the fused strip kernel above (when there are >= 2 sweeps to fuse), per-sweep launches
     otherwise -- and whenever the plane reaches
     4 GiB, which the fused kernel's 32-bit buffer offsets cannot address (an explicit FUSED request is refused there
@@ -56,8 +56,9 @@ def test_solver_algorithm_selection_and_32bit_guard(flow2d):
     assert pick(AUTO, 64, 32, pitch(64), 10, 5) == TILED and pick(AUTO, 64, 33, pitch(64), 10, 5) == TILED
     assert pick(AUTO, 64, 32, pitch(64), 10, 5, flow2d.LOG_DERIVATIVES) == ONE and pick(AUTO, 64, 32, pitch(64), 10, 1) == ONE
     assert pick(AUTO, 512, 512, pitch(512), 10, 5) == TILED and pick(AUTO, 512, 512, pitch(512), 10, 7) == FUSED
-    assert pick(AUTO, 704, 704, pitch(704), 10, 5) == TILED and pick(AUTO, 705, 704, pitch(705), 10, 5) == FUSED
-    assert pick(AUTO, 1024, 1024, pitch(1024), 10, 5) == FUSED and pick(AUTO, 1024, 1024, pitch(1024), 10, 5, flow2d.GRADIENT) == TILED
+    assert pick(AUTO, 600, 600, pitch(600), 10, 5) == TILED and pick(AUTO, 601, 600, pitch(601), 10, 5) == FUSED
+    assert pick(AUTO, 600, 600, pitch(600), 10, 5, flow2d.GRADIENT) == TILED and pick(AUTO, 640, 640, pitch(640), 10, 5, flow2d.GRADIENT) == FUSED
+    assert pick(AUTO, 1024, 1024, pitch(1024), 10, 5) == FUSED and pick(AUTO, 1024, 1024, pitch(1024), 10, 5, flow2d.GRADIENT) == FUSED
     assert pick(AUTO, 1920, 1080, pitch(1920), 10, 5, flow2d.GRADIENT) == FUSED
     assert pick(AUTO, 512, 512, pitch(512), 10, 5, flow2d.LOG_DERIVATIVES) == FUSED  # no tiled Log kernel
     assert pick(TILED, 1024, 1024, pitch(1024), 10, 6) == -1 and pick(TILED, 4096, 4096, pitch(4096), 10, 5) == TILED
