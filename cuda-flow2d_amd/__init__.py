@@ -115,6 +115,7 @@ def hip_lib():
         L.flow2d_resample_y.argtypes = [vp, vp, vp, sz, sz, sz, sz]
         L.flow2d_add_2d_pair.argtypes = [vp, vp, vp, vp, vp, sz, sz, sz]
         L.flow2d_median_2d_pair.argtypes = [vp, vp, vp, sz, sz, sz, sz, vp, vp]
+        L.flow2d_add_median_2d_pair.argtypes = [vp, vp, vp, vp, vp, sz, sz, sz, sz, vp, vp]
         L.flow2d_resample_x_pair.argtypes = [vp, vp, vp, vp, vp, sz, sz, sz, sz]
         L.flow2d_resample_y_pair.argtypes = [vp, vp, vp, vp, vp, sz, sz, sz, sz]
         L.flow2d_resample_xy_pair.argtypes = [vp, vp, vp, vp, vp, sz, sz, sz, sz, sz]
@@ -334,6 +335,12 @@ class Context:
     def median_pair(self, src_a, src_b, w, h, window, dst_a, dst_b):
         _check(hip_lib().flow2d_median_2d_pair(self.handle, src_a.ptr, src_b.ptr, w, h, src_a.pitch, window, dst_a.ptr,
                                                dst_b.ptr), "flow2d_median_2d_pair")
+
+    def add_median(self, src_a, add_a, w, h, window, dst_a, src_b=None, add_b=None, dst_b=None):
+        """Median of (src + add), the sum formed on the fly; optional second plane set."""
+        _check(hip_lib().flow2d_add_median_2d_pair(self.handle, src_a.ptr, add_a.ptr, src_b.ptr if src_b else None,
+                                                   add_b.ptr if add_b else None, w, h, src_a.pitch, window, dst_a.ptr,
+                                                   dst_b.ptr if dst_b else None), "flow2d_add_median_2d_pair")
 
     def resample_x_pair(self, src_a, dst_a, src_b, dst_b, out_w, out_h, in_w):
         _check(hip_lib().flow2d_resample_x_pair(self.handle, src_a.ptr, dst_a.ptr, src_b.ptr, dst_b.ptr, out_w, out_h,

@@ -87,6 +87,20 @@ __device__ __forceinline__ void run_network(float (&v)[N], std::index_sequence<I
         ...);
 }
 
+// What the filter reads: a plane, or (ADD) the sum of two planes formed on the fly -- the pyramid's `u += du` followed
+// by the median of u (optical_flow_2d.cpp:414-446) in one pass: add_2d's sum is a single rounded addition
+// (add_2d.cu:33-46), so the median of the sums is the same value, and the plane of sums is neither written nor re-read.
+template <bool ADD>
+struct Source {
+    const float* __restrict__ in;
+    const float* __restrict__ add;
+    __device__ __forceinline__ float operator[](size_t i) const
+    {
+        if (ADD) return in[i] + add[i];
+        return in[i];
+    }
+};
+
 // v_cmp_class mask: signalling NaN, quiet NaN, negative zero
 constexpr int kSpecialClass = 0x1 | 0x2 | 0x20;
 __device__ __forceinline__ bool is_special(float v) { return __builtin_amdgcn_classf(v, kSpecialClass); }
@@ -98,8 +112,8 @@ __device__ __forceinline__ bool is_special(float v) { return __builtin_amdgcn_cl
 //  * equal values (and -0 / +0, which compare equal) keep their gather order (the sort is stable).
 // So the result is the NaN sitting at r*r/2, or the element of stable rank r*r/2 - a in the run [a, b) of gather
 // positions between the nearest NaNs on either side.  O(n^2) loads (L1 hits); only rare windows come here.
-template <int R>
-__device__ __noinline__ float exact_median(const float* __restrict__ in, int x, int y, int w, int h, int pitch)
+template <int R, bool ADD>
+__device__ __noinline__ float exact_median(const Source<ADD> in, int x, int y, int w, int h, int pitch)
 {
     constexpr int N = R * R, R2 = R / 2, M = N / 2;
     auto at = [&](int k) {
@@ -130,12 +144,14 @@ __device__ __noinline__ float exact_median(const float* __restrict__ in, int x, 
 }
 
 // (grid.z = 2 filters a second, independent plane in the same launch: the flow's u and v)
-template <int R>
-__global__ __launch_bounds__(256) void median_kernel(const float* __restrict__ in_a, const float* __restrict__ in_b, int w,
+template <int R, bool ADD>
+__global__ __launch_bounds__(256) void median_kernel(const float* __restrict__ in_a, const float* __restrict__ in_b,
+                                                     const float* __restrict__ add_a, const float* __restrict__ add_b, int w,
                                                      int h, int pitch, float* __restrict__ out_a,
                                                      float* __restrict__ out_b, BatchArg batch)
 {
-    const float* __restrict__ in = (batch_plane(batch) ? in_b : in_a) + batch_offset(batch);
+    const Source<ADD> in{(batch_plane(batch) ? in_b : in_a) + batch_offset(batch),
+                         ADD ? (batch_plane(batch) ? add_b : add_a) + batch_offset(batch) : nullptr};
     float* __restrict__ out = (batch_plane(batch) ? out_b : out_a) + batch_offset(batch);
     constexpr int R2 = R / 2;
     constexpr int N = R * R;
@@ -149,16 +165,16 @@ __global__ __launch_bounds__(256) void median_kernel(const float* __restrict__ i
     bool special = false;
 #pragma unroll
     for (int j = 0; j < R; ++j) {
-        const float* row = in + static_cast<size_t>(mirror_index(y + j - R2, h)) * pitch;
+        const size_t row = static_cast<size_t>(mirror_index(y + j - R2, h)) * pitch;
 #pragma unroll
         for (int i = 0; i < R; ++i) {
-            v[j * R + i] = row[xs[i]];
+            v[j * R + i] = in[row + xs[i]];
             special |= is_special(v[j * R + i]);
         }
     }
     run_network<N>(v, std::make_index_sequence<network_size<N>()>{});
     float result = v[N / 2];
-    if (special) result = exact_median<R>(in, x, y, w, h, pitch);
+    if (special) result = exact_median<R, ADD>(in, x, y, w, h, pitch);
     out[static_cast<size_t>(y) * pitch + x] = result;
 }
 
@@ -215,20 +231,20 @@ struct RowLoad {
 
 // `special` collects whether any value this lane loaded is a NaN or a -0 (one v_cmp_class per load; the strip is
 // re-checked per pixel only when some lane of the wave saw one)
-template <bool EDGE>
-__device__ __forceinline__ RowLoad<EDGE> load_row(const float* __restrict__ in, int row, int h, int pitch, int xc,
+template <bool EDGE, bool ADD>
+__device__ __forceinline__ RowLoad<EDGE> load_row(const Source<ADD> in, int row, int h, int pitch, int xc,
                                                   const int (&xm)[5], bool& special)
 {
-    const float* line = in + static_cast<size_t>(min(max(mirror_index(row, h), 0), h - 1)) * pitch;
+    const size_t line = static_cast<size_t>(min(max(mirror_index(row, h), 0), h - 1)) * pitch;
     RowLoad<EDGE> r;
     if (EDGE) {
 #pragma unroll
         for (int i = 0; i < 5; ++i) {
-            r.v[i] = line[xm[i]];
+            r.v[i] = in[line + xm[i]];
             special |= is_special(r.v[i]);
         }
     } else {
-        r.v[0] = line[xc];
+        r.v[0] = in[line + xc];
         special |= is_special(r.v[0]);
     }
     return r;
@@ -255,16 +271,16 @@ __device__ __forceinline__ void sorted_tuple(const RowLoad<EDGE>& r, float (&t)[
 
 // One wave, one strip of 64 columns, rows [y0, y1).  Step I of three (the ring of six row slots advances by
 // two rows per step, so three steps bring every slot back to its place and all indices are constants).
-template <bool EDGE, int I>
-__device__ __forceinline__ void median5_step(float (&ring)[6][5], RowLoad<EDGE> (&next)[2], const float* __restrict__ in,
+template <bool EDGE, int I, bool ADD>
+__device__ __forceinline__ void median5_step(float (&ring)[6][5], RowLoad<EDGE> (&next)[2], const Source<ADD> in,
                                              float* __restrict__ out, int ya, int y1, int h, int pitch, int x, int xc,
                                              const int (&xm)[5], bool lane_stores, bool& special)
 {
     // rows ya+2 and ya+3 were requested one step ago; request the two after them before working
     sorted_tuple<EDGE>(next[0], ring[(2 * I + 4) % 6]);
     sorted_tuple<EDGE>(next[1], ring[(2 * I + 5) % 6]);
-    next[0] = load_row<EDGE>(in, ya + 4, h, pitch, xc, xm, special);
-    next[1] = load_row<EDGE>(in, ya + 5, h, pitch, xc, xm, special);
+    next[0] = load_row<EDGE, ADD>(in, ya + 4, h, pitch, xc, xm, special);
+    next[1] = load_row<EDGE, ADD>(in, ya + 5, h, pitch, xc, xm, special);
     float v[kMedianPairWires];
 #pragma unroll
     for (int g = 0; g < 6; ++g)
@@ -279,8 +295,8 @@ __device__ __forceinline__ void median5_step(float (&ring)[6][5], RowLoad<EDGE> 
     }
 }
 
-template <bool EDGE>
-__device__ __forceinline__ void median5_strip(const float* __restrict__ in, float* __restrict__ out, int w, int h, int pitch,
+template <bool EDGE, bool ADD>
+__device__ __forceinline__ void median5_strip(const Source<ADD> in, float* __restrict__ out, int w, int h, int pitch,
                                               int x, int y0, int y1, bool lane_stores)
 {
     const int xc = min(max(x, 0), w - 1);
@@ -293,20 +309,20 @@ __device__ __forceinline__ void median5_strip(const float* __restrict__ in, floa
     {
         RowLoad<EDGE> first[4];
 #pragma unroll
-        for (int g = 0; g < 4; ++g) first[g] = load_row<EDGE>(in, y0 - 2 + g, h, pitch, xc, xm, special);
+        for (int g = 0; g < 4; ++g) first[g] = load_row<EDGE, ADD>(in, y0 - 2 + g, h, pitch, xc, xm, special);
 #pragma unroll
         for (int g = 0; g < 4; ++g) sorted_tuple<EDGE>(first[g], ring[g]);
 #pragma unroll
         for (int e = 0; e < 5; ++e) ring[4][e] = ring[5][e] = 0.f;
     }
-    RowLoad<EDGE> next[2] = {load_row<EDGE>(in, y0 + 2, h, pitch, xc, xm, special),
-                             load_row<EDGE>(in, y0 + 3, h, pitch, xc, xm, special)};
+    RowLoad<EDGE> next[2] = {load_row<EDGE, ADD>(in, y0 + 2, h, pitch, xc, xm, special),
+                             load_row<EDGE, ADD>(in, y0 + 3, h, pitch, xc, xm, special)};
     for (int ya = y0; ya < y1; ya += 6) {
-        median5_step<EDGE, 0>(ring, next, in, out, ya, y1, h, pitch, x, xc, xm, lane_stores, special);
+        median5_step<EDGE, 0, ADD>(ring, next, in, out, ya, y1, h, pitch, x, xc, xm, lane_stores, special);
         if (ya + 2 >= y1) break;
-        median5_step<EDGE, 1>(ring, next, in, out, ya + 2, y1, h, pitch, x, xc, xm, lane_stores, special);
+        median5_step<EDGE, 1, ADD>(ring, next, in, out, ya + 2, y1, h, pitch, x, xc, xm, lane_stores, special);
         if (ya + 4 >= y1) break;
-        median5_step<EDGE, 2>(ring, next, in, out, ya + 4, y1, h, pitch, x, xc, xm, lane_stores, special);
+        median5_step<EDGE, 2, ADD>(ring, next, in, out, ya + 4, y1, h, pitch, x, xc, xm, lane_stores, special);
     }
     // Some lane of this wave loaded a NaN or a -0: every window of the strip is a subset of what the wave loaded,
     // so look at each stored pixel's window again and redo those that hold one the way the reference's sort would.
@@ -314,20 +330,24 @@ __device__ __forceinline__ void median5_strip(const float* __restrict__ in, floa
         for (int y = y0; y < y1; ++y) {
             bool hit = false;
             for (int j = -2; j <= 2; ++j) {
-                const float* line = in + static_cast<size_t>(mirror_index(y + j, h)) * pitch;
-                for (int i = -2; i <= 2; ++i) hit |= is_special(line[mirror_index(x + i, w)]);
+                const size_t line = static_cast<size_t>(mirror_index(y + j, h)) * pitch;
+                for (int i = -2; i <= 2; ++i) hit |= is_special(in[line + mirror_index(x + i, w)]);
             }
-            if (hit) out[static_cast<size_t>(y) * pitch + x] = exact_median<5>(in, x, y, w, h, pitch);
+            if (hit) out[static_cast<size_t>(y) * pitch + x] = exact_median<5, ADD>(in, x, y, w, h, pitch);
         }
     }
 }
 
+template <bool ADD>
 __global__ __launch_bounds__(256) void median5_stream_kernel(const float* __restrict__ in_a,
-                                                             const float* __restrict__ in_b, int w, int h, int pitch,
+                                                             const float* __restrict__ in_b,
+                                                             const float* __restrict__ add_a,
+                                                             const float* __restrict__ add_b, int w, int h, int pitch,
                                                              int rows_per_strip, float* __restrict__ out_a,
                                                              float* __restrict__ out_b, BatchArg batch)
 {
-    const float* __restrict__ in = (batch_plane(batch) ? in_b : in_a) + batch_offset(batch);
+    const Source<ADD> in{(batch_plane(batch) ? in_b : in_a) + batch_offset(batch),
+                         ADD ? (batch_plane(batch) ? add_b : add_a) + batch_offset(batch) : nullptr};
     float* __restrict__ out = (batch_plane(batch) ? out_b : out_a) + batch_offset(batch);
     const int lane = threadIdx.x & 63;
     const int strip = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -341,9 +361,9 @@ __global__ __launch_bounds__(256) void median5_stream_kernel(const float* __rest
     // at the left and right image border the mirrored columns are loaded instead
     const bool edge = x_first < 0 || x_first + 63 > w - 1;
     if (__builtin_amdgcn_readfirstlane(edge))
-        median5_strip<true>(in, out, w, h, pitch, x, y0, y1, lane_stores);
+        median5_strip<true, ADD>(in, out, w, h, pitch, x, y0, y1, lane_stores);
     else
-        median5_strip<false>(in, out, w, h, pitch, x, y0, y1, lane_stores);
+        median5_strip<false, ADD>(in, out, w, h, pitch, x, y0, y1, lane_stores);
 }
 
 // rows per strip: even, tall enough that the four start-up rows are noise, short enough to fill the chip
@@ -358,8 +378,10 @@ int median5_rows_per_strip(const flow2d_context* ctx, size_t w, size_t h)
 
 }  // namespace
 
-static int launch_median(flow2d_context* ctx, const float* input, const float* input_b, size_t width, size_t height,
-                         size_t pitch_bytes, size_t window, float* output, float* output_b)
+template <bool ADD>
+static int launch_median(flow2d_context* ctx, const float* input, const float* input_b, const float* addend,
+                         const float* addend_b, size_t width, size_t height, size_t pitch_bytes, size_t window,
+                         float* output, float* output_b)
 {
     FLOW2D_ENTER(ctx);
     if (!flow2d::plane_args_ok(input, width, height, pitch_bytes) ||
@@ -369,6 +391,10 @@ static int launch_median(flow2d_context* ctx, const float* input, const float* i
     if (pair && (!flow2d::plane_args_ok(input_b, width, height, pitch_bytes) ||
                  !flow2d::plane_args_ok(output_b, width, height, pitch_bytes) || input_b == output_b ||
                  output_b == output || output_b == input || output == input_b))
+        return FLOW2D_ERR_INVALID_ARGUMENT;
+    if (ADD && (!flow2d::plane_args_ok(addend, width, height, pitch_bytes) || addend == output || addend == output_b ||
+                (pair && (!flow2d::plane_args_ok(addend_b, width, height, pitch_bytes) || addend_b == output ||
+                          addend_b == output_b))))
         return FLOW2D_ERR_INVALID_ARGUMENT;
     if (window != 3 && window != 5 && window != 7) return FLOW2D_ERR_UNSUPPORTED;
     // the mirror rule needs every reflected index inside the image
@@ -382,14 +408,15 @@ static int launch_median(flow2d_context* ctx, const float* input, const float* i
     if (window == 5 && width >= 8 && height >= 8) {  // mirrored rows/columns up to 3 beyond the border stay inside
         const int rows = median5_rows_per_strip(ctx, width, height);
         const dim3 sgrid(flow2d::div_up(flow2d::div_up(width, kStreamValid), 4), flow2d::div_up(height, rows), z);
-        median5_stream_kernel<<<sgrid, 256, 0, ctx->stream>>>(input, input_b, w, h, pitch, rows, output, output_b, batch);
+        median5_stream_kernel<ADD><<<sgrid, 256, 0, ctx->stream>>>(input, input_b, addend, addend_b, w, h, pitch, rows, output,
+                                                                   output_b, batch);
         FLOW2D_CHECK_LAUNCH();
         return FLOW2D_OK;
     }
     switch (window) {
-        case 3: median_kernel<3><<<grid, block, 0, ctx->stream>>>(input, input_b, w, h, pitch, output, output_b, batch); break;
-        case 5: median_kernel<5><<<grid, block, 0, ctx->stream>>>(input, input_b, w, h, pitch, output, output_b, batch); break;
-        default: median_kernel<7><<<grid, block, 0, ctx->stream>>>(input, input_b, w, h, pitch, output, output_b, batch); break;
+        case 3: median_kernel<3, ADD><<<grid, block, 0, ctx->stream>>>(input, input_b, addend, addend_b, w, h, pitch, output, output_b, batch); break;
+        case 5: median_kernel<5, ADD><<<grid, block, 0, ctx->stream>>>(input, input_b, addend, addend_b, w, h, pitch, output, output_b, batch); break;
+        default: median_kernel<7, ADD><<<grid, block, 0, ctx->stream>>>(input, input_b, addend, addend_b, w, h, pitch, output, output_b, batch); break;
     }
     FLOW2D_CHECK_LAUNCH();
     return FLOW2D_OK;
@@ -398,12 +425,20 @@ static int launch_median(flow2d_context* ctx, const float* input, const float* i
 extern "C" int flow2d_median_2d(flow2d_context* ctx, const float* input, size_t width, size_t height,
                                 size_t pitch_bytes, size_t window, float* output)
 {
-    return launch_median(ctx, input, nullptr, width, height, pitch_bytes, window, output, nullptr);
+    return launch_median<false>(ctx, input, nullptr, nullptr, nullptr, width, height, pitch_bytes, window, output, nullptr);
 }
 
 extern "C" int flow2d_median_2d_pair(flow2d_context* ctx, const float* input_a, const float* input_b, size_t width,
                                      size_t height, size_t pitch_bytes, size_t window, float* output_a, float* output_b)
 {
     if (!input_b || !output_b) return FLOW2D_ERR_INVALID_ARGUMENT;
-    return launch_median(ctx, input_a, input_b, width, height, pitch_bytes, window, output_a, output_b);
+    return launch_median<false>(ctx, input_a, input_b, nullptr, nullptr, width, height, pitch_bytes, window, output_a, output_b);
+}
+
+extern "C" int flow2d_add_median_2d_pair(flow2d_context* ctx, const float* input_a, const float* addend_a, const float* input_b,
+                                         const float* addend_b, size_t width, size_t height, size_t pitch_bytes, size_t window,
+                                         float* output_a, float* output_b)
+{
+    if (!addend_a || ((input_b || output_b || addend_b) && !(input_b && output_b && addend_b))) return FLOW2D_ERR_INVALID_ARGUMENT;
+    return launch_median<true>(ctx, input_a, input_b, addend_a, addend_b, width, height, pitch_bytes, window, output_a, output_b);
 }

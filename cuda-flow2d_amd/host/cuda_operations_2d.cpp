@@ -106,6 +106,19 @@ void CudaOperationMedian2D::Execute(OperationParameters& params)
         failed_ = true;
         return;
     }
+    // optional addends (not in the reference's bag): the filter runs over dev_input + dev_addend, formed on the fly -- the
+    // pyramid's `u += du` (a single rounded addition per pixel) and the median of u in one pass; dev_input is not modified
+    DevicePtr dev_addend = 0, dev_addend_b = 0;
+    const bool sum = params.Read<DevicePtr>("dev_addend", dev_addend) && (!pair || params.Read<DevicePtr>("dev_addend_b", dev_addend_b));
+    const size_t window = (radius != 1 && radius % 2 == 0) ? radius - 1 : radius;
+    if (sum && !(window >= 3 && window <= 7)) {  // nothing to fuse into: add in place, then the plain path
+        if (pair)
+            Failed(flow2d_add_2d_pair(context_, AsPlane(dev_input), AsPlane(dev_addend), AsPlane(dev_input_b), AsPlane(dev_addend_b),
+                                      data_size.width, data_size.height, dev_container_size_.pitch), "flow2d_add_2d_pair");
+        else
+            Failed(flow2d_add_2d(context_, AsPlane(dev_input), AsPlane(dev_addend), data_size.width, data_size.height,
+                                 dev_container_size_.pitch), "flow2d_add_2d");
+    }
     if (radius == 1) {  // no filtering: copy the whole container (cuda_operation_median_2d.cpp:100-104)
         Failed(flow2d_copy_d2d(context_, AsPlane(dev_output), AsPlane(dev_input),
                                dev_container_size_.pitch * dev_container_size_.height),
@@ -120,7 +133,13 @@ void CudaOperationMedian2D::Execute(OperationParameters& params)
         std::printf("Warning. Median raduis is even (%zu), decresaing by 1...\n", radius);
         radius -= 1;
     }
-    if (radius >= 3 && radius <= 7 && pair) {
+    if (radius >= 3 && radius <= 7 && sum) {
+        Failed(flow2d_add_median_2d_pair(context_, AsPlane(dev_input), AsPlane(dev_addend), pair ? AsPlane(dev_input_b) : nullptr,
+                                         pair ? AsPlane(dev_addend_b) : nullptr, data_size.width, data_size.height,
+                                         dev_container_size_.pitch, radius, AsPlane(dev_output),
+                                         pair ? AsPlane(dev_output_b) : nullptr),
+               "flow2d_add_median_2d_pair");
+    } else if (radius >= 3 && radius <= 7 && pair) {
         Failed(flow2d_median_2d_pair(context_, AsPlane(dev_input), AsPlane(dev_input_b), data_size.width,
                                      data_size.height, dev_container_size_.pitch, radius, AsPlane(dev_output),
                                      AsPlane(dev_output_b)),

@@ -806,20 +806,11 @@ bool OpticalFlow2D::RunPyramid(OperationParameters& params)
             Release(temp_dv);
         }
 
-        {  // u += du, v += dv (one launch)
-            op.Clear();
-            op.PushValuePtr("operand_0", &flow_u);
-            op.PushValuePtr("operand_1", &flow_du);
-            op.PushValuePtr("operand_0_b", &flow_v);
-            op.PushValuePtr("operand_1_b", &flow_dv);
-            op.PushValuePtr("data_size", &current_size);
-            cuop_add_.Execute(op);
-        failed |= cuop_add_.TakeFailure();
-        }
         prev_size = current_size;
         if (failed) break;
 
-        {  // median of u and v after every level, the finest included (one launch for both)
+        {  // u += du, v += dv and the median of u and v after every level, the finest included -- one launch: the filter
+           // reads u + du (a single rounded addition, add_2d.cu:33-46) as it goes, the plane of sums is never stored
             DevicePtr temp = Acquire(), temp_b = Acquire();
             // the last median of a ComputeFlowDevice run delivers the result into the caller's planes
             const bool deliver = level == 0 && caller_flow_u_ != 0 && caller_flow_v_ != 0;
@@ -829,6 +820,8 @@ bool OpticalFlow2D::RunPyramid(OperationParameters& params)
             op.PushValuePtr("dev_output", &out_u);
             op.PushValuePtr("dev_input_b", &flow_v);
             op.PushValuePtr("dev_output_b", &out_v);
+            op.PushValuePtr("dev_addend", &flow_du);
+            op.PushValuePtr("dev_addend_b", &flow_dv);
             op.PushValuePtr("data_size", &current_size);
             op.PushValuePtr("radius", &median_radius);
             cuop_median_.Execute(op);

@@ -206,6 +206,13 @@ FLOW2D_API int flow2d_add_2d_pair(flow2d_context* ctx, float* operand_0_a, const
 FLOW2D_API int flow2d_median_2d_pair(flow2d_context* ctx, const float* input_a, const float* input_b, size_t width,
                                      size_t height, size_t pitch_bytes, size_t window, float* output_a,
                                      float* output_b);
+/* add_2d followed by median_2d (optical_flow_2d.cpp:480-530: u += du, then the median of u) in one launch: the filter runs
+ * over input + addend, formed per pixel as it is read -- add_2d's sum is one rounded addition (add_2d.cu:33-46), so the
+ * result is the same -- and the plane of sums is neither written nor read back.  input is NOT modified.  input_b,
+ * addend_b, output_b: optional second plane set (all three or none). */
+FLOW2D_API int flow2d_add_median_2d_pair(flow2d_context* ctx, const float* input_a, const float* addend_a,
+                                         const float* input_b, const float* addend_b, size_t width, size_t height,
+                                         size_t pitch_bytes, size_t window, float* output_a, float* output_b);
 FLOW2D_API int flow2d_resample_x_pair(flow2d_context* ctx, const float* input_a, float* output_a,
                                       const float* input_b, float* output_b, size_t out_width, size_t out_height,
                                       size_t in_width, size_t pitch_bytes);

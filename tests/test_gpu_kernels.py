@@ -223,6 +223,38 @@ def test_two_plane_launches(ctx, flow2d, oracle, w, h, cw, ch):
         ctx.median_pair(pa, pb, w, h, 5, pc, pc)  # the two outputs must differ
 
 
+@pytest.mark.parametrize("window", [3, 5, 7])
+@pytest.mark.parametrize("w,h,cw,ch", [(100, 70, 128, 80), (700, 133, 704, 140), (1000, 300, 1024, 300), (8, 8, 8, 8), (7, 5, 8, 8)])
+def test_add_median(ctx, flow2d, oracle, w, h, cw, ch, window):
+    """`u += du` and the median of u in one launch (the filter reads u + du as it goes): the bits of add_2d followed by
+    median_2d, sums that are NaN or -0 included (u = -0 and du = -0 is the only way to a -0 sum), for one plane and for
+    two; the inputs are left as they were."""
+    rng = np.random.default_rng(w * 7 + h + window)
+    _, _, u, v, *_ = level_fields(oracle, w, h, 36)
+    du = (rng.normal(0, 0.3, (h, w))).astype(np.float32)
+    dv = (rng.normal(0, 0.3, (h, w))).astype(np.float32)
+    du[::3, ::4] = -u[::3, ::4]            # sums of exactly +0: ties
+    u[1::4, 1::5] = -0.0
+    du[1::4, 1::5] = -0.0                  # sums of -0
+    du[rng.random((h, w)) < 0.02] = np.nan
+    du[h // 2, : min(w, 6)] = np.nan       # a run of NaN sums (propagated NaNs: the payload is the operand's on both sides)
+    pu, pdu, pv, pdv = (up(ctx, a, cw, ch, 99.0) for a in (u, du, v, dv))
+    ou, ov = ctx.plane(cw, ch).fill_bytes(0x7f), ctx.plane(cw, ch).fill_bytes(0x7f)
+    ctx.add_median(pu, pdu, w, h, window, ou, pv, pdv, ov)
+    want_u = oracle.median(oracle.add(u, du, w, h), w, h, window)
+    want_v = oracle.median(oracle.add(v, dv, w, h), w, h, window)
+    assert np.array_equal(ou.download(w, h).view(np.uint32), want_u.view(np.uint32))
+    assert np.array_equal(ov.download(w, h).view(np.uint32), want_v.view(np.uint32))
+    assert np.array_equal(pu.download(w, h).view(np.uint32), u.view(np.uint32))  # not modified
+    single = ctx.plane(cw, ch).fill_bytes(0x7f)
+    ctx.add_median(pv, pdv, w, h, window, single)
+    assert np.array_equal(single.download(w, h).view(np.uint32), want_v.view(np.uint32))
+    got = single.download()
+    assert np.all(got[h:, :].view(np.uint32) == 0x7f7f7f7f) and np.all(got[:, w:].view(np.uint32) == 0x7f7f7f7f)
+    with pytest.raises(flow2d.Flow2DError):
+        ctx.add_median(pu, pdu, w, h, window, pdu)  # the addend cannot be the output
+
+
 def test_median_rejects_bad_window(ctx, flow2d, oracle):
     src, dst = ctx.plane(32, 32), ctx.plane(32, 32)
     for bad in (0, 1, 2, 4, 9):
