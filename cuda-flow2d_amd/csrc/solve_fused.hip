@@ -80,6 +80,8 @@ struct FusedArgs {
     float inv_two_hx, inv_two_hy, inv_four_hx, inv_four_hy;  // their reciprocals (exact when h is a power of two)
     float hx_1, hy_1;                                // float(1.0 / (2.0 * h)), solve_2d.cu:868-869
     float hx_2, hy_2;                                // alpha / (h * h), solve_2d.cu:337-340
+    int plain_only;                   // a grid spacing outside the range the three-step division is proven for: every wave
+                                      // takes the fallback pass (plain divisions) at once
     int blocks, blocks_per_xcd;       // working blocks of the plan; ceil(blocks / 8), or 0 for the plain block order
     unsigned long long batch_stride;  // floats between the instances of a batched launch (blockIdx.z)
     unsigned int* fallback_count;     // waves that repeated their strip with the plain division (diagnostics; may be null)
@@ -192,6 +194,27 @@ __device__ __forceinline__ void guard_results(DivGuard& g, float du, float dv)
     g.out = max(g.out, max(__float_as_uint(du) << 1, __float_as_uint(dv) << 1));
     asm volatile("" : "+v"(g.out));
 }
+// x / d for the grid-spacing divisors 2h and 4h (wave-uniform; y = RN(1 / d) comes from the host): an exact multiply
+// when they are powers of two, the three-step division under the numerator guard otherwise, the plain division in the
+// fallback pass.  (A spacing outside [2^-30, 2^40] sends the whole launch to the fallback: FusedArgs::plain_only.)
+template <bool POW2, bool FAST>
+__device__ __forceinline__ float spacing_quotient(DivGuard& g, float n, float d, float y)
+{
+    if (POW2) return n * y;
+    if (!FAST) return n / d;
+    g.tiny = min(g.tiny, (__float_as_uint(n) << 1) - 1u);
+    asm volatile("" : "+v"(g.tiny));
+    return div3(n, d, y);
+}
+template <bool POW2, bool FAST>
+__device__ __forceinline__ v2f spacing_quotient2(DivGuard& g, v2f n, float d, float y)
+{
+    if (POW2) return n * y;
+    if (!FAST) return v2f{n.x / d, n.y / d};
+    guard_numerators(g, n.x, n.y);
+    return v2f{div3(n.x, d, y), div3(n.y, d, y)};
+}
+
 __device__ __forceinline__ bool guard_tripped(const DivGuard& g)
 {
     return g.tiny < kTinyLimit || g.den > kDenSpan || g.out > kOutLimit;
@@ -339,14 +362,8 @@ __device__ __forceinline__ void strip_step(Strip<INNER, GRAD>& s, const FusedArg
             xnum = diff4_num2(uvR, uvL, duvR, duvL);
             ynum = diff4_num2(uvD, uvU, duvD, duvU);
         }
-        v2f dx, dy;
-        if (POW2) {
-            dx = xnum * a.inv_two_hx;
-            dy = ynum * a.inv_two_hy;
-        } else {
-            dx = v2f{xnum.x / a.two_hx, xnum.y / a.two_hx};
-            dy = v2f{ynum.x / a.two_hy, ynum.y / a.two_hy};
-        }
+        const v2f dx = spacing_quotient2<POW2, FAST>(s.guard, xnum, a.two_hx, a.inv_two_hx);
+        const v2f dy = spacing_quotient2<POW2, FAST>(s.guard, ynum, a.two_hy, a.inv_two_hy);
         float t_phi = 1.f, t_ksi = 1.f;  // 2 sqrt(.) of the two robustifiers, for the guard
         if (FAST) s.phiw[s1] = half_inverse_root(phi_argument(dx.x, dy.x, dx.y, dy.y, a.e_smooth), t_phi);
         else s.phiw[s1] = phi_value(dx.x, dy.x, dx.y, dy.y, a.e_smooth);
@@ -354,16 +371,16 @@ __device__ __forceinline__ void strip_step(Strip<INNER, GRAD>& s, const FusedArg
         const float f0c = s.f0w[s1], f1c = s.f1w[s1];
         if (!EDGE) {
             const float fx_num = scalar_only(scalar_only(scalar_only(from_right(f0c) - from_left(f0c)) + from_right(f1c)) - from_left(f1c));
-            fx = div_spacing<POW2>(fx_num, a.four_hx, a.inv_four_hx);
+            fx = spacing_quotient<POW2, FAST>(s.guard, fx_num, a.four_hx, a.inv_four_hx);
         } else {
             const float f0l0 = from_left(f0c), f0r0 = from_right(f0c), f1l0 = from_left(f1c), f1r0 = from_right(f1c);
             const float f0L = at_l ? f0r0 : f0l0, f0R = at_r ? f0l0 : f0r0;
             const float f1L = at_l ? f1r0 : f1l0, f1R = at_r ? f1l0 : f1r0;
-            fx = diff4s<POW2>(f0R, f0L, f1R, f1L, a.four_hx, a.inv_four_hx);
+            fx = spacing_quotient<POW2, FAST>(s.guard, f0R - f0L + f1R - f1L, a.four_hx, a.inv_four_hx);
         }
         const float f0U = top ? s.f0w[s0] : s.f0w[s2], f0D = bot ? s.f0w[s2] : s.f0w[s0];
         const float f1U = top ? s.f1w[s0] : s.f1w[s2], f1D = bot ? s.f1w[s2] : s.f1w[s0];
-        fy = diff4s<POW2>(f0D, f0U, f1D, f1U, a.four_hy, a.inv_four_hy);
+        fy = spacing_quotient<POW2, FAST>(s.guard, f0D - f0U + f1D - f1U, a.four_hy, a.inv_four_hy);
         ft = f1c - f0c;
         if (FAST) {
             ksi = half_inverse_root(ksi_argument(fx, fy, ft, s.duvw[s1].x, s.duvw[s1].y, a.e_data), t_ksi);
@@ -380,8 +397,8 @@ __device__ __forceinline__ void strip_step(Strip<INNER, GRAD>& s, const FusedArg
             const float l1L = x_lo ? l1c : l1l0, l1R = x_hi ? l1c : (at_r ? l1l0 : l1r0);
             const float l0U = y_lo ? l0c : s.lf0w[s2], l0D = y_hi ? l0c : (bot ? s.lf0w[s2] : s.lf0w[s0]);
             const float l1U = y_lo ? l1c : s.lf1w[s2], l1D = y_hi ? l1c : (bot ? s.lf1w[s2] : s.lf1w[s0]);
-            s.fxw[s1] = diff4s<POW2>(l0R, l0L, l1R, l1L, a.four_hx, a.inv_four_hx);
-            s.fyw[s1] = diff4s<POW2>(l0D, l0U, l1D, l1U, a.four_hy, a.inv_four_hy);
+            s.fxw[s1] = spacing_quotient<POW2, FAST>(s.guard, l0R - l0L + l1R - l1L, a.four_hx, a.inv_four_hx);
+            s.fyw[s1] = spacing_quotient<POW2, FAST>(s.guard, l0D - l0U + l1D - l1U, a.four_hy, a.inv_four_hy);
             s.ftw[s1] = l1c - l0c;
         } else if (GRAD) {
             s.fxw[s1] = fx;
@@ -701,8 +718,10 @@ __global__ __launch_bounds__(256, 2) void fused_outer_kernel(FusedArgs a)
     // does any row or column this wave touches sit on an image border?  (a superset test is fine)
     const int x_first = strip_x * S::kValid - S::kHalo;
     const bool edge = x_first <= 0 || x_first + 63 >= a.w - 1 || y0 <= S::kHalo + 1 || y1 + S::kHalo + 1 >= a.h;
-    bool bad;
-    if (__builtin_amdgcn_readfirstlane(edge))
+    bool bad = a.plain_only != 0;
+    if (bad)
+        ;
+    else if (__builtin_amdgcn_readfirstlane(edge))
         bad = run_strip<INNER, GRAD, true, POW2, CONT, kThreeStepDivision>(a, x, xc, at_l, at_r, lane_stores, y0, y1, hx_2, hy_2);
     else
         bad = run_strip<INNER, GRAD, false, POW2, CONT, kThreeStepDivision>(a, x, xc, at_l, at_r, lane_stores, y0, y1, hx_2, hy_2);
@@ -841,7 +860,11 @@ int launch_fused_outer(flow2d_context* ctx, int constancy, const float* f0, cons
                 e_data,
                 2.f * hx, 2.f * hy, 4.f * hx, 4.f * hy, 1.f / (2.f * hx), 1.f / (2.f * hy), 1.f / (4.f * hx), 1.f / (4.f * hy),
                 static_cast<float>(1.0 / (2.0 * hx)), static_cast<float>(1.0 / (2.0 * hy)), alpha / (hx * hx), alpha / (hy * hy),
-                plan.blocks, 0, static_cast<unsigned long long>(ctx->batch_stride_floats), ctx->fused_fallbacks};
+                0, plan.blocks, 0, static_cast<unsigned long long>(ctx->batch_stride_floats), ctx->fused_fallbacks};
+    {  // 2h and 4h as three-step divisors (non-power-of-two spacings): within [2^-30, 2^40] like every guarded denominator
+        const float lo = std::min(a.two_hx, a.two_hy), hi = std::max(a.four_hx, a.four_hy);
+        if (!(lo >= 0x1p-30f && hi <= 0x1p40f)) a.plain_only = 1;
+    }
     // XCD-aware block order: x-adjacent blocks share their halo columns, y-adjacent strips their halo rows; in one XCD
     // they meet in its L2 (reads of a 4096^2 launch 541 -> 455 MB; worth 1-3 % of the launch since the round-3 kernel
     // is within reach of the memory system).  FLOW2D_FUSED_PLAIN_ORDER keeps the plain order (developer A/B knob).

@@ -200,3 +200,44 @@ def test_zero_regularisers_match_the_per_sweep_kernels(ctx, flow2d, oracle):
         fin = np.isfinite(y)
         assert np.array_equal(bits(x[fin]), bits(y[fin]))
     assert ctx.fused_fallbacks() > before
+
+
+@pytest.mark.parametrize("constancy", [0, 1, 2])  # (solve_2d_log with such spacings: test_gpu_reference.py, against the reference's kernel)
+@pytest.mark.parametrize("hx,hy", [(1.1, 0.9), (3.7, 1.0), (0.013, 0.02)])
+def test_spacings_that_are_no_powers_of_two(ctx, oracle, hx, hy, constancy):
+    """The six divisions by 2h and 4h of a row step go through the three-step division with the host's RN(1 / (2h)),
+    RN(1 / (4h)) when the spacing is no power of two (pyramids with a scale factor other than 0.5); same bits as the
+    oracle's plain divisions, and ordinary operands do not fall back."""
+    w, h = 640, 264
+    f0, f1, u, v, _, _ = level_fields(oracle, w, h, 51)
+    before = ctx.fused_fallbacks()
+    a, b, odu, odv = fused_vs_oracle(ctx, oracle, f0, f1, u, v, w, h, w, h, np.float32(hx), np.float32(hy), 35.0, 2, 5, constancy)
+    assert np.array_equal(bits(a), bits(odu)) and np.array_equal(bits(b), bits(odv))
+    if hx >= 1.0:  # (h = 0.013 makes second derivatives of 1e5 and more: some denominators leave the guarded range)
+        assert ctx.fused_fallbacks() == before
+
+
+def test_tiny_differences_over_a_non_power_of_two_spacing_fall_back(ctx, oracle):
+    """A flow of magnitude 1e-30 over h = 1.1: the numerators of the flow derivatives (differences of such values) are
+    below 2^-80, where the three-step division by 2h is not proven -- the guard sends the waves to the plain division."""
+    w, h = 640, 200
+    rng = np.random.default_rng(7)
+    f0, f1, _, _, _, _ = level_fields(oracle, w, h, 53)
+    u = (rng.normal(0, 1, (h, w)) * 1e-30).astype(np.float32)
+    v = (rng.normal(0, 1, (h, w)) * 1e-30).astype(np.float32)
+    before = ctx.fused_fallbacks()
+    a, b, odu, odv = fused_vs_oracle(ctx, oracle, f0, f1, u, v, w, h, w, h, np.float32(1.1), np.float32(1.1), 35.0, 1, 5, 0)
+    assert np.array_equal(bits(a), bits(odu)) and np.array_equal(bits(b), bits(odv))
+    assert ctx.fused_fallbacks() > before
+
+
+def test_a_spacing_outside_the_guarded_range_takes_the_plain_divisions(ctx, oracle):
+    """h = 3 * 2^40: 2h is above 2^40, outside the range the three-step division is proven for; the launch runs the
+    fallback pass throughout (every wave counted) and equals the oracle."""
+    w, h = 640, 200
+    f0, f1, u, v, _, _ = level_fields(oracle, w, h, 55)
+    big = np.float32(3.0 * 2.0 ** 40)
+    before = ctx.fused_fallbacks()
+    a, b, odu, odv = fused_vs_oracle(ctx, oracle, f0, f1, u, v, w, h, w, h, big, np.float32(1.1), 35.0, 1, 5, 0)
+    assert np.array_equal(bits(a), bits(odu)) and np.array_equal(bits(b), bits(odv))
+    assert ctx.fused_fallbacks() > before

@@ -1,5 +1,5 @@
 """Developer tool: level solve (10 x 5) by level size, fused strips against LDS tiles -- the numbers behind AUTO's
-threshold (solve_level.hip, tiled_max_pixels).  usage (GPU box): python tools/time_levels.py [sizes, e.g. 512,640x480,...]"""
+threshold (solve_level.hip, tiled_max_pixels).  usage (GPU box): python tools/time_levels.py [sizes, e.g. 512,640x480,...] [grid spacing h, default 1.0; e.g. 1.1 for a spacing that is no power of two]"""
 import importlib
 import os
 import sys
@@ -12,6 +12,7 @@ F = importlib.import_module("cuda-flow2d_amd")
 
 def main():
     sizes = sys.argv[1].split(",") if len(sys.argv) > 1 else ["256", "384", "512", "640", "704", "768", "896", "1024", "1200", "1920x1080"]
+    spacing = float(sys.argv[2]) if len(sys.argv) > 2 else 1.0
     ctx = F.Context(0)
     rng = np.random.default_rng(0)
     for size in sizes:
@@ -25,7 +26,7 @@ def main():
                 for rep in range(30):
                     e0, e1 = ctx.event(), ctx.event()
                     ctx.record(e0)
-                    ctx.solve_level(*planes, du, dv, phi, ksi, tdu, tdv, w, h, 1.0, 1.0, 35.0, 0.001, 0.001, 10, 5, constancy, algo)
+                    ctx.solve_level(*planes, du, dv, phi, ksi, tdu, tdv, w, h, spacing, spacing, 35.0, 0.001, 0.001, 10, 5, constancy, algo)
                     ctx.record(e1)
                     best = min(best, ctx.elapsed_ms(e0, e1))
                 line += "  %s %s %.3f" % ("grey" if constancy == 0 else "grad", "tiles" if algo == F.SOLVER_TILED else "strips", best)
