@@ -155,18 +155,19 @@ __device__ __forceinline__ float half_inverse_root(float s, float& twice_root)
     return rcp3(twice_root);
 }
 
-// What the proof does not cover is recorded per lane in three unsigned accumulators -- integer min / max on the operands'
+// What the proof does not cover is recorded per lane in four integer accumulators -- integer min / max on the operands'
 // bit patterns, vector ALU only (a comparison per division would go through the scalar unit: measured, it costs more than
 // the divisions it guards) -- and judged once, after the strip:
 //   tiny: min of (bits(n) << 1) - 1 over the numerators: the shift drops the sign, the decrement sends a zero (harmless:
 //         q0 = r = q = 0) to the top; a non-zero numerator below 2^-80 lands below kTinyLimit.  The one zero that is not
 //         harmless is a numerator of exactly -0, whose quotient is -0 while the three steps give +0; it takes a -0 in the
-//         flow planes to produce one (the sum of the four face terms is -0 only if all four are), so the same
-//         accumulator takes bits(x) ^ 0x80000000 of every flow value read: 0 for a -0
+//         flow planes to produce one (the sum of the four face terms is -0 only if all four are):
+//   zero: signed min of the raw bits of every flow value read: INT_MIN exactly when one of them is a -0
 //   den : max of bits(den) - bits(2^-30): above kDenSpan for a denominator outside [2^-30, 2^40], negative or NaN
 //   out : max of bits(du, dv) << 1 over the stored results: above kOutLimit for an infinity or a NaN
 struct DivGuard {
     unsigned tiny, den, out;
+    int zero;
 };
 constexpr unsigned kTinyLimit = 2u * 0x17800000u - 1u;         // 2^-80 = 0x17800000
 constexpr unsigned kDenLow = 0x30800000u, kDenSpan = 0x53800000u - 0x30800000u;  // 2^-30, 2^40
@@ -180,9 +181,11 @@ __device__ __forceinline__ void guard_numerators(DivGuard& g, float nu, float nv
 }
 __device__ __forceinline__ void guard_flow_row(DivGuard& g, v2f uv, v2f duv)
 {
-    g.tiny = min(min(g.tiny, min(__float_as_uint(uv.x) ^ 0x80000000u, __float_as_uint(uv.y) ^ 0x80000000u)),
-                 min(__float_as_uint(duv.x) ^ 0x80000000u, __float_as_uint(duv.y) ^ 0x80000000u));
-    asm volatile("" : "+v"(g.tiny));
+    // read as a signed integer, -0 (0x80000000) is the smallest value there is: a signed minimum over the raw bits
+    // reaches INT_MIN exactly when some value is a -0 (two v_min3_i32 per row instead of four v_xor and two minima)
+    g.zero = min(min(g.zero, __float_as_int(uv.x)), __float_as_int(uv.y));
+    g.zero = min(min(g.zero, __float_as_int(duv.x)), __float_as_int(duv.y));
+    asm volatile("" : "+v"(g.zero));
 }
 __device__ __forceinline__ void guard_denominators(DivGuard& g, float du, float dv)
 {
@@ -217,12 +220,14 @@ __device__ __forceinline__ v2f spacing_quotient2(DivGuard& g, v2f n, float d, fl
 
 __device__ __forceinline__ bool guard_tripped(const DivGuard& g)
 {
-    return g.tiny < kTinyLimit || g.den > kDenSpan || g.out > kOutLimit;
+    return g.tiny < kTinyLimit || g.den > kDenSpan || g.out > kOutLimit || g.zero == static_cast<int>(0x80000000u);
 }
 
 // (w.x * d.x, w.x * d.y) and (w.y * d.x, w.y * d.y): v_pk_mul_f32 reading ONE half of w for both products (op_sel).  The
 // compiler builds dup_x(w) * d from a register pair it first assembles with moves -- five v_mov_b32 per sweep for the four
-// face weights, in every sweep anew; the products are the same.
+// face weights, in every sweep anew; the products are the same.  (The compiler does not look into an asm statement when it
+// pads data hazards: the operands here are results of ordinary or packed arithmetic, never the direct result of a
+// transcendental instruction, which on gfx950 needs a wait state before an ordinary VALU instruction may read it.)
 __device__ __forceinline__ v2f mul_by_x(v2f w, v2f d)
 {
     v2f r;
@@ -620,7 +625,7 @@ __device__ __forceinline__ bool run_strip(const FusedArgs& a, int x, int xc, boo
         s.C[i].den = s.C[i].rden = v2f{1.f, 1.f};
     }
     s.p_fx = s.p_fy = s.p_ft = s.p_ksi = 0.f;
-    s.guard = DivGuard{0xffffffffu, 0u, 0u};
+    s.guard = DivGuard{0xffffffffu, 0u, 0u, 0x7fffffff};
 
     // first input row: the strip's first stored row needs INNER+1 rows of halo above it
     const int r_first = y0 - S::kHalo;
