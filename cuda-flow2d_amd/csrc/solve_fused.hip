@@ -340,6 +340,17 @@ __device__ __forceinline__ void strip_step(Strip<INNER, GRAD>& s, const FusedArg
         s.m_duv = a.zero_increment ? v2f{0.f, 0.f} : v2f{plane_load(a.du, off), plane_load(a.dv, off)};
     }
 
+#ifdef FLOW2D_FUSED_MEMORY_ONLY  // developer probe (timing only, wrong results): the strip's loads and stores without its arithmetic
+    {
+        const int rk = r - 2 - INNER;
+        if (lane_stores && rk >= y0 && rk < y1) {
+            const unsigned off = (static_cast<unsigned>(rk) * static_cast<unsigned>(a.pitch) + static_cast<unsigned>(xc)) * 4u;
+            plane_store(a.out_du, off, s.f0w[s0] + s.uvw[s0].x + s.duvw[s0].x);
+            plane_store(a.out_dv, off, s.f1w[s0] + s.uvw[s0].y + s.duvw[s0].y);
+        }
+        return;
+    }
+#endif
     constexpr bool run_P = T < 0 || T >= 2, run_W = T < 0 || T >= 3;
     if (T >= 0) __builtin_amdgcn_sched_barrier(0);  // keep the straight-line start-up from being interleaved across steps
 
