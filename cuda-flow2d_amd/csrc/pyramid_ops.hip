@@ -231,17 +231,17 @@ void launch_gauss_stream(flow2d_context* ctx, float* dst, const float* src, size
 template <bool kAlongX>
 __global__ __launch_bounds__(256) void resample_kernel(const float* __restrict__ in_a, float* __restrict__ out_a,
                                                        const float* __restrict__ in_b, float* __restrict__ out_b,
-                                                       int out_w, int out_h, int in_n, int pitch, BatchArg batch)
+                                                       int out_w, int out_h, int in_n, int pitch, float delta,
+                                                       float normalization, BatchArg batch)
 {
+    // delta = in_n / (float) out_n, normalization = out_n / (float) in_n (resample_2d.cu:46-47): the same for every
+    // output, so the host evaluates the two float divisions (the same IEEE operations) instead of every thread
     const float* __restrict__ in = (batch_plane(batch) ? in_b : in_a) + batch_offset(batch);
     float* __restrict__ out = (batch_plane(batch) ? out_b : out_a) + batch_offset(batch);
     const int x = blockIdx.x * kBlockX + threadIdx.x;
     const int y = blockIdx.y * kBlockY + threadIdx.y;
     if (x >= out_w || y >= out_h) return;
-    const int out_n = kAlongX ? out_w : out_h;
     const unsigned g = kAlongX ? x : y;
-    const float delta = static_cast<float>(in_n) / static_cast<float>(out_n);
-    const float normalization = static_cast<float>(out_n) / static_cast<float>(in_n);
     const float left_f = static_cast<float>(g) * delta;
     const float right_f = static_cast<float>(g + 1u) * delta;
     const int left_i = static_cast<int>(floorf(left_f));
@@ -281,53 +281,75 @@ __global__ __launch_bounds__(256) void resample_kernel(const float* __restrict__
 // values.  Same operations in the same order as resample_kernel<true> into a temp followed by resample_kernel<false>,
 // hence the same bits; the temp plane (as large as the output in x) is neither written nor read: 160 instead of 288 MB
 // for the two flow planes at 2048^2 -> 4096^2.
-__device__ __forceinline__ float resample_cells(const float* __restrict__ base, size_t stride, int in_n, int out_n, unsigned g)
-{
-    const float delta = static_cast<float>(in_n) / static_cast<float>(out_n);
-    const float normalization = static_cast<float>(out_n) / static_cast<float>(in_n);
-    const float left_f = static_cast<float>(g) * delta;
-    const float right_f = static_cast<float>(g + 1u) * delta;
-    const int left_i = static_cast<int>(floorf(left_f));
-    const int right_i = min(in_n, static_cast<int>(ceilf(right_f)));
-    const int cells = right_i - left_i;
-    float value = 0.f;
-    for (int j = 0; j < cells; ++j) {
-        float frac = 1.f;
-        if (j == 0) frac = static_cast<float>(left_i + 1) - left_f;
-        if (j == cells - 1) frac = right_f - static_cast<float>(left_i + j);
-        if (cells == 1) frac = delta;
-        value += base[static_cast<size_t>(left_i + j) * stride] * frac;
-    }
-    return value * normalization;
-}
+// (delta = in / out and normalization = out / in of either direction are the same for every output: the host evaluates
+//  the two float divisions -- the same IEEE operations -- once instead of every thread four times; an output's x cells and
+//  their fractions are worked out once and used for each input row of its y cells)
+constexpr int kResampleXYRows = 8;
+struct ResampleXY {
+    float delta_x, norm_x, delta_y, norm_y;
+};
 
 __global__ __launch_bounds__(256) void resample_xy_kernel(const float* __restrict__ in_a, float* __restrict__ out_a,
                                                           const float* __restrict__ in_b, float* __restrict__ out_b,
-                                                          int out_w, int out_h, int in_w, int in_h, int pitch, BatchArg batch)
+                                                          int out_w, int out_h, int in_w, int in_h, int pitch,
+                                                          ResampleXY k, BatchArg batch)
 {
     const float* __restrict__ in = (batch_plane(batch) ? in_b : in_a) + batch_offset(batch);
     float* __restrict__ out = (batch_plane(batch) ? out_b : out_a) + batch_offset(batch);
     const int x = blockIdx.x * kBlockX + threadIdx.x;
-    const int y = blockIdx.y * kBlockY + threadIdx.y;
-    if (x >= out_w || y >= out_h) return;
+    if (x >= out_w) return;
+    // the x cells of this output column (resample_2d.cu:46-55)
+    const float left_f = static_cast<float>(static_cast<unsigned>(x)) * k.delta_x;
+    const float right_f = static_cast<float>(static_cast<unsigned>(x) + 1u) * k.delta_x;
+    const int left_i = static_cast<int>(floorf(left_f));
+    const int cells_x = min(in_w, static_cast<int>(ceilf(right_f))) - left_i;
+    const float first_x = cells_x == 1 ? k.delta_x : static_cast<float>(left_i + 1) - left_f;
+    const float last_x = cells_x == 1 ? k.delta_x : right_f - static_cast<float>(left_i + cells_x - 1);
+    // a thread walks kResampleXYRows output rows of its column (a wave that lives for one output each spends its time
+    // being launched: 80 -> 51 us for the two 4096^2 flow planes)
+    for (int i = 0; i < kResampleXYRows; ++i) {
+    const int y = (blockIdx.y * kResampleXYRows + i) * kBlockY + threadIdx.y;
+    if (y >= out_h) return;
     // the y pass of resample_2d.cu:77-118 over x-pass values computed on the spot
-    const float delta = static_cast<float>(in_h) / static_cast<float>(out_h);
-    const float normalization = static_cast<float>(out_h) / static_cast<float>(in_h);
-    const float top_f = static_cast<float>(static_cast<unsigned>(y)) * delta;
-    const float bottom_f = static_cast<float>(static_cast<unsigned>(y) + 1u) * delta;
+    const float top_f = static_cast<float>(static_cast<unsigned>(y)) * k.delta_y;
+    const float bottom_f = static_cast<float>(static_cast<unsigned>(y) + 1u) * k.delta_y;
     const int top_i = static_cast<int>(floorf(top_f));
-    const int bottom_i = min(in_h, static_cast<int>(ceilf(bottom_f)));
-    const int cells = bottom_i - top_i;
+    const int cells = min(in_h, static_cast<int>(ceilf(bottom_f))) - top_i;
     float value = 0.f;
-    for (int j = 0; j < cells; ++j) {
-        float frac = 1.f;
-        if (j == 0) frac = static_cast<float>(top_i + 1) - top_f;
-        if (j == cells - 1) frac = bottom_f - static_cast<float>(top_i + j);
-        if (cells == 1) frac = delta;
-        const float x_pass = resample_cells(in + static_cast<size_t>(top_i + j) * pitch, 1, in_w, out_w, static_cast<unsigned>(x));
-        value += x_pass * frac;
+    if (cells_x <= 2 && cells <= 2) {
+        // up-sampling: an output has one or two cells in either direction (a third one only where the rounding of
+        // g * delta and (g + 1) * delta pushes them more than 1 apart) -- straight-line code, the second cell's
+        // product selected in or out; the sums start from 0.f and add in cell order like the loops below
+        const float* __restrict__ row0 = in + static_cast<size_t>(top_i) * pitch + left_i;
+        const float* __restrict__ row1 = in + static_cast<size_t>(min(top_i + 1, in_h - 1)) * pitch + left_i;
+        const int second = min(left_i + 1, in_w - 1) - left_i;
+        const float a0 = row0[0], a1 = row0[second], b0 = row1[0], b1 = row1[second];
+        float xa = 0.f + a0 * first_x, xb = 0.f + b0 * first_x;
+        const float xa2 = xa + a1 * last_x, xb2 = xb + b1 * last_x;
+        xa = cells_x == 2 ? xa2 : xa;
+        xb = cells_x == 2 ? xb2 : xb;
+        const float first_y = cells == 1 ? k.delta_y : static_cast<float>(top_i + 1) - top_f;
+        const float last_y = bottom_f - static_cast<float>(top_i + 1);
+        value = 0.f + (xa * k.norm_x) * first_y;
+        const float value2 = value + (xb * k.norm_x) * last_y;
+        value = cells == 2 ? value2 : value;
+    } else {
+        for (int j = 0; j < cells; ++j) {
+            float frac = 1.f;
+            if (j == 0) frac = static_cast<float>(top_i + 1) - top_f;
+            if (j == cells - 1) frac = bottom_f - static_cast<float>(top_i + j);
+            if (cells == 1) frac = k.delta_y;
+            const float* __restrict__ row = in + static_cast<size_t>(top_i + j) * pitch + left_i;
+            float x_pass = 0.f;  // the x pass of this input row: first cell, whole cells, last cell, in that order (:56-72)
+            for (int i = 0; i < cells_x; ++i) {
+                const float fx = i == 0 ? first_x : (i == cells_x - 1 ? last_x : 1.f);
+                x_pass += row[i] * fx;
+            }
+            value += (x_pass * k.norm_x) * frac;
+        }
     }
-    out[static_cast<size_t>(y) * pitch + x] = value * normalization;
+    out[static_cast<size_t>(y) * pitch + x] = value * k.norm_y;
+    }
 }
 
 // Down-sampling along x with a large ratio (the frames are resampled from FULL resolution at every level,
@@ -710,14 +732,16 @@ static int launch_resample(flow2d_context* ctx, bool along_x, const float* input
     else {
         dim3 grid = grid_for(out_width, out_height);
         grid.z = z;
+        const float out_n = static_cast<float>(along_x ? out_width : out_height), in_n = static_cast<float>(in_extent);
+        const float delta = in_n / out_n, normalization = out_n / in_n;
         if (along_x)
             resample_kernel<true><<<grid, dim3(kBlockX, kBlockY), 0, ctx->stream>>>(
                 input, output, input_b, output_b, (int)out_width, (int)out_height, (int)in_extent, (int)(pitch_bytes / 4),
-                batch);
+                delta, normalization, batch);
         else
             resample_kernel<false><<<grid, dim3(kBlockX, kBlockY), 0, ctx->stream>>>(
                 input, output, input_b, output_b, (int)out_width, (int)out_height, (int)in_extent, (int)(pitch_bytes / 4),
-                batch);
+                delta, normalization, batch);
     }
     FLOW2D_CHECK_LAUNCH();
     return FLOW2D_OK;
@@ -801,11 +825,15 @@ int flow2d_resample_xy_pair(flow2d_context* ctx, const float* input_a, float* ou
                  output_b == output_a || output_b == input_a || output_a == input_b))
         return FLOW2D_ERR_INVALID_ARGUMENT;
     const unsigned planes = pair ? 2 : 1;
-    dim3 grid = grid_for(out_width, out_height);
+    dim3 grid = grid_for(out_width, flow2d::div_up(out_height, kResampleXYRows));
     grid.z = flow2d::batch_z(ctx, planes);
+    const ResampleXY k{static_cast<float>(in_width) / static_cast<float>(out_width),
+                       static_cast<float>(out_width) / static_cast<float>(in_width),
+                       static_cast<float>(in_height) / static_cast<float>(out_height),
+                       static_cast<float>(out_height) / static_cast<float>(in_height)};
     resample_xy_kernel<<<grid, dim3(kBlockX, kBlockY), 0, ctx->stream>>>(
         input_a, output_a, input_b, output_b, (int)out_width, (int)out_height, (int)in_width, (int)in_height,
-        (int)(pitch_bytes / 4), flow2d::batch_arg(ctx, planes));
+        (int)(pitch_bytes / 4), k, flow2d::batch_arg(ctx, planes));
     FLOW2D_CHECK_LAUNCH();
     return FLOW2D_OK;
 }

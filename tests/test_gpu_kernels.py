@@ -72,7 +72,7 @@ def test_resample(ctx, oracle, w, h, ow, oh):
 
 @pytest.mark.parametrize("w,h,ow,oh", [(37, 20, 100, 70), (33, 17, 34, 18), (50, 35, 100, 70), (64, 64, 64, 64), (2, 3, 257, 130),
                                        (512, 270, 1024, 540), (231, 130, 461, 260), (100, 70, 37, 20), (300, 40, 150, 80),
-                                       (1000, 37, 77, 90)])
+                                       (1000, 37, 77, 90), (4095, 3, 4096, 5), (3, 4093, 4, 4096), (2047, 9, 2049, 10)])
 def test_resample_xy(ctx, oracle, w, h, ow, oh):
     """Both passes in one launch (no temp plane): the bits of the x pass into a temp followed by the y pass, for one plane
     and for two, up-sampling (what the operator routes here) and any other ratio."""

@@ -43,6 +43,8 @@ def main():
         ("resample y to 1/128 at width n/128 (coarsest level)", lambda: ctx.resample_y(a, out, n // 128, n // 128, n), 1 / 128),
         ("resample y to 1/32 at width n/32", lambda: ctx.resample_y(a, out, n // 32, n // 32, n), 1 / 32),
         ("resample x to 0.9", lambda: ctx.resample_x(a, tmp, int(n * 0.9), n, n), 1.9),
+        ("resample x and y from 1/2 (two planes, one launch)", lambda: ctx.resample_xy(a, out, n // 2, n // 2, n, n, b, tmp), 2.5),
+        ("median 5 of a + b (two planes)", lambda: ctx.add_median(a, b, n, n, 5, out, c, d, tmp), 6),
     ]
     for name, fn, planes in rows:
         us = timed(ctx, fn)
