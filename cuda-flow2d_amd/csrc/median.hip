@@ -223,42 +223,45 @@ __device__ __forceinline__ float lane_right(float v)  // lane i <- lane i+1
 
 constexpr int kStreamValid = 60;  // lanes 2..61 of a wave have both neighbours on either side
 
-// the values a lane loads for one image row: its own column, or (EDGE) the five mirrored columns
-template <bool EDGE>
+// the values a lane loads for one image row: its own column, or (EDGE) the five mirrored columns -- RAW, as they come
+// from memory: the sum with the addend and the NaN / -0 check happen where the row is consumed (sorted_tuple), two
+// steps later, so that nothing waits for a load at the place it is issued
+template <bool EDGE, bool ADD>
 struct RowLoad {
     float v[EDGE ? 5 : 1];
+    float a[ADD ? (EDGE ? 5 : 1) : 1];
 };
 
-// `special` collects whether any value this lane loaded is a NaN or a -0 (one v_cmp_class per load; the strip is
-// re-checked per pixel only when some lane of the wave saw one)
 template <bool EDGE, bool ADD>
-__device__ __forceinline__ RowLoad<EDGE> load_row(const Source<ADD> in, int row, int h, int pitch, int xc,
-                                                  const int (&xm)[5], bool& special)
+__device__ __forceinline__ RowLoad<EDGE, ADD> load_row(const Source<ADD> in, int row, int h, int pitch, int xc,
+                                                       const int (&xm)[5])
 {
     const size_t line = static_cast<size_t>(min(max(mirror_index(row, h), 0), h - 1)) * pitch;
-    RowLoad<EDGE> r;
-    if (EDGE) {
+    RowLoad<EDGE, ADD> r;
+    r.a[0] = 0.f;
 #pragma unroll
-        for (int i = 0; i < 5; ++i) {
-            r.v[i] = in[line + xm[i]];
-            special |= is_special(r.v[i]);
-        }
-    } else {
-        r.v[0] = in[line + xc];
-        special |= is_special(r.v[0]);
+    for (int i = 0; i < (EDGE ? 5 : 1); ++i) {
+        const size_t at = line + (EDGE ? xm[i] : xc);
+        r.v[i] = in.in[at];
+        if (ADD) r.a[i] = in.add[at];
     }
     return r;
 }
 
-// sorted 5-tuple (x-2 .. x+2) of the loaded row
-template <bool EDGE>
-__device__ __forceinline__ void sorted_tuple(const RowLoad<EDGE>& r, float (&t)[5])
+// sorted 5-tuple (x-2 .. x+2) of the loaded row.  `special` collects whether any value this lane loaded is a NaN or a
+// -0 (one v_cmp_class per value; the strip is re-checked per pixel only when some lane of the wave saw one)
+template <bool EDGE, bool ADD>
+__device__ __forceinline__ void sorted_tuple(const RowLoad<EDGE, ADD>& r, float (&t)[5], bool& special)
 {
     if (EDGE) {
 #pragma unroll
-        for (int i = 0; i < 5; ++i) t[i] = r.v[i];
+        for (int i = 0; i < 5; ++i) {
+            t[i] = ADD ? r.v[i] + r.a[i] : r.v[i];
+            special |= is_special(t[i]);
+        }
     } else {
-        const float c = r.v[0];
+        const float c = ADD ? r.v[0] + r.a[0] : r.v[0];
+        special |= is_special(c);
         const float l1 = lane_left(c), r1 = lane_right(c);
         t[0] = lane_left(l1);
         t[1] = l1;
@@ -272,15 +275,18 @@ __device__ __forceinline__ void sorted_tuple(const RowLoad<EDGE>& r, float (&t)[
 // One wave, one strip of 64 columns, rows [y0, y1).  Step I of three (the ring of six row slots advances by
 // two rows per step, so three steps bring every slot back to its place and all indices are constants).
 template <bool EDGE, int I, bool ADD>
-__device__ __forceinline__ void median5_step(float (&ring)[6][5], RowLoad<EDGE> (&next)[2], const Source<ADD> in,
+__device__ __forceinline__ void median5_step(float (&ring)[6][5], RowLoad<EDGE, ADD> (&next)[4], const Source<ADD> in,
                                              float* __restrict__ out, int ya, int y1, int h, int pitch, int x, int xc,
                                              const int (&xm)[5], bool lane_stores, bool& special)
 {
-    // rows ya+2 and ya+3 were requested one step ago; request the two after them before working
-    sorted_tuple<EDGE>(next[0], ring[(2 * I + 4) % 6]);
-    sorted_tuple<EDGE>(next[1], ring[(2 * I + 5) % 6]);
-    next[0] = load_row<EDGE, ADD>(in, ya + 4, h, pitch, xc, xm, special);
-    next[1] = load_row<EDGE, ADD>(in, ya + 5, h, pitch, xc, xm, special);
+    // rows ya+2 and ya+3 were requested two steps ago (a step is shorter than the way to memory and back, and with one
+    // step of distance the wait for the rows also waited for the previous step's stores); request rows ya+6, ya+7
+    sorted_tuple<EDGE, ADD>(next[0], ring[(2 * I + 4) % 6], special);
+    sorted_tuple<EDGE, ADD>(next[1], ring[(2 * I + 5) % 6], special);
+    next[0] = next[2];
+    next[1] = next[3];
+    next[2] = load_row<EDGE, ADD>(in, ya + 6, h, pitch, xc, xm);
+    next[3] = load_row<EDGE, ADD>(in, ya + 7, h, pitch, xc, xm);
     float v[kMedianPairWires];
 #pragma unroll
     for (int g = 0; g < 6; ++g)
@@ -307,16 +313,16 @@ __device__ __forceinline__ void median5_strip(const Source<ADD> in, float* __res
     bool special = false;
     // rows y0-2 .. y0+1 fill slots 0..3; rows y0+2, y0+3 are the first pair in flight
     {
-        RowLoad<EDGE> first[4];
+        RowLoad<EDGE, ADD> first[4];
 #pragma unroll
-        for (int g = 0; g < 4; ++g) first[g] = load_row<EDGE, ADD>(in, y0 - 2 + g, h, pitch, xc, xm, special);
+        for (int g = 0; g < 4; ++g) first[g] = load_row<EDGE, ADD>(in, y0 - 2 + g, h, pitch, xc, xm);
 #pragma unroll
-        for (int g = 0; g < 4; ++g) sorted_tuple<EDGE>(first[g], ring[g]);
+        for (int g = 0; g < 4; ++g) sorted_tuple<EDGE, ADD>(first[g], ring[g], special);
 #pragma unroll
         for (int e = 0; e < 5; ++e) ring[4][e] = ring[5][e] = 0.f;
     }
-    RowLoad<EDGE> next[2] = {load_row<EDGE, ADD>(in, y0 + 2, h, pitch, xc, xm, special),
-                             load_row<EDGE, ADD>(in, y0 + 3, h, pitch, xc, xm, special)};
+    RowLoad<EDGE, ADD> next[4] = {load_row<EDGE, ADD>(in, y0 + 2, h, pitch, xc, xm), load_row<EDGE, ADD>(in, y0 + 3, h, pitch, xc, xm),
+                                  load_row<EDGE, ADD>(in, y0 + 4, h, pitch, xc, xm), load_row<EDGE, ADD>(in, y0 + 5, h, pitch, xc, xm)};
     for (int ya = y0; ya < y1; ya += 6) {
         median5_step<EDGE, 0, ADD>(ring, next, in, out, ya, y1, h, pitch, x, xc, xm, lane_stores, special);
         if (ya + 2 >= y1) break;

@@ -149,17 +149,29 @@ __device__ __forceinline__ float blur_row_sum(float c, const GaussTaps& taps)
 }
 
 // Step J of 2R+1: image row `ry` enters ring slot J, output row ry - R leaves.
+// keep ? v : +0.f as a bit mask.  (Written as a select, the compiler turns it into a branch around the LOAD of v with a
+// wait for it inside: every row's load was waited for where it was issued, and a wave walked its strip one memory
+// latency per row.)
+__device__ __forceinline__ float value_or_zero(float v, bool keep)
+{
+    return __int_as_float(__float_as_int(v) & -static_cast<int>(keep));
+}
+
+constexpr int kBlurAhead = 4;  // image rows in flight per lane: a wave has one load per row, and a row is a microsecond away
+
 template <int R, int J>
-__device__ __forceinline__ void blur_step(float (&ring)[2 * R + 1], float& next, float* __restrict__ dst,
+__device__ __forceinline__ void blur_step(float (&ring)[2 * R + 1], float (&next)[kBlurAhead], float* __restrict__ dst,
                                           const float* __restrict__ src, int ry, int y0, int y1, int h, int pitch,
                                           int xc, bool in_image, bool lane_stores, const GaussTaps& taps)
 {
     constexpr int N = 2 * R + 1;
-    const float c = next;  // row ry, requested one step ago
+    const float c = next[0];  // row ry, requested kBlurAhead steps ago
     {
-        const int rn = ry + 1;
+#pragma unroll
+        for (int i = 0; i + 1 < kBlurAhead; ++i) next[i] = next[i + 1];
+        const int rn = ry + kBlurAhead;
         const float v = src[static_cast<size_t>(min(max(rn, 0), h - 1)) * pitch + xc];
-        next = (in_image && rn >= 0 && rn < h) ? v : 0.f;
+        next[kBlurAhead - 1] = value_or_zero(v, in_image && rn >= 0 && rn < h);
     }
     ring[J] = blur_row_sum<R>(c, taps);
     const int yo = ry - R;
@@ -172,7 +184,7 @@ __device__ __forceinline__ void blur_step(float (&ring)[2 * R + 1], float& next,
 }
 
 template <int R, size_t... Js>
-__device__ __forceinline__ void blur_steps(float (&ring)[2 * R + 1], float& next, float* __restrict__ dst,
+__device__ __forceinline__ void blur_steps(float (&ring)[2 * R + 1], float (&next)[kBlurAhead], float* __restrict__ dst,
                                            const float* __restrict__ src, int ry, int y0, int y1, int h, int pitch,
                                            int xc, bool in_image, bool lane_stores, const GaussTaps& taps,
                                            std::index_sequence<Js...>)
@@ -204,10 +216,12 @@ __global__ __launch_bounds__(256) void gauss_stream_kernel(float* __restrict__ d
     for (int i = 0; i < N; ++i) ring[i] = 0.f;
     // rows y0-R .. y1-1+R go through the rows pass (rows outside the image are zero rows)
     const int r_first = y0 - R, r_last = y1 - 1 + R;
-    float next;
-    {
-        const float v = src[static_cast<size_t>(min(max(r_first, 0), h - 1)) * pitch + xc];
-        next = (in_image && r_first >= 0 && r_first < h) ? v : 0.f;
+    float next[kBlurAhead];
+#pragma unroll
+    for (int i = 0; i < kBlurAhead; ++i) {
+        const int rn = r_first + i;
+        const float v = src[static_cast<size_t>(min(max(rn, 0), h - 1)) * pitch + xc];
+        next[i] = value_or_zero(v, in_image && rn >= 0 && rn < h);
     }
     for (int ry = r_first; ry <= r_last; ry += N)
         blur_steps<R>(ring, next, dst, src, ry, y0, y1, h, pitch, xc, in_image, lane_stores, taps,
