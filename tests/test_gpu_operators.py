@@ -106,6 +106,42 @@ def test_registration_and_resample(flow2d, oracle, rig):
     assert np.array_equal(dst.download(37, 20), want)
 
 
+def test_median_with_addend_and_resample_upwards(flow2d, oracle, rig):
+    """The two one-launch forms the pyramid uses, through the operator bags: the median operator's optional dev_addend /
+    dev_addend_b keys (filter of input + addend; the input planes stay as they were; width 1 = add, then copy) and the
+    resample operator when both directions up-sample (both passes in one launch, dev_temp unused)."""
+    up, make = rig
+    _, _, u, v, *_ = level_fields(oracle, W, H, 23)
+    rng = np.random.default_rng(3)
+    du, dv = (rng.normal(0, 0.2, (H, W)).astype(np.float32) for _ in range(2))
+    size = flow2d.DataSize3(W, H, 0)
+    pu, pv, pdu, pdv, ou, ov = up("u", u), up("v", v), up("du", du), up("dv", dv), up("ou"), up("ov")
+    med = make("median")
+    for radius, want in ((5, 5), (4, 3), (7, 7)):
+        med.execute(dev_input=dp(pu), dev_output=dp(ou), dev_input_b=dp(pv), dev_output_b=dp(ov), dev_addend=dp(pdu),
+                    dev_addend_b=dp(pdv), data_size=size, radius=C.c_size_t(radius))
+        assert np.array_equal(ou.download(W, H), oracle.median(oracle.add(u, du, W, H), W, H, want))
+        assert np.array_equal(ov.download(W, H), oracle.median(oracle.add(v, dv, W, H), W, H, want))
+        assert np.array_equal(pu.download(W, H), u) and np.array_equal(pv.download(W, H), v)
+    single = up("single")
+    med.execute(dev_input=dp(pu), dev_output=dp(single), dev_addend=dp(pdu), data_size=size, radius=C.c_size_t(3))
+    assert np.array_equal(single.download(W, H), oracle.median(oracle.add(u, du, W, H), W, H, 3))
+    # width 1: no filter to carry the sum, so the operator adds in place (like the reference's add) and copies
+    med.execute(dev_input=dp(pu), dev_output=dp(ou), dev_input_b=dp(pv), dev_output_b=dp(ov), dev_addend=dp(pdu),
+                dev_addend_b=dp(pdv), data_size=size, radius=C.c_size_t(1))
+    assert np.array_equal(ou.download(W, H), oracle.add(u, du, W, H)) and np.array_equal(ov.download(W, H), oracle.add(v, dv, W, H))
+    assert np.array_equal(pu.download(W, H), oracle.add(u, du, W, H))
+
+    small = flow2d.DataSize3(37, 20, 0)
+    a, b = u[:20, :37].copy(), v[:20, :37].copy()
+    sa, sb, da, db, ta, tb = up("sa", a), up("sb", b), up("da"), up("db"), up("ta"), up("tb")
+    make("resample").execute(dev_input=dp(sa), dev_output=dp(da), dev_temp=dp(ta), dev_input_b=dp(sb), dev_output_b=dp(db),
+                             dev_temp_b=dp(tb), data_size=small, resample_size=size)
+    assert np.array_equal(da.download(W, H), oracle.resample(in_container(a, CW, CH), 37, 20, W, H)[:H, :W])
+    assert np.array_equal(db.download(W, H), oracle.resample(in_container(b, CW, CH), 37, 20, W, H)[:H, :W])
+    assert np.all(ta.download().view(np.uint32) == 0x7f7f7f7f)  # the temp plane is not touched on this route
+
+
 @pytest.mark.parametrize("constancy", [0, 1])
 @pytest.mark.parametrize("outer,inner", [(2, 3), (3, 5)])
 def test_solve_operator_swaps_callers_pointers(flow2d, oracle, rig, constancy, outer, inner):
