@@ -31,6 +31,9 @@ private:
 
 // keys: dev_input, dev_output (DevicePtr), data_size (DataSize3), radius (size_t; the window width).
 // cuda_operation_median_2d.cpp:77-155
+// Optional, not in the reference's bag: dev_input_b, dev_output_b (a second plane in the same launch); dev_addend,
+// dev_addend_b (the filter runs over input + addend formed on the fly -- the pyramid's add_2d followed by median_2d in
+// one launch; the input planes are not modified, except for width 1, where the operator adds in place and copies).
 class CudaOperationMedian2D : public CudaOperationBase {
 public:
     CudaOperationMedian2D() : CudaOperationBase("CUDA Median 2D") {}
@@ -47,6 +50,8 @@ public:
 
 // keys: dev_input, dev_output, dev_temp (DevicePtr), data_size, resample_size (DataSize3).
 // cuda_operation_resample_2d.cpp:76-107
+// Optional second plane set: dev_input_b, dev_output_b, dev_temp_b.  When both directions up-sample, the two passes run
+// in one launch and dev_temp is left untouched (same results).
 class CudaOperationResample2D : public CudaOperationBase {
 public:
     CudaOperationResample2D() : CudaOperationBase("CUDA Resample 2D") {}
