@@ -332,7 +332,11 @@ __device__ __forceinline__ void strip_step(Strip<INNER, GRAD>& s, const FusedArg
     }
     {  // row r+1 arrived a step ago; fetch row r+2 (clamped: rows outside the image are never used by a stored pixel)
         s.n_f0 = s.m_f0, s.n_f1 = s.m_f1, s.n_uv = s.m_uv, s.n_duv = s.m_duv;
+#ifdef FLOW2D_FUSED_COMPUTE_ONLY  // developer probe (timing only, wrong results): every row folded onto eight cache-resident rows
+        const int rn = (r + 2) & 7;
+#else
         const int rn = min(max(r + 2, 0), h - 1);
+#endif
         const unsigned off = (static_cast<unsigned>(rn) * static_cast<unsigned>(a.pitch) + static_cast<unsigned>(xc)) * 4u;
         s.m_f0 = plane_load(a.f0, off);
         s.m_f1 = plane_load(a.f1, off);
@@ -567,7 +571,11 @@ __device__ __forceinline__ void strip_step(Strip<INNER, GRAD>& s, const FusedArg
             dv_in = s.dvc[k];      // dv^k of row r-3-k, produced by this sweep one step ago
             s.dvc[k] = dv_new;     // dv^k of row r-2-k, for the next step
         } else if (lane_stores && rk >= y0 && rk < y1) {
+#ifdef FLOW2D_FUSED_COMPUTE_ONLY
+            const unsigned off = (static_cast<unsigned>(rk & 7) * static_cast<unsigned>(a.pitch) + static_cast<unsigned>(xc)) * 4u;
+#else
             const unsigned off = (static_cast<unsigned>(rk) * static_cast<unsigned>(a.pitch) + static_cast<unsigned>(xc)) * 4u;
+#endif
             plane_store(a.out_du, off, du_new);
             plane_store(a.out_dv, off, dv_new);
         }
