@@ -165,6 +165,11 @@ __device__ __forceinline__ float half_inverse_root(float s, float& twice_root)
 //   zero: signed min of the raw bits of every flow value read: INT_MIN exactly when one of them is a -0
 //   den : max of bits(den) - bits(2^-30): above kDenSpan for a denominator outside [2^-30, 2^40], negative or NaN
 //   out : max of bits(du, dv) << 1 over the stored results: above kOutLimit for an infinity or a NaN
+#ifdef FLOW2D_FUSED_NO_PINS  // developer switch: let the scheduler place the guard updates
+#define FLOW2D_GUARD_PIN(x) ((void)0)
+#else
+#define FLOW2D_GUARD_PIN(x) asm volatile("" : "+v"(x))
+#endif
 struct DivGuard {
     unsigned tiny, den, out;
     int zero;
@@ -177,7 +182,7 @@ constexpr unsigned kOutLimit = 0xfefffffeu;                    // FLT_MAX << 1
 __device__ __forceinline__ void guard_numerators(DivGuard& g, float nu, float nv)
 {
     g.tiny = min(g.tiny, min((__float_as_uint(nu) << 1) - 1u, (__float_as_uint(nv) << 1) - 1u));
-    asm volatile("" : "+v"(g.tiny));
+    FLOW2D_GUARD_PIN(g.tiny);
 }
 __device__ __forceinline__ void guard_flow_row(DivGuard& g, v2f uv, v2f duv)
 {
@@ -185,17 +190,17 @@ __device__ __forceinline__ void guard_flow_row(DivGuard& g, v2f uv, v2f duv)
     // reaches INT_MIN exactly when some value is a -0 (two v_min3_i32 per row instead of four v_xor and two minima)
     g.zero = min(min(g.zero, __float_as_int(uv.x)), __float_as_int(uv.y));
     g.zero = min(min(g.zero, __float_as_int(duv.x)), __float_as_int(duv.y));
-    asm volatile("" : "+v"(g.zero));
+    FLOW2D_GUARD_PIN(g.zero);
 }
 __device__ __forceinline__ void guard_denominators(DivGuard& g, float du, float dv)
 {
     g.den = max(g.den, max(__float_as_uint(du) - kDenLow, __float_as_uint(dv) - kDenLow));
-    asm volatile("" : "+v"(g.den));
+    FLOW2D_GUARD_PIN(g.den);
 }
 __device__ __forceinline__ void guard_results(DivGuard& g, float du, float dv)
 {
     g.out = max(g.out, max(__float_as_uint(du) << 1, __float_as_uint(dv) << 1));
-    asm volatile("" : "+v"(g.out));
+    FLOW2D_GUARD_PIN(g.out);
 }
 // x / d for the grid-spacing divisors 2h and 4h (wave-uniform; y = RN(1 / d) comes from the host): an exact multiply
 // when they are powers of two, the three-step division under the numerator guard otherwise, the plain division in the
@@ -206,7 +211,7 @@ __device__ __forceinline__ float spacing_quotient(DivGuard& g, float n, float d,
     if (POW2) return n * y;
     if (!FAST) return n / d;
     g.tiny = min(g.tiny, (__float_as_uint(n) << 1) - 1u);
-    asm volatile("" : "+v"(g.tiny));
+    FLOW2D_GUARD_PIN(g.tiny);
     return div3(n, d, y);
 }
 template <bool POW2, bool FAST>
