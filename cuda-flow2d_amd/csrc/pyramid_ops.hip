@@ -518,9 +518,13 @@ __global__ __launch_bounds__(256) void resample_x_levels_kernel(const float* __r
 }
 
 // ---- backward registration: src/kernels/registration_2d.cu:34-73 --------------------------------
+// (1.f / hx and 1.f / hy are the same for every pixel: evaluated by the host, the same IEEE division.  A thread takes
+//  kRegistrationRows pixels of its column: their flow values are requested together, then the four frame values each.)
+constexpr int kRegistrationRows = 4;
+
 __global__ __launch_bounds__(256) void registration_kernel(const float* __restrict__ f0, const float* __restrict__ f1,
                                                            const float* __restrict__ u, const float* __restrict__ v,
-                                                           int w, int h, int pitch, float hx, float hy,
+                                                           int w, int h, int pitch, float inv_hx, float inv_hy,
                                                            float* __restrict__ out, BatchArg batch)
 {
     f0 += batch_offset(batch);
@@ -529,28 +533,40 @@ __global__ __launch_bounds__(256) void registration_kernel(const float* __restri
     v += batch_offset(batch);
     out += batch_offset(batch);
     const int gx = blockIdx.x * kBlockX + threadIdx.x;
-    const int gy = blockIdx.y * kBlockY + threadIdx.y;
-    if (gx >= w || gy >= h) return;
-    const size_t c = static_cast<size_t>(gy) * pitch + gx;
-    const float x_f = static_cast<float>(gx) + (u[c] * (1.f / hx));
-    const float y_f = static_cast<float>(gy) + (v[c] * (1.f / hy));
-    float value;
-    if ((x_f < 0.f) || (x_f > static_cast<float>(w - 1)) || (y_f < 0.f) || (y_f > static_cast<float>(h - 1)) ||
-        isnan(x_f) || isnan(y_f)) {
-        value = f0[c];
-    } else {
-        const int x = static_cast<int>(floorf(x_f));
-        const int y = static_cast<int>(floorf(y_f));
-        const float dx = x_f - static_cast<float>(x);
-        const float dy = y_f - static_cast<float>(y);
-        const int x1 = min(w - 1, x + 1);
-        const int y1 = min(h - 1, y + 1);
-        const float* r0 = f1 + static_cast<size_t>(y) * pitch;
-        const float* r1 = f1 + static_cast<size_t>(y1) * pitch;
-        value = (1.f - dx) * (1.f - dy) * r0[x] + (dx) * (1.f - dy) * r0[x1] + (1.f - dx) * (dy)*r1[x] +
-                (dx) * (dy)*r1[x1];
+    if (gx >= w) return;
+    float uu[kRegistrationRows], vv[kRegistrationRows];
+#pragma unroll
+    for (int i = 0; i < kRegistrationRows; ++i) {
+        const int gy = min((blockIdx.y * kRegistrationRows + i) * kBlockY + threadIdx.y, h - 1);
+        const size_t c = static_cast<size_t>(gy) * pitch + gx;
+        uu[i] = u[c];
+        vv[i] = v[c];
     }
-    out[c] = value;
+#pragma unroll
+    for (int i = 0; i < kRegistrationRows; ++i) {
+        const int gy = (blockIdx.y * kRegistrationRows + i) * kBlockY + threadIdx.y;
+        if (gy >= h) return;
+        const size_t c = static_cast<size_t>(gy) * pitch + gx;
+        const float x_f = static_cast<float>(gx) + (uu[i] * inv_hx);
+        const float y_f = static_cast<float>(gy) + (vv[i] * inv_hy);
+        float value;
+        if ((x_f < 0.f) || (x_f > static_cast<float>(w - 1)) || (y_f < 0.f) || (y_f > static_cast<float>(h - 1)) ||
+            isnan(x_f) || isnan(y_f)) {
+            value = f0[c];
+        } else {
+            const int x = static_cast<int>(floorf(x_f));
+            const int y = static_cast<int>(floorf(y_f));
+            const float dx = x_f - static_cast<float>(x);
+            const float dy = y_f - static_cast<float>(y);
+            const int x1 = min(w - 1, x + 1);
+            const int y1 = min(h - 1, y + 1);
+            const float* r0 = f1 + static_cast<size_t>(y) * pitch;
+            const float* r1 = f1 + static_cast<size_t>(y1) * pitch;
+            value = (1.f - dx) * (1.f - dy) * r0[x] + (dx) * (1.f - dy) * r0[x1] + (1.f - dx) * (dy)*r1[x] +
+                    (dx) * (dy)*r1[x1];
+        }
+        out[c] = value;
+    }
 }
 
 }  // namespace
@@ -864,10 +880,10 @@ int flow2d_registration_2d(flow2d_context* ctx, const float* frame_0, const floa
         !flow2d::plane_args_ok(output, width, height, pitch_bytes) || output == frame_1 || output == frame_0 ||
         !(hx > 0.f) || !(hy > 0.f))
         return FLOW2D_ERR_INVALID_ARGUMENT;
-    dim3 grid = grid_for(width, height);
+    dim3 grid = grid_for(width, flow2d::div_up(height, kRegistrationRows));
     grid.z = flow2d::batch_z(ctx, 1);
     registration_kernel<<<grid, dim3(kBlockX, kBlockY), 0, ctx->stream>>>(
-        frame_0, frame_1, flow_u, flow_v, (int)width, (int)height, (int)(pitch_bytes / 4), hx, hy, output,
+        frame_0, frame_1, flow_u, flow_v, (int)width, (int)height, (int)(pitch_bytes / 4), 1.f / hx, 1.f / hy, output,
         flow2d::batch_arg(ctx, 1));
     FLOW2D_CHECK_LAUNCH();
     return FLOW2D_OK;
