@@ -246,15 +246,19 @@ template <bool kAlongX>
 __global__ __launch_bounds__(256) void resample_kernel(const float* __restrict__ in_a, float* __restrict__ out_a,
                                                        const float* __restrict__ in_b, float* __restrict__ out_b,
                                                        int out_w, int out_h, int in_n, int pitch, float delta,
-                                                       float normalization, BatchArg batch)
+                                                       float normalization, int rows_per_thread, BatchArg batch)
 {
     // delta = in_n / (float) out_n, normalization = out_n / (float) in_n (resample_2d.cu:46-47): the same for every
     // output, so the host evaluates the two float divisions (the same IEEE operations) instead of every thread
     const float* __restrict__ in = (batch_plane(batch) ? in_b : in_a) + batch_offset(batch);
     float* __restrict__ out = (batch_plane(batch) ? out_b : out_a) + batch_offset(batch);
     const int x = blockIdx.x * kBlockX + threadIdx.x;
-    const int y = blockIdx.y * kBlockY + threadIdx.y;
-    if (x >= out_w || y >= out_h) return;
+    if (x >= out_w) return;
+    // a thread takes rows_per_thread outputs of its column: four on the finer levels (one output per thread was bound by
+    // wave launches there), one on the coarse ones (few outputs, each a long chain of cells)
+    for (int row = 0; row < rows_per_thread; ++row) {
+    const int y = (blockIdx.y * rows_per_thread + row) * kBlockY + threadIdx.y;
+    if (y >= out_h) return;
     const unsigned g = kAlongX ? x : y;
     const float left_f = static_cast<float>(g) * delta;
     const float right_f = static_cast<float>(g + 1u) * delta;
@@ -287,6 +291,7 @@ __global__ __launch_bounds__(256) void resample_kernel(const float* __restrict__
         value += base[static_cast<size_t>(left_i + j) * stride] * frac;
     }
     out[static_cast<size_t>(y) * pitch + x] = value * normalization;
+    }
 }
 
 // Both passes in one launch, for up-sampling (the flow of the previous pyramid level, optical_flow_2d.cpp:320-345): every
@@ -760,18 +765,19 @@ static int launch_resample(flow2d_context* ctx, bool along_x, const float* input
                                 ctx->stream>>>(input, output, input_b, output_b, (int)out_width, (int)out_height,
                                                (int)in_extent, (int)(pitch_bytes / 4), batch);
     else {
-        dim3 grid = grid_for(out_width, out_height);
+        const int rows_per_thread = out_width * out_height >= (size_t)512 * 512 ? 4 : 1;
+        dim3 grid = grid_for(out_width, flow2d::div_up(out_height, rows_per_thread));
         grid.z = z;
         const float out_n = static_cast<float>(along_x ? out_width : out_height), in_n = static_cast<float>(in_extent);
         const float delta = in_n / out_n, normalization = out_n / in_n;
         if (along_x)
             resample_kernel<true><<<grid, dim3(kBlockX, kBlockY), 0, ctx->stream>>>(
                 input, output, input_b, output_b, (int)out_width, (int)out_height, (int)in_extent, (int)(pitch_bytes / 4),
-                delta, normalization, batch);
+                delta, normalization, rows_per_thread, batch);
         else
             resample_kernel<false><<<grid, dim3(kBlockX, kBlockY), 0, ctx->stream>>>(
                 input, output, input_b, output_b, (int)out_width, (int)out_height, (int)in_extent, (int)(pitch_bytes / 4),
-                delta, normalization, batch);
+                delta, normalization, rows_per_thread, batch);
     }
     FLOW2D_CHECK_LAUNCH();
     return FLOW2D_OK;
