@@ -359,13 +359,13 @@ class Job:
         self.single = cfg["pairs_per_rank"] == 1
         self.grouped = not self.single and args.batch_mode == "groups"
         self.group = cfg["pairs_per_rank"] if self.grouped else 1
-        # Mid-size single-pair workloads (config 2): consecutive STEPS are handed to the batch entry `step_group` at a time
+        # Single-pair workloads up to 4096^2 (configs 2 and 3): consecutive STEPS are handed to the batch entry `step_group` at a time
         # as independent pairs in planes of their own, and the C++ object forms a lock-step group of them itself
         # (OpticalFlowBatch2D::ComputeFlowBatchDeviceGrouped: gather, one launch per kernel for the group, hand back).
         # A step is still one pair's whole pyramid; K steps are K pairs.
         self.step_group = 1
         if self.single:
-            self.step_group = args.step_group if args.step_group > 0 else (4 if w * h <= 2048 * 2048 else 1)
+            self.step_group = args.step_group if args.step_group > 0 else (4 if w * h <= 2048 * 2048 else (2 if w * h <= 4096 * 4096 else 1))
         self.pending = []
         self.rotate = self.single or self.grouped  # a step is one entry; steps rotate over the lanes
         self.n_lanes = max(1, min(args.max_lanes, args.pipeline if self.rotate else cfg["pairs_per_rank"] * args.pipeline))
@@ -767,9 +767,8 @@ def main():
     ap.add_argument("--max-lanes", type=int, default=4, help="upper bound on the lanes (streams) per GPU")
     ap.add_argument("--step-group", type=int, default=0,
                     help="single-pair workloads: consecutive steps handed to the batch entry this many at a time, which "
-                         "forms a lock-step group of them (0 = automatic: 4 up to 2048^2, else 1; 2 at 4096^2 is worth "
-                         "+3.5 %, but the default keeps one pair per launch there so that the kernel trace of the default "
-                         "command shows the launches the roofline block describes)")
+                         "forms a lock-step group of them (0 = automatic: 4 up to 2048^2, 2 up to 4096^2, else 1; the "
+                         "finest level of a 4096^2 group still runs one launch per pair)")
     ap.add_argument("--batch-mode", choices=["groups", "lanes"], default="groups",
                     help="batched workloads: all pairs of a step as one lock-step group (every kernel launched once for "
                          "the group) or spread one by one over the lanes")

@@ -829,7 +829,7 @@ struct FusedPlan {
 // EDGE body / interior body: 1.2-1.26 in VALU instructions per row step; FLOW2D_FUSED_EDGE_COST overrides (developer knob)
 static const double kEdgeCost = std::getenv("FLOW2D_FUSED_EDGE_COST") ? std::atof(std::getenv("FLOW2D_FUSED_EDGE_COST")) : 1.22;
 
-FusedPlan fused_plan(const flow2d_context* ctx, size_t w, size_t h, size_t inner)
+FusedPlan fused_plan(const flow2d_context* ctx, size_t w, size_t h, size_t inner, long instances)
 {
     const int valid = 64 - 2 * ((int)inner + 1);
     const long blocks_x = (div_up(w, valid) + 3) / 4;
@@ -840,7 +840,7 @@ FusedPlan fused_plan(const flow2d_context* ctx, size_t w, size_t h, size_t inner
     double saved = 2 * 102.0 + 3 * 20.0;
     for (int k = 1; k <= (int)inner; ++k) saved += 46.0 * std::min(3 + 2 * k, peel);
     const double halo = (double)(2 * (long)inner + 3) - saved / (138.0 + 46.0 * (double)inner);  // the last ring turn is partial
-    const long batch = (long)ctx->batch_count;  // the instances of a batched launch share the chip
+    const long batch = instances;  // the instances of a batched launch share the chip
     auto rounds = [&](long blocks, double slowest) {
         const long full = blocks / cap, rem = blocks % cap;
         return full * 2.0 * slowest + (rem == 0 ? 0.0 : (rem <= cus ? 1.3 * slowest : 2.0 * slowest));
@@ -879,7 +879,14 @@ int launch_fused_outer(flow2d_context* ctx, int constancy, const float* f0, cons
 {
     if (!fused_supports(inner) || !fused_addressable(h, pitch_bytes)) return FLOW2D_ERR_UNSUPPORTED;
     // rows_per_strip > 0: uniform strips of that height (developer override); 0: the planner's choice
-    FusedPlan plan = fused_plan(ctx, w, h, inner);
+    // A lock-step group whose every instance fills the chip on its own with long strips (128 rows and more: 4096^2 and
+    // up) is launched instance by instance: nothing is gained by one launch of several rounds, and the strips are then
+    // planned -- and show in a kernel trace -- exactly as for a single pair.  Smaller levels share a launch (grid.z),
+    // which lets the planner give them longer strips.
+    static const bool never_split = std::getenv("FLOW2D_FUSED_NO_SPLIT") != nullptr;  // developer A/B knob
+    const bool split = !never_split && ctx->batch_count > 1 && fused_plan(ctx, w, h, inner, 1).rows_interior >= 128;
+    const unsigned instances_per_launch = split ? 1u : ctx->batch_count;
+    FusedPlan plan = fused_plan(ctx, w, h, inner, (long)instances_per_launch);
     if (rows_per_strip > 0)
         plan = FusedPlan{rows_per_strip, rows_per_strip, (int)div_up(h, rows_per_strip), plan.blocks_x,
                          plan.blocks_x * (int)div_up(h, rows_per_strip)};
@@ -901,9 +908,15 @@ int launch_fused_outer(flow2d_context* ctx, int constancy, const float* f0, cons
     if (!plain_order) a.blocks_per_xcd = (plan.blocks + 7) / 8;
     const int valid = 64 - 2 * ((int)inner + 1);
     const unsigned strips_x = div_up(w, valid);
-    const dim3 grid(a.blocks_per_xcd ? a.blocks_per_xcd * 8 : plan.blocks, 1, ctx->batch_count);
+    const dim3 grid(a.blocks_per_xcd ? a.blocks_per_xcd * 8 : plan.blocks, 1, instances_per_launch);
     const bool pow2 = is_power_of_two(hx) && is_power_of_two(hy);
-    int rc;
+    int rc = 0;
+    for (unsigned first = 0; first < ctx->batch_count && rc == 0; first += instances_per_launch) {
+    if (first) {  // the next instance of a split group: every plane one batch stride further
+        const size_t off = static_cast<size_t>(ctx->batch_stride_floats) * instances_per_launch;
+        a.f0 += off, a.f1 += off, a.u += off, a.v += off, a.du += off, a.dv += off, a.out_du += off, a.out_dv += off;
+        if (a.continue_sweeps) a.start_du += off, a.start_dv += off;
+    }
     if (constancy == FLOW2D_CONSTANCY_GRADIENT)
         rc = pow2 ? launch_for_inner<1, true>((int)inner, grid, ctx->stream, a)
                   : launch_for_inner<1, false>((int)inner, grid, ctx->stream, a);
@@ -916,6 +929,7 @@ int launch_fused_outer(flow2d_context* ctx, int constancy, const float* f0, cons
     else
         rc = pow2 ? launch_for_inner<0, true>((int)inner, grid, ctx->stream, a)
                   : launch_for_inner<0, false>((int)inner, grid, ctx->stream, a);
+    }
     if (rc) return FLOW2D_ERR_UNSUPPORTED;
     FLOW2D_CHECK_LAUNCH();
     return FLOW2D_OK;

@@ -390,6 +390,40 @@ def test_lock_step_groups_match_single_pairs(flow2d, oracle, constancy, sigma, m
         c.close()
 
 
+@pytest.mark.parametrize("constancy,inner", [(0, 7), (1, 5)])
+def test_lock_step_group_of_chip_filling_pairs(flow2d, oracle, constancy, inner):
+    """A group of two 4096 x 3456 pairs: on the finest level every instance fills the chip with strips of 128 rows and
+    more, so the fused kernel is launched instance by instance (launch_fused_outer's split), while the coarser levels and
+    the small kernels share launches.  Both pairs, eager and graph-replayed, equal the oracle's flow of each pair alone;
+    a continued launch (7 sweeps = 4 + 3) goes through the same split."""
+    w, h, G = 4096, 3456, 2
+    for _ in range(1):
+        p = (3, 0.5, 2, inner, 35.0, 0.001, 0.001, 5, 1.5)
+        pairs = [oracle.synthetic_pair(w, h, 1.5 - k, 0.75 * k, seed=k + 1, noise=False) for k in range(G)]
+        want = [oracle.compute_flow(f0, f1, *p, constancy)[:2] for f0, f1 in pairs]
+        c = flow2d.Context(0)
+        batch = flow2d.OpticalFlowBatch(w, h, constancy, lanes=1, group_size=G)
+        try:
+            group = (c.plane(w, h * G, np.vstack([q[0] for q in pairs])), c.plane(w, h * G, np.vstack([q[1] for q in pairs])),
+                     c.plane(w, h * G), c.plane(w, h * G))
+            columns = [[q.ptr] for q in group]
+            params = batch.params(*p)
+            for mode in ("eager", "graph"):
+                batch.use_graph(mode == "graph")
+                group[2].fill_bytes(0x7f)
+                group[3].fill_bytes(0x7f)
+                c.synchronize()
+                batch.compute_flow_batch_device(*columns, params)
+                batch.synchronize()
+                u, v = group[2].download(), group[3].download()
+                for k in range(G):
+                    assert np.array_equal(u[k * h:(k + 1) * h], want[k][0]) and np.array_equal(v[k * h:(k + 1) * h], want[k][1]), \
+                        (inner, mode, k)
+        finally:
+            batch.close()
+            c.close()
+
+
 @pytest.mark.parametrize("what", ["sor", "per-sweep", "seven sweeps"])
 def test_lock_step_groups_on_the_unbatched_kernels(flow2d, oracle, what):
     """The solver paths that have no batched kernel run once per instance of a group (red-black SOR, the per-sweep
