@@ -829,7 +829,8 @@ def main():
         check["oracle"] = oracle_check(job)
         oracle_timing = check["oracle"].pop("_timing")
         check["ok"] = check["ok"] and check["oracle"]["first_pair_equals_cpu_oracle"]
-    host_entry = host_entry_leg(job, batch, torch, max(5, args.steps)) if not args.no_host_entry_leg else None
+    # (its own leg after the timed region: at least 64 steps, so that four lanes' fill and drain do not weigh on a short --steps run)
+    host_entry = host_entry_leg(job, batch, torch, max(64, args.steps)) if not args.no_host_entry_leg else None
     if host_entry is not None and not host_entry["flows_bit_identical_to_device_resident_run"]:
         check["ok"] = False
     finest, pair_latency_ms = roofline_sample(job)
