@@ -71,12 +71,9 @@ static size_t tiled_max_pixels(int data_constancy)
     return static_cast<size_t>(600) * 600;
 }
 
-extern "C" {
-
-// The algorithm flow2d_solve_level runs for a request (never AUTO), or -1 when the requested one cannot run the
-// level.  Pure host logic, no device needed.
-int flow2d_solver_algorithm_for(int requested, size_t width, size_t height, size_t pitch_bytes, size_t outer, size_t inner,
-                                int data_constancy)
+// `instances`: pairs of a lock-step group that share every launch (flow2d_context_set_batch; 1 for a single pair)
+static int solver_algorithm_for(int requested, size_t width, size_t height, size_t pitch_bytes, size_t outer, size_t inner,
+                                int data_constancy, size_t instances)
 {
     if (requested < FLOW2D_SOLVER_AUTO || requested > FLOW2D_SOLVER_TILED) return -1;
     if (requested == FLOW2D_SOLVER_AUTO) {
@@ -85,7 +82,13 @@ int flow2d_solver_algorithm_for(int requested, size_t width, size_t height, size
         // (level solve 10 x 5 at 256^2: 0.07 against 0.11 ms, at 512^2 0.12 against 0.17, at 640^2 0.19 against 0.17).
         // That includes the coarsest levels: ten launches of a few
         // 8 x 8 tiles take 0.05 ms at 16 x 16 ... 64 x 32, the single-workgroup kernel 0.06 ... 0.11 ms.
-        if (inner >= 2 && width * height <= tiled_max_pixels(data_constancy) && flow2d::tiled_supports(data_constancy, inner))
+        // A lock-step group moves the crossover down with the square of its size: its instances share the strips' launch
+        // (longer strips, the planner sees all of them) and, in a pipeline of several lanes, a few strip waves find room
+        // beside another lane's kernels where 1024-thread tile workgroups with their LDS wait (config 2, groups of four:
+        // 3 416-3 439 pairs/s with the tiles up to 600^2 per instance, 3 524-3 567 up to 64^2 ... 128^2; config 4, groups
+        // of eight: 2 168-2 197 -> 2 224-2 239; groups of two at 4096^2: no difference).
+        if (inner >= 2 && width * height * instances * instances <= tiled_max_pixels(data_constancy) &&
+            flow2d::tiled_supports(data_constancy, inner))
             return FLOW2D_SOLVER_TILED;
         // Where the tiled kernel does not apply (solve_2d_log, a single sweep per outer iteration), levels up to 64 x 32
         // run whole in one launch on one CU (solve_small.hip; 0.06-0.10 ms against 0.16-0.19 ms for 60 per-sweep launches;
@@ -103,6 +106,16 @@ int flow2d_solver_algorithm_for(int requested, size_t width, size_t height, size
         if (!flow2d::fused_addressable(height, pitch_bytes)) return -1;
     }
     return requested;
+}
+
+extern "C" {
+
+// The algorithm flow2d_solve_level runs for a request (never AUTO) on a single pair, or -1 when the requested one cannot
+// run the level.  Pure host logic, no device needed.  (In a lock-step group AUTO gives fewer levels to the tiles: above.)
+int flow2d_solver_algorithm_for(int requested, size_t width, size_t height, size_t pitch_bytes, size_t outer, size_t inner,
+                                int data_constancy)
+{
+    return solver_algorithm_for(requested, width, height, pitch_bytes, outer, inner, data_constancy, 1);
 }
 
 int flow2d_solve_level(flow2d_context* ctx, const float* frame_0, const float* frame_1, const float* flow_u,
@@ -130,9 +143,9 @@ int flow2d_solve_level(flow2d_context* ctx, const float* frame_0, const float* f
     if (sor && p->algorithm != FLOW2D_SOLVER_AUTO && p->algorithm != FLOW2D_SOLVER_PER_SWEEP) return FLOW2D_ERR_UNSUPPORTED;
     if (sor && p->data_constancy == FLOW2D_CONSTANCY_LOG_DERIVATIVES) return FLOW2D_ERR_UNSUPPORTED;
     const int algorithm = sor ? FLOW2D_SOLVER_PER_SWEEP
-                              : flow2d_solver_algorithm_for(p->algorithm, p->width, p->height, p->pitch_bytes,
-                                                            p->outer_iterations_count, p->inner_iterations_count,
-                                                            p->data_constancy);
+                              : solver_algorithm_for(p->algorithm, p->width, p->height, p->pitch_bytes,
+                                                     p->outer_iterations_count, p->inner_iterations_count,
+                                                     p->data_constancy, ctx->batch_count);
     if (algorithm < 0) return FLOW2D_ERR_UNSUPPORTED;
 
     flow2d_timing_slot* slot = nullptr;
