@@ -337,7 +337,7 @@ def test_batch_entry_uneven_pairs_and_lane_offsets(flow2d, oracle, constancy):
         c.close()
 
 
-@pytest.mark.parametrize("w,h,G", [(208, 144, 3), (101, 75, 5)])
+@pytest.mark.parametrize("w,h,G", [(208, 144, 3), (101, 75, 5), (512, 384, 3)])  # (512 x 384 x 3: AUTO gives the two finest levels of the group to the strips, the rest to the tiles)
 @pytest.mark.parametrize("constancy,sigma,median", [(0, 1.5, 5), (1, 1.5, 5), (0, 0.0, 3), (3, 1.5, 5)])
 def test_lock_step_groups_match_single_pairs(flow2d, oracle, constancy, sigma, median, w, h, G):
     """OpticalFlow2D::group_size (flow2d_context_set_batch): groups of 3 pairs stored one below the other in tall
