@@ -365,7 +365,7 @@ class Job:
         # A step is still one pair's whole pyramid; K steps are K pairs.
         self.step_group = 1
         if self.single:
-            self.step_group = args.step_group if args.step_group > 0 else (4 if w * h <= 2048 * 2048 else (2 if w * h <= 4096 * 4096 else 1))
+            self.step_group = args.step_group if args.step_group > 0 else (8 if w * h <= 1024 * 1024 else 4 if w * h <= 2048 * 2048 else 2 if w * h <= 4096 * 4096 else 1)
         self.pending = []
         self.rotate = self.single or self.grouped  # a step is one entry; steps rotate over the lanes
         self.n_lanes = max(1, min(args.max_lanes, args.pipeline if self.rotate else cfg["pairs_per_rank"] * args.pipeline))
@@ -767,7 +767,7 @@ def main():
     ap.add_argument("--max-lanes", type=int, default=4, help="upper bound on the lanes (streams) per GPU")
     ap.add_argument("--step-group", type=int, default=0,
                     help="single-pair workloads: consecutive steps handed to the batch entry this many at a time, which "
-                         "forms a lock-step group of them (0 = automatic: 4 up to 2048^2, 2 up to 4096^2, else 1; the "
+                         "forms a lock-step group of them (0 = automatic: 8 up to 1024^2, 4 up to 2048^2, 2 up to 4096^2, else 1; the "
                          "finest level of a 4096^2 group still runs one launch per pair)")
     ap.add_argument("--batch-mode", choices=["groups", "lanes"], default="groups",
                     help="batched workloads: all pairs of a step as one lock-step group (every kernel launched once for "
