@@ -57,8 +57,12 @@ SIMDS = 256 * 4            # CUs x SIMDs per CU
 CLOCK_HZ = 2.4e9           # max shader clock
 VALU_ISSUE_CYCLES = 2.0    # a wave64 VALU instruction occupies a SIMD-32 for 2 cycles (same guide)
 
-# BASELINE.json configs[1..4] with the concrete parameters of SURVEY.md 8(d)
+# BASELINE.json configs[0..4] with the concrete parameters of SURVEY.md 8(d)
 WORKLOADS = {
+    # configs[0]: the reference's own sample pair with the values of its settings.xml (settings.xml:17-19: 20 levels at 0.9,
+    # 20 x 5 sweeps, alpha 3.5, sigma 0.45, median 5): the launch-bound shape -- 20 levels of at most 584 x 388 pixels
+    "cfg1_rub": dict(w=584, h=388, dx=0.0, dy=0.0, seed=0, constancy=0, levels=20, scale=0.9, outer=20, inner=5, median=5,
+                     sigma=0.45, alpha=3.5, pairs_per_rank=1, frames="rub"),
     # configs[2]: the HBM-roofline run the north_star's target is quoted on
     "cfg3_4096_gradient": dict(w=4096, h=4096, dx=2.0, dy=1.0, seed=3, constancy=1, levels=8, scale=0.5, outer=10,
                                inner=5, median=5, sigma=1.5, alpha=35.0, pairs_per_rank=1),
@@ -94,6 +98,16 @@ def synthetic_pair(w, h, dx, dy):
                 + 30.0 * np.sin(2 * np.pi * (xx + 2 * yy) / 23.7))
 
     return img(x, y).astype(np.float32), img(x - dx, y - dy).astype(np.float32)
+
+
+def workload_pair(workload, cfg, k):
+    """Global pair k of a workload: the SURVEY 8(d) synthetic pair, or (cfg1_rub) the reference's sample frames rub1 / rub2
+    (tests/data, 584 x 388 u8 raws widened to float like Data2D::ReadRAWFromFileU8 does)."""
+    if cfg.get("frames") == "rub":
+        d = os.path.join(ROOT, "tests", "data")
+        return tuple(np.fromfile(os.path.join(d, n), np.uint8).reshape(cfg["h"], cfg["w"]).astype(np.float32)
+                     for n in ("rub1.raw", "rub2.raw"))
+    return synthetic_pair(cfg["w"], cfg["h"], *pair_shift(workload, cfg, k))
 
 
 def pair_shift(workload, cfg, k):
@@ -217,6 +231,10 @@ def measured_copy_peak(flow2d, local_rank):
         c.close()
 
 
+PMC_CALIBRATION_ADDS = 4
+PMC_EXTRA_SWEEPS = 6
+
+
 def pmc_child(flow2d, args, cfg):
     """--pmc-child: what the rocprofv3 --pmc passes profile -- the workload's first pair, two eager pyramids on one stream
     (same data, same parameters, same AUTO choice as the timed run), nothing else."""
@@ -224,12 +242,22 @@ def pmc_child(flow2d, args, cfg):
     c = flow2d.Context(0)
     flow = flow2d.OpticalFlow(w, h, cfg["constancy"], ctx=c)
     try:
-        f0, f1 = (c.plane(w, h, a) for a in synthetic_pair(w, h, *pair_shift(args.workload, cfg, 0)))
+        f0, f1 = (c.plane(w, h, a) for a in workload_pair(args.workload, cfg, 0))
         u, v = c.plane(w, h), c.plane(w, h)
         p = flow.params(cfg["levels"], cfg["scale"], cfg["outer"], cfg["inner"], cfg["alpha"], 0.001, 0.001,
                         cfg["median"], cfg["sigma"], args.algorithm)
         for _ in range(2):
             flow.compute_flow_device(f0.ptr, f1.ptr, u.ptr, v.ptr, p, 0)
+        c.synchronize()
+        # after the pyramids: PMC_CALIBRATION_ADDS launches of add_2d at full resolution, whose traffic is known exactly
+        # (2 planes read, 1 written: the FETCH_SIZE / WRITE_SIZE corrections), and PMC_EXTRA_SWEEPS launches of the per-sweep
+        # Jacobi kernel of this data term at the finest level (roofline.per_sweep: its physical bytes)
+        du, dv, phi, ksi, tdu, tdv = (c.plane(w, h).fill_bytes(0) for _ in range(6))
+        for _ in range(PMC_CALIBRATION_ADDS):
+            c.add(tdu, f0, w, h)
+        c.compute_phi_ksi(f0, f1, u, v, du, dv, w, h, 1.0, 1.0, 0.001, 0.001, phi, ksi)
+        for _ in range(PMC_EXTRA_SWEEPS):
+            c.solve_sweep(f0, f1, u, v, du, dv, phi, ksi, w, h, 1.0, 1.0, cfg["alpha"], tdu, tdv, cfg["constancy"])
         c.synchronize()
     finally:
         flow.close()
@@ -295,6 +323,8 @@ def pmc_select(collected, cfg, algorithm_used):
         goes coarse to fine, so they are the last `per_pyramid` launches of that family in each pyramid (Grid_Size alone
         cannot tell 5120 x 25 from 2560 x 50)."""
         sel = sorted(r for r in rows.get(counter, []) if r[1].startswith(prefix))
+        if prefix == "sweep_":
+            sel = sel[:-PMC_EXTRA_SWEEPS]  # pmc_child's explicit sweeps after the pyramids
         n = len(sel) // PYRAMIDS
         if n < per_pyramid or len(sel) != n * PYRAMIDS:
             return None, []
@@ -305,13 +335,29 @@ def pmc_select(collected, cfg, algorithm_used):
     if dominant is None:
         return {"error": "no %s* launches in the counter rows" % family}
     plane = float(cfg["w"]) * cfg["h"] * 4
-    _, add_fetch = launches("FETCH_SIZE", "add_2d_kernel", 1)
-    _, add_write = launches("WRITE_SIZE", "add_2d_kernel", 1)
-    corr = 4 * plane / (np.mean(add_fetch) * 1024) if add_fetch else 2.0
-    wcorr = 2 * plane / (np.mean(add_write) * 1024) if add_write else 1.0
+
+    def extras(counter, prefix, count):
+        """the explicit launches pmc_child makes after the pyramids: the last `count` of their family (the first one left out: cold)"""
+        sel = sorted(r for r in rows.get(counter, []) if r[1].startswith(prefix))[-count:]
+        return [r[3] for r in sel[1:]], (sel[-1][1] if sel else None)
+
+    add_fetch, _ = extras("FETCH_SIZE", "add_2d_kernel", PMC_CALIBRATION_ADDS)
+    add_write, _ = extras("WRITE_SIZE", "add_2d_kernel", PMC_CALIBRATION_ADDS)
+    # small frames live in the caches: the calibration needs planes well beyond the 256 MiB Infinity Cache
+    calibrate = bool(add_fetch and add_write) and plane >= 32 * 2 ** 20
+    corr = 2 * plane / (np.mean(add_fetch) * 1024) if calibrate else 2.0
+    wcorr = plane / (np.mean(add_write) * 1024) if calibrate else 1.0
     out = {"kernel": dominant, "fetch_size_correction": round(float(corr), 4), "write_size_correction": round(float(wcorr), 4),
-           "correction_from": "the pyramid's full-resolution add_2d launches (4 planes read, 2 written)" if add_fetch
-           else "MI355X_MICROARCH.md (FETCH_SIZE x 2)"}
+           "correction_from": ("%d full-resolution add_2d launches after the pyramids (2 planes read, 1 written)" % (PMC_CALIBRATION_ADDS - 1))
+           if calibrate else "MI355X_MICROARCH.md (FETCH_SIZE x 2)"}
+    sweep_fetch, sweep_name = extras("FETCH_SIZE", "sweep_", PMC_EXTRA_SWEEPS)
+    sweep_write, _ = extras("WRITE_SIZE", "sweep_", PMC_EXTRA_SWEEPS)
+    sweep_valu, _ = extras("SQ_INSTS_VALU", "sweep_", PMC_EXTRA_SWEEPS)
+    if sweep_fetch and sweep_write:
+        out["per_sweep"] = {"kernel": sweep_name, "launches_sampled": len(sweep_fetch),
+                            "hbm_read_bytes_per_launch": round(float(np.mean(sweep_fetch)) * 1024 * corr),
+                            "hbm_write_bytes_per_launch": round(float(np.mean(sweep_write)) * 1024 * wcorr),
+                            "valu_insts_per_launch": round(float(np.mean(sweep_valu))) if sweep_valu else None}
     split = {}
     for counter in ("FETCH_SIZE", "WRITE_SIZE", "SQ_INSTS_VALU", "SQ_WAVES"):
         _, vals = launches(counter, family, per_solve)
@@ -328,6 +374,27 @@ def pmc_select(collected, cfg, algorithm_used):
     out["valu_insts_per_launch"] = round(split["SQ_INSTS_VALU"][1])
     out["waves_per_launch"] = round(split["SQ_WAVES"][1])
     return out
+
+
+def per_sweep_block(cfg, sweep_ms, pmc):
+    if not sweep_ms:
+        return None
+    w, h = cfg["w"], cfg["h"]
+    algorithmic = 40.0 * w * h  # 8 planes read, 2 written
+    phys = (pmc.get("hbm_read_bytes_per_launch") or 0) + (pmc.get("hbm_write_bytes_per_launch") or 0) or None
+    return {
+        "kernel": pmc.get("kernel") or {0: "sweep_grey_kernel", 1: "sweep_grad_kernel", 3: "sweep_log_kernel"}.get(cfg["constancy"], "sweep kernel"),
+        "bound": "hbm",
+        "avg_launch_ms": round(sweep_ms, 5),
+        "algorithmic_bytes_per_launch": algorithmic,
+        "traffic": phys,
+        "traffic_over_algorithmic": round(phys / algorithmic, 4) if phys else None,
+        "achieved": round((phys or algorithmic) / (sweep_ms * 1e-3) / 1e9, 1),  # physical bytes when the PMC passes have them
+        "achieved_is": "physical (PMC) bytes" if phys else "algorithmic bytes (no PMC figures in this run)",
+        "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "frac": round((phys or algorithmic) / (sweep_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+        "mpix_sweeps_per_s": round(w * h / (sweep_ms * 1e-3) / 1e6, 1),
+    }
 
 
 def load_pmc(workload, algorithm):
@@ -380,8 +447,9 @@ class Job:
                                          block[6], int(block[7]), block[8], int(block[9]))
         # this rank's pairs, resident in HBM before any timed region; pair k -> rank k mod world
         self.owned = batch.pairs_of_rank(cfg["pairs_per_rank"] * world, rank, world)
-        frames = [synthetic_pair(w, h, *pair_shift(workload, cfg, gk)) for gk in self.owned]
+        frames = [workload_pair(workload, cfg, gk) for gk in self.owned]
         self.first_pair = frames[0]
+        self.touched = set()  # plane sets written since the last poison()
         c, G = self.ctx, self.group
         # entries: (frame 0, frame 1, u, v, [global pair indices]); planes are G containers tall
         self.sets = []
@@ -427,6 +495,7 @@ class Job:
         sets = self.sets[lane * self.step_group:lane * self.step_group + n]
         cols = [[q[i].ptr for q in sets] for i in range(4)]
         self.runner.compute_flow_batch_device_grouped(*cols, self.params, first_lane=lane)
+        self.touched.update(range(lane * self.step_group, lane * self.step_group + n))
         self.pending = []
 
     def step(self, index):
@@ -438,8 +507,19 @@ class Job:
         elif self.rotate:
             lane = index % self.n_lanes
             self._queue([self.sets[lane]], lane)
+            self.touched.add(lane)
         else:
             self._queue(self.sets, 0)
+            self.touched.update(range(len(self.sets)))
+
+    def poison(self):
+        """Every flow plane of the job filled with 0x7f bytes (3.39e38): what a step does not write stays recognisable."""
+        self.sync()
+        for _, _, pu, pv, _ in self.sets:
+            for q in (pu, pv):
+                self.flow2d.Plane.fill_bytes(q, 0x7f)
+        self.sync()
+        self.touched = set()
 
     def eager_pass(self):
         """Every plane set once, launched eagerly (no graph): the recomputation the output check compares with."""
@@ -478,6 +558,9 @@ class _Borrowed:
     def download(self):
         return importlib.import_module("cuda-flow2d_amd").Plane.download(self)
 
+    def fill_bytes(self, value):
+        return importlib.import_module("cuda-flow2d_amd").Plane.fill_bytes(self, value)
+
 
 def timed_region(job, batch, torch, steps, warmup):
     def barrier():
@@ -488,6 +571,16 @@ def timed_region(job, batch, torch, steps, warmup):
     for k in range(max(warmup, 1) * (job.n_lanes if job.rotate else 1) * job.step_group):
         job.step(k)  # also records the graphs of every lane
     job.flush()
+    # K steps that are no multiple of the lock-step group end in a smaller group: its graph (another plane list, another
+    # tile / strip mix) is recorded here, not inside the timed region
+    whole = steps // job.step_group * job.step_group
+    for k in range(whole, steps):
+        job.step(k)
+    job.flush()
+    barrier()
+    # the flow planes are poisoned between warm-up and the timed region: the digests the output check takes afterwards
+    # are of values the K timed steps wrote (a replay that launched nothing would leave 0x7f7f7f7f behind)
+    job.poison()
     barrier()
     t0 = time.perf_counter()
     for k in range(steps):
@@ -499,9 +592,12 @@ def timed_region(job, batch, torch, steps, warmup):
 
 def output_check(job):
     """The timed steps' results against an eager recomputation; single-pair workloads: all streams agree."""
-    replayed = job.digests()
+    touched = set(job.touched)  # the plane sets the timed steps wrote (the others still hold the poison)
+    replayed = {k: d for k, d in job.digests().items() if k[0] in touched}
+    poison = sha(np.frombuffer(b"\x7f" * (job.cfg["w"] * job.cfg["h"] * 4), np.float32))
+    poisoned = [k for k, d in replayed.items() if poison in d]
     job.eager_pass()
-    eager = job.digests()
+    eager = {k: d for k, d in job.digests().items() if k[0] in touched}
     lanes_identical = True
     if job.rotate:  # every lane holds a copy of the same pairs: pair by pair the lanes must agree
         by_pair = {}
@@ -509,8 +605,10 @@ def output_check(job):
             by_pair.setdefault(gk, set()).add(d)
         lanes_identical = all(len(ds) == 1 for ds in by_pair.values())
     return {
-        "ok": bool(replayed == eager and lanes_identical),
+        "ok": bool(replayed and replayed == eager and lanes_identical and not poisoned),
         "graph_replay_equals_eager": bool(replayed == eager),
+        "planes_poisoned_before_timed_region": True,
+        "plane_sets_written_by_timed_steps": len(touched),
         "streams_identical": bool(lanes_identical) if job.rotate else None,
         "fields_hashed": 2 * len(replayed),
         "sha256_u_v_first_pair": list(replayed[min(replayed)]),
@@ -526,7 +624,7 @@ def host_entry_leg(job, batch, torch, steps):
     reused round-robin).  Timed like the main region: barrier + synchronise on both sides, max over ranks."""
     flow2d, cfg = job.flow2d, job.cfg
     w, h, G = cfg["w"], cfg["h"], cfg["pairs_per_rank"]
-    frames = [synthetic_pair(w, h, *pair_shift(job.workload, cfg, gk)) for gk in job.owned]
+    frames = [workload_pair(job.workload, cfg, gk) for gk in job.owned]
     f0s = [flow2d.HostImage(w, h, True, f[0]) for f in frames]
     f1s = [flow2d.HostImage(w, h, True, f[1]) for f in frames]
     N = job.step_group  # steps handed over together (config 2: the batch object forms a lock-step group of them)
@@ -638,6 +736,35 @@ def roofline_sample(job, passes=3):
         return finest, latency
     finally:
         flow.close()
+        c.close()
+
+
+def per_sweep_sample(job, launches=10, rounds=4):
+    """SURVEY 8(d) metric 1, second half: the pure inner-sweep rate.  The per-sweep Jacobi kernel of the workload's data
+    term (sweep_grey / sweep_grad / sweep_log: one launch per reference launch of solve_2d*, cuda_operation_solve_2d.cpp:263-289)
+    at the workload's finest level, alone on the GPU: HIP events on the launch stream around `launches` back-to-back
+    launches, mean of the rounds after the first.  Returns ms per launch."""
+    flow2d, cfg = job.flow2d, job.cfg
+    w, h = cfg["w"], cfg["h"]
+    job.sync()
+    c = flow2d.Context(job.local_rank)
+    try:
+        f0, f1 = (c.plane(w, h, a) for a in job.first_pair)
+        u, v, du, dv, phi, ksi, tdu, tdv = (c.plane(w, h).fill_bytes(0) for _ in range(8))
+        c.compute_phi_ksi(f0, f1, u, v, du, dv, w, h, 1.0, 1.0, 0.001, 0.001, phi, ksi)
+        ms = []
+        for _ in range(rounds):
+            e0, e1 = c.event(), c.event()
+            c.record(e0)
+            for k in range(launches):  # ping-pong like CudaOperationSolve2D::Execute does between du/dv and the temporaries
+                a, b = ((du, dv), (tdu, tdv)) if k % 2 == 0 else ((tdu, tdv), (du, dv))
+                c.solve_sweep(f0, f1, u, v, a[0], a[1], phi, ksi, w, h, 1.0, 1.0, cfg["alpha"], b[0], b[1], cfg["constancy"])
+            c.record(e1)
+            ms.append(c.elapsed_ms(e0, e1) / launches)
+        return float(np.mean(ms[1:]))
+    except Exception:  # noqa: BLE001 - an informational leg
+        return None
+    finally:
         c.close()
 
 
@@ -834,6 +961,7 @@ def main():
     if host_entry is not None and not host_entry["flows_bit_identical_to_device_resident_run"]:
         check["ok"] = False
     finest, pair_latency_ms = roofline_sample(job)
+    sweep_ms = per_sweep_sample(job) if rank == 0 else None
     copy_gbs = measured_copy_peak(flow2d, local_rank) if rank == 0 else None
     first_pair = job.first_pair
     n_lanes, step_group = job.n_lanes, job.step_group
@@ -898,6 +1026,11 @@ def main():
             "valu_instr_per_launch": valu,
             "valu_issue_frac": round(valu_frac, 4) if valu_frac else None,  # of one wave64 instruction per 2 cycles per SIMD
             "valu_peak_instr_per_s": SIMDS * CLOCK_HZ / VALU_ISSUE_CYCLES,
+            # SURVEY 8(d) metric 1, second half -- "the pure inner-sweep rate (events around K7 only)": the per-sweep Jacobi
+            # kernel (one launch per reference launch of solve_2d*) at this workload's finest level, alone on the GPU.  It is
+            # the path of inner = 1, red-black SOR and planes of 4 GiB and more, and the literal subject of north_star's
+            # "70 % of the HBM roofline on the SOR inner loop"; the pyramids of this line run the fused kernel above instead.
+            "per_sweep": per_sweep_block(cfg, sweep_ms, pmc.get("per_sweep") or {}),
             "pmc_source": pmc_source,
             "pmc_detail": {k: pmc_run[k] for k in ("kernel", "fetch_size_correction", "write_size_correction",
                                                     "correction_from", "launches_sampled", "waves_per_launch")
@@ -919,7 +1052,7 @@ def main():
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "f32",
-            "data": "synthetic",
+            "data": "synthetic" if cfg.get("frames") != "rub" else "rub1 / rub2, the reference's sample pair (tests/data)",
             "config": {
                 "workload": args.workload, "width": w, "height": h, "pairs_per_gpu_per_step": cfg["pairs_per_rank"],
                 "pyramid_levels": levels_run,
@@ -939,6 +1072,7 @@ def main():
             "pairs_per_s_incl_h2d": host_entry["pairs_per_s"] if host_entry else None,
             "host_entry": host_entry,
             "single_pair_latency_ms": round(pair_latency_ms, 3),  # one pair alone on the GPU, graph replay, launch to done
+            "pairs_per_s_single": round(1e3 / pair_latency_ms, 3),  # = 1 / single_pair_latency: no second pair in flight
             "finest_level": {
                 "solve_ms": round(solve_ms, 4),
                 "mpix_iters_per_s": round(px_iters / (solve_ms * 1e-3) / 1e6, 1),

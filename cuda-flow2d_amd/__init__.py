@@ -130,6 +130,7 @@ def hip_lib():
         L.flow2d_solve_level.argtypes = [vp] * 11 + [C.POINTER(SolveParams), C.POINTER(i)]
         L.flow2d_timing_enable.argtypes = [vp, i]
         L.flow2d_fused_fallbacks.argtypes = [vp, C.POINTER(C.c_ulonglong)]
+        L.flow2d_fused_plain_waves.argtypes = [vp, C.POINTER(C.c_ulonglong)]
         L.flow2d_timing_launch_filter.argtypes = [vp, sz, sz]
         L.flow2d_timing_count.argtypes = [vp, C.POINTER(sz)]
         L.flow2d_timing_get.argtypes = [vp, sz, C.POINTER(TimingRecord)]
@@ -236,6 +237,12 @@ class Context:
         """Waves of the fused kernel that repeated their strip with the plain division (synchronises)."""
         n = C.c_ulonglong()
         _check(hip_lib().flow2d_fused_fallbacks(self.handle, C.byref(n)), "flow2d_fused_fallbacks")
+        return n.value
+
+    def fused_plain_waves(self):
+        """Waves of fused launches that ran the plain expressions throughout (grid spacing outside the proven range)."""
+        n = C.c_ulonglong()
+        _check(hip_lib().flow2d_fused_plain_waves(self.handle, C.byref(n)), "flow2d_fused_plain_waves")
         return n.value
 
     def device_name(self):

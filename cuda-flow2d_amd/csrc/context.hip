@@ -110,8 +110,8 @@ static int create_context(int device_ordinal, void* stream, bool adopt, flow2d_c
     }
     // (stream-ordered on the context's own stream: a call on the NULL stream here would bring the legacy default stream
     //  to life, and with it the lanes of a batch lose their overlap -- measured: config 2 at half its rate)
-    if (hipMalloc(reinterpret_cast<void**>(&ctx->fused_fallbacks), sizeof(unsigned int)) != hipSuccess ||
-        hipMemsetAsync(ctx->fused_fallbacks, 0, sizeof(unsigned int), ctx->stream) != hipSuccess) {
+    if (hipMalloc(reinterpret_cast<void**>(&ctx->fused_fallbacks), 2 * sizeof(unsigned int)) != hipSuccess ||
+        hipMemsetAsync(ctx->fused_fallbacks, 0, 2 * sizeof(unsigned int), ctx->stream) != hipSuccess) {
         (void)hipGetLastError();
         ctx->fused_fallbacks = nullptr;  // diagnostics only: the kernels run without it
     }
@@ -166,18 +166,23 @@ int flow2d_synchronize(flow2d_context* ctx)
     return FLOW2D_OK;
 }
 
-int flow2d_fused_fallbacks(flow2d_context* ctx, unsigned long long* waves)
+// word 0: guard trips, word 1: waves of plain-only launches (solve_fused.hip)
+static int read_fused_counter(flow2d_context* ctx, int word, unsigned long long* waves)
 {
     FLOW2D_ENTER(ctx);
     if (!waves) return FLOW2D_ERR_INVALID_ARGUMENT;
     *waves = 0;
     if (!ctx->fused_fallbacks) return FLOW2D_OK;
     unsigned int n = 0;
-    FLOW2D_HIP_TRY(hipMemcpyAsync(&n, ctx->fused_fallbacks, sizeof(n), hipMemcpyDeviceToHost, ctx->stream));
+    FLOW2D_HIP_TRY(hipMemcpyAsync(&n, ctx->fused_fallbacks + word, sizeof(n), hipMemcpyDeviceToHost, ctx->stream));
     FLOW2D_HIP_TRY(hipStreamSynchronize(ctx->stream));
     *waves = n;
     return FLOW2D_OK;
 }
+
+int flow2d_fused_fallbacks(flow2d_context* ctx, unsigned long long* waves) { return read_fused_counter(ctx, 0, waves); }
+
+int flow2d_fused_plain_waves(flow2d_context* ctx, unsigned long long* waves) { return read_fused_counter(ctx, 1, waves); }
 
 int flow2d_mem_info(flow2d_context* ctx, size_t* free_bytes, size_t* total_bytes)
 {

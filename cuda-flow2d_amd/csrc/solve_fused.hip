@@ -39,9 +39,35 @@
 #include "common.hpp"
 #include "solver_math.hpp"
 
+// Developer switches (timing builds under ab/, loaded through FLOW2D_HIP_LIB; tools/ab_time.sh, tools/ab_bench.sh) exist in
+// developer builds only (-DFLOW2D_DEV_BUILD); the product library has none of them and reads no environment variable:
+//   FLOW2D_FUSED_DEV             only the instantiations of the 4096^2 benchmark (compiles in half a minute)
+//   FLOW2D_FUSED_STAMPS          per-wave time stamps (tools/fused_wave_stamps.py)
+//   FLOW2D_FUSED_TURN_SHIFT=n    the two waves of a SIMD swap issue priority every 2^n cycles (take_turns)
+//   FLOW2D_FUSED_PLAIN_DIVISION  the compiler's division in the sweeps instead of the three-step one
+//   FLOW2D_FUSED_NO_PINS         let the scheduler place the guard updates
+//   FLOW2D_FUSED_EDGE_COST=x     border / interior body cost ratio of the strip planner (default 1.22)
+//   FLOW2D_FUSED_NO_SPLIT        a lock-step group's finest level as one launch of several rounds
+//   FLOW2D_FUSED_PLAIN_ORDER     blocks in plain order instead of one contiguous run per XCD
+//   FLOW2D_FUSED_COMPUTE_ONLY, FLOW2D_FUSED_MEMORY_ONLY   timing probes that compute WRONG results
+#if (defined(FLOW2D_FUSED_STAMPS) || defined(FLOW2D_FUSED_COMPUTE_ONLY) || defined(FLOW2D_FUSED_MEMORY_ONLY) ||          \
+     defined(FLOW2D_FUSED_TURN_SHIFT) || defined(FLOW2D_FUSED_PLAIN_DIVISION) || defined(FLOW2D_FUSED_NO_PINS) ||          \
+     defined(FLOW2D_FUSED_DEV) || defined(FLOW2D_FUSED_EDGE_COST) || defined(FLOW2D_FUSED_NO_SPLIT) ||                    \
+     defined(FLOW2D_FUSED_PLAIN_ORDER)) &&                                                                               \
+    !defined(FLOW2D_DEV_BUILD)
+#error "the fused kernel's timing probes need -DFLOW2D_DEV_BUILD: they are not part of the product library"
+#endif
+
 namespace {
 
 using namespace flow2d_math;
+
+#ifdef FLOW2D_FUSED_STAMPS
+// per wave: start / end on the 100 MHz clock, shader cycles, HW_ID, XCC_ID, block id, wave in block | edge << 8, y0 | y1 << 32
+constexpr int kStampWords = 8, kStampWaves = 1 << 16;
+__device__ unsigned long long g_fused_stamps[kStampWords * kStampWaves];
+__device__ unsigned int g_fused_stamp_count;
+#endif
 
 struct FusedArgs {
     const float* f0;
@@ -84,7 +110,8 @@ struct FusedArgs {
                                       // takes the fallback pass (plain divisions) at once
     int blocks, blocks_per_xcd;       // working blocks of the plan; ceil(blocks / 8), or 0 for the plain block order
     unsigned long long batch_stride;  // floats between the instances of a batched launch (blockIdx.z)
-    unsigned int* fallback_count;     // waves that repeated their strip with the plain division (diagnostics; may be null)
+    unsigned int* fallback_count;     // [0] waves that repeated their strip with the plain division, [1] waves of plain_only
+                                      // launches (diagnostics; may be null)
 };
 
 // A plane row is addressed as base pointer (a scalar register pair) + one 32-bit per-lane byte offset that all planes
@@ -110,6 +137,35 @@ __device__ __forceinline__ float from_left(float v)
 __device__ __forceinline__ float from_right(float v)
 {
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x130, 0xf, 0xf, true));
+}
+
+// Developer experiment (round 4, -DFLOW2D_FUSED_TURN_SHIFT=15; not in the product build): the two waves of a SIMD take
+// turns at being the one the issue arbiter favours.  Vector issue on a SIMD goes to the wave of higher priority and, among
+// equals, to the OLDER one: the older wave of a SIMD runs its strip at the pace of a lone wave (124 us at 4096^2), the
+// younger one gets the slots it leaves and finishes the rest alone (208 us) -- per-wave stamps, tools/fused_wave_stamps.py.
+// With the priority swapped every 2^shift shader cycles both waves advance at the same pace (185 / 196 us) and the launch
+// is 2-4 % shorter alone, but a pipeline of lanes already fills the slots a lone wave leaves: no gain end to end
+// (profiles/r04_experiments/README.md).
+#ifndef FLOW2D_FUSED_TURN_SHIFT
+#define FLOW2D_FUSED_TURN_SHIFT (-1)
+#endif
+constexpr int kTurnShift = FLOW2D_FUSED_TURN_SHIFT;  // < 0: never
+// the wave's slot on its SIMD (0 or 1 with two waves per SIMD)
+__device__ __forceinline__ unsigned turn_parity()
+{
+    unsigned slot = 0;
+    if (kTurnShift >= 0) asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID, 0, 4)" : "=s"(slot));
+    return slot;
+}
+// clock: a reading of the shader clock taken a row step ago (the read is issued at the end of a step and waited for at
+// the beginning of the next, so its latency stays out of the way)
+__device__ __forceinline__ void take_turns(unsigned long long clock, unsigned parity)
+{
+    if (kTurnShift < 0) return;
+    if (((static_cast<unsigned>(clock >> (kTurnShift < 0 ? 0 : kTurnShift)) ^ parity) & 1u) != 0u)
+        __builtin_amdgcn_s_setprio(1);
+    else
+        __builtin_amdgcn_s_setprio(0);
 }
 
 // static per-pixel coefficients of one outer iteration (what the sweeps need besides the moving flow)
@@ -165,7 +221,7 @@ __device__ __forceinline__ float half_inverse_root(float s, float& twice_root)
 //   zero: signed min of the raw bits of every flow value read: INT_MIN exactly when one of them is a -0
 //   den : max of bits(den) - bits(2^-30): above kDenSpan for a denominator outside [2^-30, 2^40], negative or NaN
 //   out : max of bits(du, dv) << 1 over the stored results: above kOutLimit for an infinity or a NaN
-#ifdef FLOW2D_FUSED_NO_PINS  // developer switch: let the scheduler place the guard updates
+#ifdef FLOW2D_FUSED_NO_PINS
 #define FLOW2D_GUARD_PIN(x) ((void)0)
 #else
 #define FLOW2D_GUARD_PIN(x) asm volatile("" : "+v"(x))
@@ -292,6 +348,8 @@ struct Strip {
     // next step (n_start)
     v2f start_cur, n_start;
     DivGuard guard;  // three-step division: operands outside the proven range leave their mark here
+    unsigned long long turn_clock;  // take_turns: the shader clock a step ago, the wave's slot on its SIMD (both wave-uniform)
+    unsigned turn_parity;
 };
 
 // EDGE = false: the strip touches no image border, so the reflect substitutions (a v_cndmask per
@@ -360,6 +418,7 @@ __device__ __forceinline__ void strip_step(Strip<INNER, GRAD>& s, const FusedArg
         return;
     }
 #endif
+    if (T < 0) take_turns(s.turn_clock, s.turn_parity);
     constexpr bool run_P = T < 0 || T >= 2, run_W = T < 0 || T >= 3;
     if (T >= 0) __builtin_amdgcn_sched_barrier(0);  // keep the straight-line start-up from being interleaved across steps
 
@@ -585,6 +644,7 @@ __device__ __forceinline__ void strip_step(Strip<INNER, GRAD>& s, const FusedArg
             plane_store(a.out_dv, off, dv_new);
         }
     }
+    if (T < 0 && kTurnShift >= 0) s.turn_clock = __builtin_amdgcn_s_memtime();
 }
 
 template <int INNER, int GRAD, bool EDGE, bool POW2, bool CONT, bool FAST, size_t... Js>
@@ -650,6 +710,8 @@ __device__ __forceinline__ bool run_strip(const FusedArgs& a, int x, int xc, boo
     }
     s.p_fx = s.p_fy = s.p_ft = s.p_ksi = 0.f;
     s.guard = DivGuard{0xffffffffu, 0u, 0u, 0x7fffffff};
+    s.turn_parity = turn_parity();
+    s.turn_clock = kTurnShift >= 0 ? __builtin_amdgcn_s_memtime() : 0ull;
 
     // first input row: the strip's first stored row needs INNER+1 rows of halo above it
     const int r_first = y0 - S::kHalo;
@@ -680,15 +742,15 @@ __device__ __forceinline__ bool run_strip(const FusedArgs& a, int x, int xc, boo
     strip_startup<INNER, GRAD, EDGE, POW2, CONT, FAST>(s, a, r_first, x, xc, at_l, at_r, lane_stores, y0, y1, hx_2, hy_2,
                                                        std::make_index_sequence<kPeel>{});
     int r = r_first + kPeel;
-    for (; r + S::kRing - 1 <= r_last; r += S::kRing)
+    for (; r + S::kRing - 1 <= r_last; r += S::kRing) {
         strip_steps<INNER, GRAD, EDGE, POW2, CONT, FAST>(s, a, r, x, xc, at_l, at_r, lane_stores, y0, y1, hx_2, hy_2,
                                                          std::make_index_sequence<S::kRing>{});
+    }
     strip_tail<INNER, GRAD, EDGE, POW2, CONT, FAST>(s, a, r, r_last, x, xc, at_l, at_r, lane_stores, y0, y1, hx_2, hy_2,
                                                     std::make_index_sequence<S::kRing - 1>{});
     return guard_tripped(s.guard);
 }
 
-// developer switch (A/B timing builds): -DFLOW2D_FUSED_PLAIN_DIVISION keeps the compiler's division in the sweeps
 #ifdef FLOW2D_FUSED_PLAIN_DIVISION
 constexpr bool kThreeStepDivision = false;
 #else
@@ -700,6 +762,9 @@ __global__ __launch_bounds__(256, 2) void fused_outer_kernel(FusedArgs a)
 {
     using S = Strip<INNER, GRAD>;
     const int lane = threadIdx.x & 63;
+#ifdef FLOW2D_FUSED_STAMPS
+    const unsigned long long stamp_r0 = __builtin_amdgcn_s_memrealtime(), stamp_c0 = __builtin_amdgcn_s_memtime();
+#endif
     // block id -> block column bx and strip by: uniform strips row by row; a border-aware plan first the interior
     // block columns (strips_interior strips each), then the first and the last block column (strips of rows_edge)
     int bx, by;
@@ -754,12 +819,28 @@ __global__ __launch_bounds__(256, 2) void fused_outer_kernel(FusedArgs a)
         bad = run_strip<INNER, GRAD, true, POW2, CONT, kThreeStepDivision>(a, x, xc, at_l, at_r, lane_stores, y0, y1, hx_2, hy_2);
     else
         bad = run_strip<INNER, GRAD, false, POW2, CONT, kThreeStepDivision>(a, x, xc, at_l, at_r, lane_stores, y0, y1, hx_2, hy_2);
-    if (kThreeStepDivision && __builtin_amdgcn_ballot_w64(bad) != 0ull) {
-        // some lane's operands left the range the three-step division is proven for: the whole strip again with the
-        // plain division (same stores, now from the reference's own arithmetic)
+    if (__builtin_amdgcn_ballot_w64(bad) != 0ull) {
+        // some lane's operands left the range the three-step division is proven for (or the launch's grid spacing did:
+        // plain_only): the whole strip with the plain division (same stores, now from the reference's own arithmetic)
         (void)run_strip<INNER, GRAD, true, POW2, CONT, false>(a, x, xc, at_l, at_r, lane_stores, y0, y1, hx_2, hy_2);
-        if (a.fallback_count && lane == 0) atomicAdd(a.fallback_count, 1u);
+        // word 0 counts guard trips, word 1 the waves of launches that never tried the short forms
+        if (a.fallback_count && lane == 0) atomicAdd(a.fallback_count + (a.plain_only ? 1 : 0), 1u);
     }
+#ifdef FLOW2D_FUSED_STAMPS
+    if (lane == 0) {
+        const unsigned long long r1 = __builtin_amdgcn_s_memrealtime(), c1 = __builtin_amdgcn_s_memtime();
+        const unsigned slot = atomicAdd(&g_fused_stamp_count, 1u) % kStampWaves;
+        unsigned long long* o = g_fused_stamps + static_cast<size_t>(slot) * kStampWords;
+        o[0] = stamp_r0, o[1] = r1, o[2] = c1 - stamp_c0;
+        unsigned hw_id, xcc_id;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_id));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc_id));
+        o[3] = hw_id, o[4] = xcc_id;
+        o[5] = blockIdx.x | (static_cast<unsigned long long>(blockIdx.z) << 32);
+        o[6] = (threadIdx.x >> 6) | (static_cast<unsigned>(edge) << 8) | (static_cast<unsigned long long>(strip_x) << 32);
+        o[7] = static_cast<unsigned>(y0) | (static_cast<unsigned long long>(y1) << 32);
+    }
+#endif
 }
 
 #define FUSED_LAUNCH(N)                                                      \
@@ -826,8 +907,12 @@ bool fused_addressable(size_t h, size_t pitch_bytes) { return h != 0 && pitch_by
 struct FusedPlan {
     int rows_interior, rows_edge, strips_interior, blocks_x, blocks;  // blocks: the launch's grid (per batch instance)
 };
-// EDGE body / interior body: 1.2-1.26 in VALU instructions per row step; FLOW2D_FUSED_EDGE_COST overrides (developer knob)
-static const double kEdgeCost = std::getenv("FLOW2D_FUSED_EDGE_COST") ? std::atof(std::getenv("FLOW2D_FUSED_EDGE_COST")) : 1.22;
+// EDGE body / interior body: 1.2-1.26 in VALU instructions per row step (swept 1.0 ... 1.38 in round 3: 1.22)
+#ifdef FLOW2D_FUSED_EDGE_COST
+static const double kEdgeCost = FLOW2D_FUSED_EDGE_COST;
+#else
+static const double kEdgeCost = 1.22;
+#endif
 
 FusedPlan fused_plan(const flow2d_context* ctx, size_t w, size_t h, size_t inner, long instances)
 {
@@ -883,7 +968,11 @@ int launch_fused_outer(flow2d_context* ctx, int constancy, const float* f0, cons
     // up) is launched instance by instance: nothing is gained by one launch of several rounds, and the strips are then
     // planned -- and show in a kernel trace -- exactly as for a single pair.  Smaller levels share a launch (grid.z),
     // which lets the planner give them longer strips.
-    static const bool never_split = std::getenv("FLOW2D_FUSED_NO_SPLIT") != nullptr;  // developer A/B knob
+#ifdef FLOW2D_FUSED_NO_SPLIT
+    const bool never_split = true;
+#else
+    const bool never_split = false;
+#endif
     const bool split = !never_split && ctx->batch_count > 1 && fused_plan(ctx, w, h, inner, 1).rows_interior >= 128;
     const unsigned instances_per_launch = split ? 1u : ctx->batch_count;
     FusedPlan plan = fused_plan(ctx, w, h, inner, (long)instances_per_launch);
@@ -903,11 +992,10 @@ int launch_fused_outer(flow2d_context* ctx, int constancy, const float* f0, cons
     }
     // XCD-aware block order: x-adjacent blocks share their halo columns, y-adjacent strips their halo rows; in one XCD
     // they meet in its L2 (reads of a 4096^2 launch 541 -> 455 MB; worth 1-3 % of the launch since the round-3 kernel
-    // is within reach of the memory system).  FLOW2D_FUSED_PLAIN_ORDER keeps the plain order (developer A/B knob).
-    static const bool plain_order = std::getenv("FLOW2D_FUSED_PLAIN_ORDER") != nullptr;
-    if (!plain_order) a.blocks_per_xcd = (plan.blocks + 7) / 8;
-    const int valid = 64 - 2 * ((int)inner + 1);
-    const unsigned strips_x = div_up(w, valid);
+    // is within reach of the memory system).
+#ifndef FLOW2D_FUSED_PLAIN_ORDER
+    a.blocks_per_xcd = (plan.blocks + 7) / 8;
+#endif
     const dim3 grid(a.blocks_per_xcd ? a.blocks_per_xcd * 8 : plan.blocks, 1, instances_per_launch);
     const bool pow2 = is_power_of_two(hx) && is_power_of_two(hy);
     int rc = 0;
@@ -937,3 +1025,18 @@ int launch_fused_outer(flow2d_context* ctx, int constancy, const float* f0, cons
 
 }  // namespace flow2d
 
+#ifdef FLOW2D_FUSED_STAMPS
+// developer builds only: the wave stamps recorded since the last call (8 words per wave), newest launches last
+extern "C" FLOW2D_API int flow2d_dev_fused_stamps(unsigned long long* out, size_t max_waves, size_t* waves)
+{
+    unsigned int n = 0;
+    if (hipMemcpyFromSymbol(&n, HIP_SYMBOL(g_fused_stamp_count), sizeof(n)) != hipSuccess) return FLOW2D_ERR_DEVICE;
+    const size_t take = std::min<size_t>(std::min<size_t>(n, kStampWaves), max_waves);
+    if (take && hipMemcpyFromSymbol(out, HIP_SYMBOL(g_fused_stamps), take * kStampWords * sizeof(unsigned long long)) != hipSuccess)
+        return FLOW2D_ERR_DEVICE;
+    const unsigned int zero = 0;
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_fused_stamp_count), &zero, sizeof(zero));
+    *waves = take;
+    return FLOW2D_OK;
+}
+#endif

@@ -59,14 +59,17 @@ hipError_t mark(flow2d_context* ctx, flow2d_timing_slot* slot)
 }
 }  // namespace
 
-// largest level (pixels) AUTO gives to the tiled kernel; FLOW2D_TILED_MAX_PIXELS overrides (developer knob).  Measured
+// largest level (pixels) AUTO gives to the tiled kernel (developer builds, -DFLOW2D_DEV_BUILD: the environment variable
+// FLOW2D_TILED_MAX_PIXELS overrides; the product library reads no environment variable here).  Measured
 // against the strips as they are at the end of round 3 (tools/time_levels.py; level solve 10 x 5, tiles / strips, ms):
 // Grey 384^2 0.111 / 0.115, 512^2 0.119 / 0.165, 640^2 0.193 / 0.170, 768^2 0.253 / 0.181, 1024^2 0.340 / 0.260;
 // Gradient 512^2 0.127 / 0.183, 640^2 0.207 / 0.182, 1024^2 0.366 / 0.280, 1920 x 1080 0.679 / 0.393.
 static size_t tiled_max_pixels(int data_constancy)
 {
+#ifdef FLOW2D_DEV_BUILD
     static const long long forced = std::getenv("FLOW2D_TILED_MAX_PIXELS") ? std::atoll(std::getenv("FLOW2D_TILED_MAX_PIXELS")) : -1;
     if (forced >= 0) return static_cast<size_t>(forced);
+#endif
     (void)data_constancy;  // the same crossover for the brightness and the gradient terms
     return static_cast<size_t>(600) * 600;
 }
@@ -186,7 +189,11 @@ int flow2d_solve_level(flow2d_context* ctx, const float* frame_0, const float* f
         if (per_launch) FLOW2D_HIP_TRY(mark(ctx, slot));
         ++launches;
     }
+#ifdef FLOW2D_DEV_BUILD  // uniform strips of that many rows instead of the planner's choice
     static const int rows_env = std::getenv("FLOW2D_FUSED_ROWS") ? std::atoi(std::getenv("FLOW2D_FUSED_ROWS")) : 0;
+#else
+    const int rows_env = 0;
+#endif
     // Fused path: one launch per outer iteration does phi/ksi and up to 5 sweeps (solve_fused.hip); phi and ksi
     // are not materialised, so their planes serve as a third (du, dv) pair.  More than 5 sweeps per outer
     // iteration are split into equal chunks: every chunk rebuilds the coefficients from the outer iteration's

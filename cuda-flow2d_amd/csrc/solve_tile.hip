@@ -316,7 +316,11 @@ int launch_tiled_outer(flow2d_context* ctx, int constancy, const float* f0, cons
     // level thinly; 16 x 16 (28 x 28 region, 3x) up to 352^2; 32 x 32 (44 x 44 region, two pixels per thread, 1.9x)
     // above: fewer, larger workgroups, two of them per CU (64 VGPRs), so one tile's barriers hide behind the other's
     // arithmetic.
-    static const int variant = std::getenv("FLOW2D_TILE_VARIANT") ? std::atoi(std::getenv("FLOW2D_TILE_VARIANT")) : 0;  // developer knob
+#ifdef FLOW2D_DEV_BUILD  // force a tile size: 1 = 8 x 8, 2 = 16 x 16, 3 = 32 x 32
+    static const int variant = std::getenv("FLOW2D_TILE_VARIANT") ? std::atoi(std::getenv("FLOW2D_TILE_VARIANT")) : 0;
+#else
+    const int variant = 0;
+#endif
     const bool tiny = w * h <= 160 * 160, mid = w * h <= 352 * 352;
     if (variant == 1 || (variant == 0 && tiny))
         launch_tiles<8, 8, 512>(grad, dim3(div_up(w, 8), div_up(h, 8), ctx->batch_count), ctx->stream, a);

@@ -9,6 +9,16 @@
 
 #include "flow2d_c_abi.h"
 
+// FLOW2D_DATA2D_NO_DEVICE: a build of this file for host-only tools (flow2d_batch_selftest) that must not link the HIP
+// library: a request for page-locked memory is then served from pageable memory, like any failed pinned allocation.
+#ifdef FLOW2D_DATA2D_NO_DEVICE
+static int HostAlloc(size_t, void**) { return FLOW2D_ERR_DEVICE; }
+static void HostFree(void*) {}
+#else
+static int HostAlloc(size_t bytes, void** p) { return flow2d_host_alloc(nullptr, bytes, p); }
+static void HostFree(void* p) { flow2d_host_free(nullptr, p); }
+#endif
+
 namespace {
 struct FileCloser {
     void operator()(std::FILE* f) const
@@ -57,7 +67,7 @@ bool Data2D::Allocate(size_t width, size_t height, HostMemory memory)
     const bool want_pinned = memory == HostMemory::Pinned || (memory == HostMemory::Default && g_default_pinned);
     if (want_pinned) {
         void* p = nullptr;
-        if (flow2d_host_alloc(nullptr, count * sizeof(float), &p) == FLOW2D_OK && p) {
+        if (HostAlloc(count * sizeof(float), &p) == FLOW2D_OK && p) {
             data_ = static_cast<float*>(p);
             pinned_ = true;
         }
@@ -78,7 +88,7 @@ bool Data2D::Allocate(size_t width, size_t height, HostMemory memory)
 void Data2D::Free()
 {
     if (data_) {
-        if (pinned_) flow2d_host_free(nullptr, data_);
+        if (pinned_) HostFree(data_);
         else delete[] data_;
     }
     data_ = nullptr;

@@ -322,14 +322,19 @@ void OpticalFlow2D::ComputeFlow(Data2D& frame_0, Data2D& frame_1, Data2D& flow_u
 }
 
 namespace {
-// Everything a recorded pyramid depends on: the four caller buffers and the nine (+1) parameters.
-std::vector<unsigned char> GraphKey(const std::vector<DevicePtr>& planes, OperationParameters& params)
+// Everything a recorded pyramid depends on: which entry recorded it ('P': a pair or a tall group through
+// ComputeFlowDevice, 'G': a group gathered from scattered planes -- a group of ONE scattered pair names the same four
+// planes as the pair entry but records gather -> pyramid of one instance -> hand back), the number of instances, the
+// caller buffers and the nine (+1) parameters.
+std::vector<unsigned char> GraphKey(char entry, size_t instances, const std::vector<DevicePtr>& planes, OperationParameters& params)
 {
     std::vector<unsigned char> key;
     auto put = [&key](const void* p, size_t n) {
         const unsigned char* q = static_cast<const unsigned char*>(p);
         key.insert(key.end(), q, q + n);
     };
+    put(&entry, sizeof(entry));
+    put(&instances, sizeof(instances));
     put(planes.data(), planes.size() * sizeof(DevicePtr));
     const char* size_keys[] = {"warp_levels_count", "outer_iterations_count", "inner_iterations_count", "median_radius"};
     const char* float_keys[] = {"warp_scale_factor", "equation_alpha", "equation_smoothness", "equation_data",
@@ -397,7 +402,7 @@ bool OpticalFlow2D::ComputeFlowDevice(DevicePtr dev_frame_0, DevicePtr dev_frame
     if (!IsInitialized() || !dev_frame_0 || !dev_frame_1 || !dev_flow_u || !dev_flow_v) return false;
     active_group_ = group_;
     if (!use_graph || timing_mode != 0) return QueuePair(dev_frame_0, dev_frame_1, dev_flow_u, dev_flow_v, params);
-    return ReplayOrRecord(GraphKey({dev_frame_0, dev_frame_1, dev_flow_u, dev_flow_v}, params), [&] {
+    return ReplayOrRecord(GraphKey('P', group_, {dev_frame_0, dev_frame_1, dev_flow_u, dev_flow_v}, params), [&] {
         return QueuePair(dev_frame_0, dev_frame_1, dev_flow_u, dev_flow_v, params);
     });
 }
@@ -407,7 +412,7 @@ bool OpticalFlow2D::ComputeFlowGroupDevice(size_t count, const DevicePtr* dev_fr
                                            OperationParameters& params)
 {
     if (!IsInitialized() || !dev_frames_0 || !dev_frames_1 || !dev_flows_u || !dev_flows_v) return false;
-    if (count == 0 || count > group_ || 2 * count > FLOW2D_COPY_PLANES_MAX) {
+    if (count == 0 || count > group_) {
         std::printf("Error: '%s': a group of %zu pairs (1..%zu).\n", GetName(), count, group_);
         return false;
     }
@@ -429,7 +434,7 @@ bool OpticalFlow2D::ComputeFlowGroupDevice(size_t count, const DevicePtr* dev_fr
     }
     if (!use_graph || timing_mode != 0)
         return QueueScatteredGroup(count, dev_frames_0, dev_frames_1, dev_flows_u, dev_flows_v, params);
-    return ReplayOrRecord(GraphKey(planes, params), [&] {
+    return ReplayOrRecord(GraphKey('G', count, planes, params), [&] {
         return QueueScatteredGroup(count, dev_frames_0, dev_frames_1, dev_flows_u, dev_flows_v, params);
     });
 }
@@ -447,10 +452,19 @@ bool OpticalFlow2D::QueueScatteredGroup(size_t count, const DevicePtr* dev_frame
         src.push_back(AsPlane(dev_frames_0[g])), dst.push_back(slot(0, g));
         src.push_back(AsPlane(dev_frames_1[g])), dst.push_back(slot(1, g));
     }
-    if (CheckFlow2DError(flow2d_copy_planes(context_, src.size(), src.data(), dst.data(), dev_container_size_.pitch,
-                                            dev_container_size_.width, dev_container_size_.height),
-                         "flow2d_copy_planes"))
-        return false;
+    // one launch per FLOW2D_COPY_PLANES_MAX planes (the pointer tables travel in the kernel arguments): groups of up to 32
+    // pairs gather with one launch, the largest (64) with two
+    auto copy_planes = [&]() {
+        for (size_t first = 0; first < src.size(); first += FLOW2D_COPY_PLANES_MAX) {
+            const size_t n = std::min<size_t>(FLOW2D_COPY_PLANES_MAX, src.size() - first);
+            if (CheckFlow2DError(flow2d_copy_planes(context_, n, src.data() + first, dst.data() + first, dev_container_size_.pitch,
+                                                    dev_container_size_.width, dev_container_size_.height),
+                                 "flow2d_copy_planes"))
+                return false;
+        }
+        return true;
+    };
+    if (!copy_planes()) return false;
     active_group_ = count;
     const bool ok = QueuePair(group_staging_[0], group_staging_[1], group_staging_[2], group_staging_[3], params);
     active_group_ = group_;
@@ -460,9 +474,7 @@ bool OpticalFlow2D::QueueScatteredGroup(size_t count, const DevicePtr* dev_frame
         src.push_back(slot(2, g)), dst.push_back(AsPlane(dev_flows_u[g]));
         src.push_back(slot(3, g)), dst.push_back(AsPlane(dev_flows_v[g]));
     }
-    return !CheckFlow2DError(flow2d_copy_planes(context_, src.size(), src.data(), dst.data(), dev_container_size_.pitch,
-                                                dev_container_size_.width, dev_container_size_.height),
-                             "flow2d_copy_planes");
+    return copy_planes();
 }
 
 bool OpticalFlow2D::QueuePair(DevicePtr dev_frame_0, DevicePtr dev_frame_1, DevicePtr dev_flow_u,

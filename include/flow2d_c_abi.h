@@ -362,6 +362,10 @@ typedef struct flow2d_timing_record {
  * NaN result -- repeats its strip with the plain division.  Number of such repeats on this context since it was
  * created (synchronises the stream). */
 FLOW2D_API int flow2d_fused_fallbacks(flow2d_context* ctx, unsigned long long* waves);
+/* Waves of launches that never tried the short forms because the level's grid spacing lies outside the range they are
+ * proven for (2h or 4h outside [2^-30, 2^40], a NaN spacing): such a launch runs the plain expressions throughout.  Counted
+ * apart from the guard trips above (synchronises the stream). */
+FLOW2D_API int flow2d_fused_plain_waves(flow2d_context* ctx, unsigned long long* waves);
 
 FLOW2D_API int flow2d_timing_enable(flow2d_context* ctx, int mode);
 /* mode 2 brackets individual launches only for levels of at least min_width x min_height pixels

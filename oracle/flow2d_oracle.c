@@ -8,7 +8,7 @@
  *
  * PARITY STATUS: pinned against the reference itself, two ways (the reference ships no tests or vectors of its own):
  *   (1) its device kernels: src/kernels/{add,convolution,median,registration,resample,solve}_2d.cu are compiled
- *       for gfx950 from where they lie (oracle/Makefile -> oracle/_ref/*.co, no FMA contraction) and run on an
+ *       for gfx950 from where they lie (oracle/Makefile -> oracle/_ref/<op>_2d.co, no FMA contraction) and run on an
  *       MI355X through oracle/ref_driver.cpp (symbol names, launch geometry and argument order of the reference's
  *       operator layer).  Their outputs on seeded inputs -- every kernel, CudaOperationSolve2D::Execute, and whole
  *       ComputeFlow runs on rub1/rub2 (settings.xml values and main.cpp defaults) and synthetic pairs -- are the

@@ -1,0 +1,110 @@
+"""The rank logic of the C++ multi-GPU driver flow2d_batch (cuda-flow2d_amd/host/batch_driver.cpp) at world sizes 2, 3
+and 8 WITHOUT a GPU: flow2d_batch_selftest runs the same RunBatchRank as the product over an in-process loopback
+(threads + shared memory instead of librccl) with planes in host memory and a stamp instead of the flow computation
+(u = 2 f0 + 1, v = f1 - f0 + levels).  Pinned here: pair k -> rank k mod world, the padded gather blocks and their byte
+offsets, the flow_%04d files rank 0 writes, that only rank 0's parameters count, and that a rank which fails locally
+takes every rank out with the same exit code instead of leaving the others blocked in a collective.
+(The reference has no counterpart: one context on device 0, src/utils/cuda_utils.cpp:43.)"""
+import json
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+TOOL = os.path.join(ROOT, "cuda-flow2d_amd", "host", "flow2d_batch_selftest")
+
+
+def run(args, timeout=60):
+    return subprocess.run([TOOL] + [str(a) for a in args], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
+                          timeout=timeout)
+
+
+def frames_of(k, w, h):
+    y, x = np.mgrid[0:h, 0:w]
+    f0 = (1000.0 * k + x + 0.5 * y).astype(np.float32)
+    f1 = (f0 + np.float32(0.25) * np.float32(k + 1)).astype(np.float32)
+    return f0, f1
+
+
+@pytest.mark.parametrize("world", [1, 2, 3, 8])
+@pytest.mark.parametrize("pairs", [5, 64])
+def test_pairs_ranks_blocks_and_files(tmp_path, world, pairs):
+    w, h, levels = 100, 12, 7  # pitch 512 B: rows are padded, so a tight-for-pitched mix-up shows
+    pairs_dir, out_dir = tmp_path / "pairs", tmp_path / "out"
+    pairs_dir.mkdir()
+    out_dir.mkdir()
+    for k in range(pairs):
+        f0, f1 = frames_of(k, w, h)
+        f0.astype("<f4").tofile(pairs_dir / ("pair_%04d_0.raw" % k))
+        f1.astype("<f4").tofile(pairs_dir / ("pair_%04d_1.raw" % k))
+    p = run(["--world", world, "--pairs", pairs, "--width", w, "--height", h, "--levels", levels, "--repeat", 2,
+             "--pairs-dir", pairs_dir, "--out-dir", out_dir, "--print-layout"])
+    assert p.returncode == 0, p.stderr[-2000:]
+    line = json.loads([x for x in p.stdout.splitlines() if x.startswith("{")][0])
+    pitch = (w * 4 + 255) // 256 * 256
+    per_rank = -(-pairs // world)
+    plane = pitch * h
+    assert line["world"] == world and line["pairs"] == pairs and line["repeat"] == 2
+    assert line["pitch_bytes"] == pitch and line["pairs_per_block"] == per_rank
+    assert line["gather_bytes_per_rank"] == per_rank * 2 * plane  # ranks with fewer pairs pad their block
+    # pair k: rank k mod world, slot k // world of that rank's block
+    assert line["layout"] == [[k, k % world, k // world, (k % world) * per_rank * 2 * plane + (k // world) * 2 * plane]
+                              for k in range(pairs)]
+    digest = 1469598103934665603
+    for k in range(pairs):
+        f0, f1 = frames_of(k, w, h)
+        u = np.fromfile(out_dir / ("flow_%04d_u.raw" % k), "<f4").reshape(h, w)
+        v = np.fromfile(out_dir / ("flow_%04d_v.raw" % k), "<f4").reshape(h, w)
+        assert np.array_equal(u, np.float32(2) * f0 + np.float32(1)), k
+        # `levels` reaches every rank through the broadcast of rank 0's block (the other ranks are started with 1)
+        assert np.array_equal(v, f1 - f0 + np.float32(levels)), k
+    assert len(os.listdir(out_dir)) == 2 * pairs
+
+
+def test_digest_does_not_depend_on_the_world_size(tmp_path):
+    lines = []
+    for world in (1, 2, 5):
+        p = run(["--world", world, "--pairs", 11, "--width", 72, "--height", 40])
+        assert p.returncode == 0, p.stderr[-2000:]
+        lines.append(json.loads(p.stdout.splitlines()[-1]))
+    assert len({l["flows_fnv1a"] for l in lines}) == 1
+
+
+@pytest.mark.parametrize("phase", ["init", "load", "warmup", "pass", "gather-alloc"])
+@pytest.mark.parametrize("rank", [0, 2])
+def test_a_failing_rank_takes_every_rank_out(phase, rank):
+    """flow2d_batch_selftest returns 99 when the ranks disagree on the exit code, and the timeout catches a rank left
+    blocked in a collective (round 3's driver returned from the failing rank alone)."""
+    p = run(["--world", 3, "--pairs", 7, "--fail-rank", rank, "--fail-phase", phase], timeout=30)
+    expected = 0 if (phase == "gather-alloc" and rank != 0) else 1  # only rank 0 allocates the gathered buffer
+    assert p.returncode == expected, (p.returncode, p.stderr[-1000:])
+    if expected:
+        assert "another rank failed" in p.stderr
+        assert not [x for x in p.stdout.splitlines() if x.startswith("{")]  # no result line from a failed job
+
+
+def test_exit_codes_of_a_job(tmp_path):
+    pairs_dir = tmp_path / "pairs"
+    pairs_dir.mkdir()
+    w, h = 32, 8
+    for k in (0, 1, 3):  # pair 2 (rank 2 of 4) is missing: exit code 2 on every rank
+        for j, f in enumerate(frames_of(k, w, h)):
+            f.astype("<f4").tofile(pairs_dir / ("pair_%04d_%d.raw" % (k, j)))
+    p = run(["--world", 4, "--pairs", 4, "--width", w, "--height", h, "--pairs-dir", pairs_dir], timeout=30)
+    assert p.returncode == 2, p.stderr[-1000:]
+    # an output directory that does not exist: 255, the reference's code for an output that cannot be written
+    p = run(["--world", 2, "--pairs", 3, "--width", w, "--height", h, "--out-dir", tmp_path / "nope"], timeout=30)
+    assert p.returncode == 255
+    assert run(["--no-such-flag"]).returncode == 3
+
+
+def test_more_ranks_than_pairs(tmp_path):
+    out_dir = tmp_path / "out"
+    out_dir.mkdir()
+    p = run(["--world", 8, "--pairs", 3, "--width", 40, "--height", 10, "--out-dir", out_dir, "--print-layout"])
+    assert p.returncode == 0, p.stderr[-1000:]
+    line = json.loads(p.stdout.splitlines()[-1])
+    assert line["pairs_per_block"] == 1 and [r for _, r, _, _ in line["layout"]] == [0, 1, 2]
+    assert len(os.listdir(out_dir)) == 6

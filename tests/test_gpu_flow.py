@@ -685,6 +685,75 @@ def test_groups_formed_from_scattered_planes(flow2d, oracle, constancy, sigma):
         c.close()
 
 
+def test_scattered_group_larger_than_one_gather_launch(flow2d, oracle):
+    """Groups of more than 32 scattered pairs need more planes than one flow2d_copy_planes launch names (64): the gather
+    and the hand-back are issued in chunks.  40 small pairs as ONE lock-step group, every pair against the oracle.
+    (Round 3 accepted group sizes up to 64 at Initialize and then refused every such group.)"""
+    w, h, G = 64, 48, 40
+    p = (2, 0.5, 2, 3, 35.0, 0.001, 0.001, 3, 1.0)
+    pairs = [oracle.synthetic_pair(w, h, 0.5 + 0.05 * k, -0.3 + 0.02 * k, seed=900 + k, noise=True) for k in range(G)]
+    c = flow2d.Context(0)
+    batch = flow2d.OpticalFlowBatch(w, h, flow2d.GREY, lanes=1, group_size=G)
+    try:
+        f0s = [c.plane(w, h, q[0]) for q in pairs]
+        f1s = [c.plane(w, h, q[1]) for q in pairs]
+        us = [c.plane(w, h).fill_bytes(0x7f) for _ in pairs]
+        vs = [c.plane(w, h).fill_bytes(0x7f) for _ in pairs]
+        c.synchronize()
+        for graph in (False, True, True):
+            batch.use_graph(graph)
+            batch.compute_flow_batch_device_grouped([q.ptr for q in f0s], [q.ptr for q in f1s], [q.ptr for q in us],
+                                                    [q.ptr for q in vs], batch.params(*p))
+            batch.synchronize()
+            for k, (f0, f1) in enumerate(pairs):
+                ou, ov, _ = oracle.compute_flow(f0, f1, *p, flow2d.GREY)
+                assert np.array_equal(us[k].download(), ou) and np.array_equal(vs[k].download(), ov), (graph, k)
+            for q in us + vs:
+                q.fill_bytes(0x7f)
+            c.synchronize()
+    finally:
+        batch.close()
+        c.close()
+
+
+def test_group_of_one_scattered_pair_and_the_tall_entry_do_not_share_a_graph(flow2d, oracle):
+    """On an object with groups of two, ComputeFlowGroupDevice(count = 1) and ComputeFlowDevice may be handed the same
+    four pointers: the first records gather -> pyramid of ONE instance -> hand back, the second a pyramid over the TWO
+    instances of tall containers at those pointers.  Their graphs are keyed apart (entry tag + instance count); round 3
+    replayed whichever had been recorded first for both."""
+    w, h, G = 96, 64, 2
+    p = (3, 0.5, 2, 4, 35.0, 0.001, 0.001, 5, 1.2)
+    pairs = [oracle.synthetic_pair(w, h, 1.0 + 0.5 * k, -0.4 * k, seed=940 + k, noise=True) for k in range(G)]
+    want = [oracle.compute_flow(f0, f1, *p, flow2d.GREY)[:2] for f0, f1 in pairs]
+    c = flow2d.Context(0)
+    batch = flow2d.OpticalFlowBatch(w, h, flow2d.GREY, lanes=1, group_size=G)
+    try:
+        # tall containers: pair g of every plane `group_stride` bytes behind the pointer
+        tall = [c.plane(w, h * G, np.vstack([q[0] for q in pairs])), c.plane(w, h * G, np.vstack([q[1] for q in pairs])),
+                c.plane(w, h * G), c.plane(w, h * G)]
+        c.synchronize()
+        batch.use_graph(True)
+        for order in ("scattered first", "again"):
+            # a scattered group of one pair: only the first instance's flow is written
+            for q in tall[2:]:
+                q.fill_bytes(0x7f)
+            c.synchronize()
+            batch.compute_flow_batch_device_grouped([tall[0].ptr], [tall[1].ptr], [tall[2].ptr], [tall[3].ptr], batch.params(*p))
+            batch.synchronize()
+            u, v = tall[2].download(), tall[3].download()
+            assert np.array_equal(u[:h], want[0][0]) and np.array_equal(v[:h], want[0][1]), order
+            assert np.all(u[h:].view(np.uint32) == 0x7f7f7f7f) and np.all(v[h:].view(np.uint32) == 0x7f7f7f7f), order
+            # the tall entry on the same pointers: both instances
+            batch.compute_flow_batch_device([tall[0].ptr], [tall[1].ptr], [tall[2].ptr], [tall[3].ptr], batch.params(*p))
+            batch.synchronize()
+            u, v = tall[2].download(), tall[3].download()
+            for g in range(G):
+                assert np.array_equal(u[g * h:(g + 1) * h], want[g][0]) and np.array_equal(v[g * h:(g + 1) * h], want[g][1]), (order, g)
+    finally:
+        batch.close()
+        c.close()
+
+
 def test_cli_full_settings_xml_values(flow2d, tmp_path):
     """The `flow2d` binary with the values of the reference's settings.xml untouched (20 levels at 0.9, 20 x 5 sweeps,
     median 5, sigma 0.45, alpha 3.5) on rub1/rub2: the flow raws it writes hash to what the reference's own kernels

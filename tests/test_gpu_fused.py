@@ -233,11 +233,12 @@ def test_tiny_differences_over_a_non_power_of_two_spacing_fall_back(ctx, oracle)
 
 def test_a_spacing_outside_the_guarded_range_takes_the_plain_divisions(ctx, oracle):
     """h = 3 * 2^40: 2h is above 2^40, outside the range the three-step division is proven for; the launch runs the
-    fallback pass throughout (every wave counted) and equals the oracle."""
+    plain pass throughout -- every wave counted as a plain-only wave, none as a guard trip -- and equals the oracle."""
     w, h = 640, 200
     f0, f1, u, v, _, _ = level_fields(oracle, w, h, 55)
     big = np.float32(3.0 * 2.0 ** 40)
-    before = ctx.fused_fallbacks()
+    before, plain_before = ctx.fused_fallbacks(), ctx.fused_plain_waves()
     a, b, odu, odv = fused_vs_oracle(ctx, oracle, f0, f1, u, v, w, h, w, h, big, np.float32(1.1), 35.0, 1, 5, 0)
     assert np.array_equal(bits(a), bits(odu)) and np.array_equal(bits(b), bits(odv))
-    assert ctx.fused_fallbacks() > before
+    assert ctx.fused_plain_waves() > plain_before
+    assert ctx.fused_fallbacks() == before  # the guard counter is for guard trips only

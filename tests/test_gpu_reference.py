@@ -22,7 +22,10 @@ pytestmark = pytest.mark.gpu
 def RK():
     from oracle import ref_kernels
     if not ref_kernels.available():
-        pytest.skip("oracle/_ref holds no reference kernels (build with `make -C oracle ref` where /root/reference exists)")
+        # these tests only run where a HIP device is (-m gpu): there the prebuilt oracle/_ref must have travelled with the
+        # snapshot.  A skip would let the pin to the reference's own kernels disappear without anybody noticing.
+        pytest.fail("oracle/_ref holds no reference kernels: build them with `make -C oracle ref` where /root/reference "
+                    "exists (python -c 'import __graft_entry__ as g; g.build()') and ship oracle/_ref with the snapshot")
     return ref_kernels
 
 

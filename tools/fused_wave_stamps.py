@@ -1,0 +1,134 @@
+"""Developer tool (round 4): where does a launch of the fused strip kernel spend its time, wave by wave?
+
+Needs a developer build of the library with the wave stamps compiled in:
+    make -C cuda-flow2d_amd/csrc BUILD=build_stamps LIB=$PWD/ab/stamps.so EXTRA="-DFLOW2D_DEV_BUILD -DFLOW2D_FUSED_STAMPS -DFLOW2D_FUSED_DEV"
+    FLOW2D_HIP_LIB=$PWD/ab/stamps.so python tools/fused_wave_stamps.py [WxH[*instances]] [grey|grad]
+Every wave records its start and end on the 100 MHz clock, its shader cycles, where it ran (XCC, SE, CU, SIMD) and which
+strip it had.  Printed per launch: the span of the launch, the distribution of the waves' lifetimes, the spread of their
+start and end times, the clock they held, and the lifetimes by strip kind, by XCC and by how many waves shared the SIMD."""
+import collections
+import ctypes as C
+import importlib
+import os
+import statistics
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+F = importlib.import_module("cuda-flow2d_amd")
+
+
+def fetch(lib):
+    n = C.c_size_t(0)
+    buf = np.zeros((1 << 16, 8), np.uint64)
+    rc = lib.flow2d_dev_fused_stamps(buf.ctypes.data_as(C.c_void_p), C.c_size_t(1 << 16), C.byref(n))
+    assert rc == 0, rc
+    return buf[:n.value]
+
+
+def pct(v, q):
+    return float(np.percentile(v, q))
+
+
+def report(st, label):
+    t0 = st[:, 0].astype(np.int64) * 10  # ns
+    t1 = st[:, 1].astype(np.int64) * 10
+    cyc = st[:, 2].astype(np.float64)
+    hw = st[:, 3].astype(np.int64)
+    xcc = st[:, 4].astype(np.int64) & 15
+    edge = (st[:, 6].astype(np.int64) >> 8) & 1
+    rows = (st[:, 7].astype(np.int64) >> 32) - (st[:, 7].astype(np.int64) & 0xffffffff)
+    simd = (hw >> 4) & 3
+    cu = (hw >> 8) & 15
+    sh = (hw >> 12) & 1
+    se = (hw >> 13) & 7
+    life = (t1 - t0) / 1e3  # us
+    base = t0.min()
+    span = (t1.max() - base) / 1e3
+    print("%s: %d waves, launch span %.1f us" % (label, len(st), span))
+    print("  wave lifetime us: min %.1f  p10 %.1f  median %.1f  mean %.1f  p90 %.1f  max %.1f" %
+          (life.min(), pct(life, 10), pct(life, 50), life.mean(), pct(life, 90), life.max()))
+    print("  start after launch begin us: median %.1f  p90 %.1f  max %.1f;   end before launch end us: median %.1f  p90 %.1f  max %.1f" %
+          (pct((t0 - base) / 1e3, 50), pct((t0 - base) / 1e3, 90), (t0 - base).max() / 1e3,
+           pct(span - (t1 - base) / 1e3, 50), pct(span - (t1 - base) / 1e3, 90), (span - (t1 - base) / 1e3).max()))
+    print("  shader clock held (cycles / lifetime): median %.2f GHz  min %.2f  max %.2f" %
+          (pct(cyc / (life * 1e3), 50), (cyc / (life * 1e3)).min(), (cyc / (life * 1e3)).max()))
+    for e in (0, 1):
+        m = edge == e
+        if m.any():
+            steps = rows[m] + 13
+            print("  %s strips: %5d waves, rows %d..%d, lifetime median %.1f us (%.3f us, %.0f cycles per row step)" %
+                  ("border  " if e else "interior", m.sum(), rows[m].min(), rows[m].max(), pct(life[m], 50),
+                   pct(life[m] / steps, 50), pct(cyc[m] / steps, 50)))
+    print("  by XCC (waves, median lifetime, last end): " +
+          "  ".join("%d: %d %.1f %.1f" % (x, (xcc == x).sum(), pct(life[xcc == x], 50), (t1[xcc == x].max() - base) / 1e3)
+                    for x in sorted(set(xcc.tolist()))))
+    # how many waves of the launch shared a SIMD
+    key = ((((xcc * 8 + se) * 2 + sh) * 16 + cu) * 4 + simd)
+    cnt = collections.Counter(key.tolist())
+    share = np.array([cnt[k] for k in key.tolist()])
+    print("  SIMDs used %d; waves by SIMD occupancy: " % len(cnt) +
+          "  ".join("%d per SIMD: %d waves, median lifetime %.1f" % (c, (share == c).sum(), pct(life[share == c], 50))
+                    for c in sorted(set(share.tolist()))))
+    slots = collections.defaultdict(list)
+    for k, wv in zip(key.tolist(), (hw & 15).tolist()):
+        slots[k].append(wv)
+    print("  wave slots of the waves that shared a SIMD: %s" %
+          dict(collections.Counter(tuple(sorted(v)) for v in slots.values()).most_common(6)))
+    cus = collections.Counter((key // 4).tolist())
+    print("  CUs used %d; waves per CU: %s" % (len(cus), dict(collections.Counter(cus.values()))))
+
+
+def main():
+    args = [a for a in sys.argv[1:]]
+    case = args[0] if args and "x" in args[0] else "4096x4096"
+    modes = [a for a in args if a in ("grey", "grad")] or ["grey", "grad"]
+    inst = 1
+    if "*" in case:
+        case, n = case.split("*")
+        inst = int(n)
+    w, h = (int(t) for t in case.split("x"))
+    lib = F.hip_lib()
+    if not hasattr(lib, "flow2d_dev_fused_stamps"):
+        raise SystemExit("this library has no wave stamps: build ab/stamps.so and set FLOW2D_HIP_LIB (see the docstring)")
+    ctx = F.Context(0)
+    rng = np.random.default_rng(0)
+    tall = h * inst
+    planes = [ctx.plane(w, tall, rng.normal(0, 1, (tall, w)).astype(np.float32)) for _ in range(4)]
+    du, dv, phi, ksi, tdu, tdv = (ctx.plane(w, tall).fill_bytes(0) for _ in range(6))
+    if inst > 1:
+        lib.flow2d_context_set_batch.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t]
+        assert lib.flow2d_context_set_batch(ctx.handle, inst, planes[0].pitch * h) == 0
+    for mode in modes:
+        constancy = 0 if mode == "grey" else 1
+        for rep in range(12):  # warm: sustained clocks
+            ctx.solve_level(*planes, du, dv, phi, ksi, tdu, tdv, w, h, 1.0, 1.0, 35.0, 0.001, 0.001, 10, 5, constancy,
+                            F.SOLVER_FUSED, container_height=h)
+        ctx.synchronize()
+        fetch(lib)
+        e0, e1 = ctx.event(), ctx.event()
+        ctx.record(e0)
+        ctx.solve_level(*planes, du, dv, phi, ksi, tdu, tdv, w, h, 1.0, 1.0, 35.0, 0.001, 0.001, 4, 5, constancy,
+                        F.SOLVER_FUSED, container_height=h)
+        ctx.record(e1)
+        ms = ctx.elapsed_ms(e0, e1)
+        st = fetch(lib)
+        # split into launches by start time: the waves of one launch start within a few us, launches are >100 us apart
+        order = np.argsort(st[:, 0])
+        st = st[order]
+        gaps = np.nonzero(np.diff(st[:, 0].astype(np.int64)) > 2000)[0]  # > 20 us
+        launches = np.split(st, gaps + 1)
+        print("== %dx%d x%d %s: 4 outer iterations %.1f us (%.1f per launch by events); %d launches found" %
+              (w, h, inst, mode, ms * 1e3, ms * 1e3 / 4, len(launches)))
+        out = os.environ.get("FLOW2D_STAMPS_OUT")
+        if out:  # raw stamps of the last launch, for offline analysis
+            np.save("%s_%dx%dx%d_%s.npy" % (out, w, h, inst, mode), launches[-1])
+        for k, l in enumerate(launches):
+            if k in (0, len(launches) - 1):
+                report(l, "  launch %d%s" % (k, " (first of the level: du = dv = 0, not read)" if k == 0 else ""))
+    ctx.close()
+
+
+if __name__ == "__main__":
+    main()
