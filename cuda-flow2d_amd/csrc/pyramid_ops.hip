@@ -268,27 +268,32 @@ __global__ __launch_bounds__(256) void resample_kernel(const float* __restrict__
     const float* base = kAlongX ? in + static_cast<size_t>(y) * pitch : in + x;
     const size_t stride = kAlongX ? 1 : pitch;
     float value = 0.f;
-    // the cells are summed in order (parity), but their loads do not depend on the sum: eight at a time in flight
-    // (a coarse level sums up to 128 cells per output with only a few thousand outputs to hide the latency)
-    int j = 0;
-    for (; j + 8 <= cells; j += 8) {
-        float v[8];
+    // The cells are summed in order (parity), but their loads do not depend on the sum.  Only the first and the last cell
+    // carry a fraction other than 1 (resample_2d.cu:58-66; v * 1.f is v); the ones between are plain additions, their
+    // loads issued 32 (long chains: the y pass of the coarsest levels of a large frame sums 2048 rows per output with a
+    // handful of outputs -- pure latency, 147 -> see profiles/r04 at 8192^2) or 8 at a time.
+    if (cells == 1) {
+        value += base[static_cast<size_t>(left_i) * stride] * delta;
+    } else if (cells > 1) {
+        const int last = left_i + cells - 1;
+        value += base[static_cast<size_t>(left_i) * stride] * (static_cast<float>(left_i + 1) - left_f);
+        int k = left_i + 1;
+        for (; k + 32 <= last; k += 32) {
+            float v[32];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) v[k] = base[static_cast<size_t>(left_i + j + k) * stride];
+            for (int i = 0; i < 32; ++i) v[i] = base[static_cast<size_t>(k + i) * stride];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            float frac = 1.f;
-            if (j + k == 0) frac = static_cast<float>(left_i + 1) - left_f;
-            if (j + k == cells - 1) frac = right_f - static_cast<float>(left_i + j + k);
-            value += v[k] * frac;
+            for (int i = 0; i < 32; ++i) value += v[i];
         }
-    }
-    for (; j < cells; ++j) {
-        float frac = 1.f;
-        if (j == 0) frac = static_cast<float>(left_i + 1) - left_f;
-        if (j == cells - 1) frac = right_f - static_cast<float>(left_i + j);
-        if (cells == 1) frac = delta;
-        value += base[static_cast<size_t>(left_i + j) * stride] * frac;
+        for (; k + 8 <= last; k += 8) {
+            float v[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] = base[static_cast<size_t>(k + i) * stride];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) value += v[i];
+        }
+        for (; k < last; ++k) value += base[static_cast<size_t>(k) * stride];
+        value += base[static_cast<size_t>(last) * stride] * (right_f - static_cast<float>(last));
     }
     out[static_cast<size_t>(y) * pitch + x] = value * normalization;
     }
@@ -441,6 +446,11 @@ __global__ __launch_bounds__(256) void resample_x_lds_kernel(const float* __rest
 // together, one output per thread, so the row's critical path is its longest chain instead of the sum of them
 // (8192^2, 12 levels, both frames: 3.7 ms -> see profiles/).  Inside a chain only the first and the last cell carry
 // a fraction other than 1 (resample_2d.cu:58-66), the others are plain additions with eight LDS reads in flight.
+// Which wave of a workgroup takes the longest chains: it rotates with the workgroup, so that the long-chain waves of the
+// workgroups sharing a CU do not all sit on the last SIMD.  (Only speed depends on it; (block >> 8) + (block >> 3), which
+// follows the dealing of workgroups to XCDs and CUs more closely, measured the same.)
+__device__ __forceinline__ unsigned long_chain_wave(unsigned block) { return block; }
+
 struct ResampleLevels {
     int count;
     int out_w[FLOW2D_RESAMPLE_MAX_LEVELS];
@@ -462,18 +472,20 @@ __device__ __forceinline__ float resample_x_output_lds(const float* __restrict__
     } else if (cells > 1) {
         const int last = left_i + cells - 1;
         value += cell(left_i) * (static_cast<float>(left_i + 1) - left_f);
+        // the cells between: fraction 1, value += row[k] * 1.f is value += row[k].  Up to the next multiple of 32 one by
+        // one; then whole blocks of 32 cells, which lie contiguously in LDS behind ONE address (the pad word follows each
+        // block): 32 reads with immediate offsets in flight and one addition per cell -- the dependent additions are what
+        // a 2048-cell chain costs, not the address arithmetic and the read latency of every single cell
         int k = left_i + 1;
-        for (; k + 8 <= last; k += 8) {  // fraction 1: value += row[k] * 1.f is value += row[k]
-            const float c0 = cell(k), c1 = cell(k + 1), c2 = cell(k + 2), c3 = cell(k + 3);
-            const float c4 = cell(k + 4), c5 = cell(k + 5), c6 = cell(k + 6), c7 = cell(k + 7);
-            value += c0;
-            value += c1;
-            value += c2;
-            value += c3;
-            value += c4;
-            value += c5;
-            value += c6;
-            value += c7;
+        const int head_end = min(last, (k + 31) & ~31);
+        for (; k < head_end; ++k) value += cell(k);
+        for (; k + 32 <= last; k += 32) {
+            const float* __restrict__ block = row + k + (k >> 5);
+            float c[32];
+#pragma unroll
+            for (int i = 0; i < 32; ++i) c[i] = block[i];
+#pragma unroll
+            for (int i = 0; i < 32; ++i) value += c[i];
         }
         for (; k < last; ++k) value += cell(k);
         value += cell(last) * (right_f - static_cast<float>(last));
@@ -504,8 +516,14 @@ __global__ __launch_bounds__(256) void resample_x_levels_kernel(const float* __r
         for (int g = threadIdx.x; g < out_w; g += 256)
             out[line + lv.col[l] + g] = resample_x_output_lds(row, in_w, g, delta, normalization);
     }
-    // all narrower levels together: item i of their concatenation -> (level, g)
-    for (int i = threadIdx.x; i < narrow_total; i += 256) {
+    // all narrower levels together: item i of their concatenation -> (level, g).  The concatenation runs from the widest
+    // to the narrowest level, i.e. from the shortest to the longest chains, so the long chains meet in ONE wave (dealt over
+    // all four, each wave would walk the longest chain with a few lanes active: four times the LDS and VALU instructions);
+    // which wave that is rotates with the workgroup -- the last wave of EVERY workgroup sits on the same SIMD of its CU,
+    // which then issued the additions of all the long chains while the other three SIMDs idled.
+    for (int first = 0; first < narrow_total; first += 256) {
+        const int i = first + static_cast<int>((threadIdx.x + 64u * long_chain_wave(blockIdx.x)) & 255u);
+        if (i >= narrow_total) continue;
         int g = i, level = -1;
         for (int l = 0; l < lv.count; ++l) {
             const int out_w = lv.out_w[l];
@@ -519,6 +537,135 @@ __global__ __launch_bounds__(256) void resample_x_levels_kernel(const float* __r
         const float delta = static_cast<float>(in_w) / static_cast<float>(out_w);
         const float normalization = static_cast<float>(out_w) / static_cast<float>(in_w);
         out[line + lv.col[level] + g] = resample_x_output_lds(row, in_w, g, delta, normalization);
+    }
+}
+
+// The same for levels whose ratio in_w / out_w is a power of two -- every level of a 0.5 pyramid on a frame whose width
+// divides evenly (4096, 8192, 1024, 1920 = 15 * 128 ...).  Then delta is an integer R, every output sums exactly R whole
+// cells (all fractions of resample_2d.cu:58-66 are 1, and c * 1.f is c) and normalization is 1 / R: the output is
+// ((0 + c[0]) + c[1] + ... + c[R-1]) * (1 / R), additions in cell order.
+//  * Levels with R <= 32: a thread owns 32 consecutive cells of the row -- eight 16-byte loads, a whole 128-byte line per
+//    lane -- and sums them for every such level out of REGISTERS: no LDS traffic, no address arithmetic per cell, no
+//    bank conflicts (the general kernel walks LDS with lane strides of 2 ... 16 words there: 2- to 16-way conflicts).
+//  * Levels with R >= 64 (long chains): the cells go to LDS once (32 contiguous words per thread, 16-byte aligned: four pad
+//    words per 32 cells and four more per 256, which spreads the cell positions the chains of a wave touch in one step over
+//    the banks), and one output per thread walks its R / 32 blocks there: eight 16-byte reads per block, issued a block
+//    ahead, and one dependent addition per cell -- a lone wave issues an instruction every four to five cycles whatever its
+//    kind, so one read per cell (ds_read_b32) doubled the time of a 2048-cell chain (level 8192 -> 4 alone: 257 us).  Chains of one length share a wave (the concatenation runs from the shortest to
+//    the longest), and the wave with the longest ones rotates with the workgroup over the four SIMDs of the CU.
+// 8192^2, 11 levels, both frames: 868 us (general kernel, round 3) -> see profiles/r04_experiments.
+constexpr int kPow2Cells = 32;  // cells per thread
+__device__ __forceinline__ int pow2_lds_index(int k) { return k + 4 * ((k >> 5) + (k >> 8)); }
+
+template <int R>
+__device__ __forceinline__ void pow2_emit(const float (&c)[kPow2Cells], float* __restrict__ dst)
+{
+    constexpr int kOutputs = kPow2Cells / R;
+    constexpr float kNorm = 1.f / static_cast<float>(R);
+    float r[kOutputs];
+#pragma unroll
+    for (int o = 0; o < kOutputs; ++o) {
+        float v = 0.f;
+#pragma unroll
+        for (int j = 0; j < R; ++j) v += c[o * R + j];
+        r[o] = v * kNorm;
+    }
+    if constexpr (kOutputs >= 4) {
+#pragma unroll
+        for (int o = 0; o < kOutputs; o += 4) *reinterpret_cast<float4*>(dst + o) = make_float4(r[o], r[o + 1], r[o + 2], r[o + 3]);
+    } else if constexpr (kOutputs == 2) {
+        *reinterpret_cast<float2*>(dst) = make_float2(r[0], r[1]);
+    } else {
+        dst[0] = r[0];
+    }
+}
+
+__global__ __launch_bounds__(256) void resample_x_levels_pow2_kernel(const float* __restrict__ in_a, float* __restrict__ out_a,
+                                                                     const float* __restrict__ in_b, float* __restrict__ out_b,
+                                                                     int in_w, int pitch, ResampleLevels lv, int deep_total,
+                                                                     BatchArg batch)
+{
+    extern __shared__ float row[];
+    const float* __restrict__ in = (batch_plane(batch) ? in_b : in_a) + batch_offset(batch);
+    float* __restrict__ out = (batch_plane(batch) ? out_b : out_a) + batch_offset(batch);
+    const size_t line = static_cast<size_t>(blockIdx.x) * pitch;
+    const int t = threadIdx.x;
+    if (t * kPow2Cells < in_w) {  // (in_w is a multiple of 32: whole threads)
+        float c[kPow2Cells];
+        const float4* __restrict__ src = reinterpret_cast<const float4*>(in + line + static_cast<size_t>(t) * kPow2Cells);
+#pragma unroll
+        for (int q = 0; q < kPow2Cells / 4; ++q) {
+            const float4 v = src[q];
+            c[4 * q] = v.x, c[4 * q + 1] = v.y, c[4 * q + 2] = v.z, c[4 * q + 3] = v.w;
+        }
+        if (deep_total > 0) {
+            float4* __restrict__ mine = reinterpret_cast<float4*>(row + pow2_lds_index(t * kPow2Cells));
+#pragma unroll
+            for (int q = 0; q < kPow2Cells / 4; ++q) mine[q] = make_float4(c[4 * q], c[4 * q + 1], c[4 * q + 2], c[4 * q + 3]);
+        }
+        for (int l = 0; l < lv.count; ++l) {
+            const int ratio = in_w / lv.out_w[l];  // a power of two (the launcher checked)
+            if (ratio > kPow2Cells) continue;
+            float* __restrict__ dst = out + line + lv.col[l] + t * (kPow2Cells / ratio);
+            switch (ratio) {
+                case 2: pow2_emit<2>(c, dst); break;
+                case 4: pow2_emit<4>(c, dst); break;
+                case 8: pow2_emit<8>(c, dst); break;
+                case 16: pow2_emit<16>(c, dst); break;
+                default: pow2_emit<32>(c, dst); break;
+            }
+        }
+    }
+    if (deep_total == 0) return;
+    __syncthreads();
+    // the long chains: item i of the concatenation of the levels with R >= 64 (in the order given: the pyramid lists its
+    // levels from the finest to the coarsest, i.e. from the shortest chains to the longest)
+    for (int first = 0; first < deep_total; first += 256) {
+        const int i = first + static_cast<int>((threadIdx.x + 64u * long_chain_wave(blockIdx.x)) & 255u);
+        if (i >= deep_total) continue;
+        int g = i, level = -1;
+        for (int l = 0; l < lv.count; ++l) {
+            const int out_w = lv.out_w[l];
+            if (in_w / out_w <= kPow2Cells || level >= 0) continue;
+            if (g < out_w)
+                level = l;
+            else
+                g -= out_w;
+        }
+        const int out_w = lv.out_w[level];
+        const int blocks = (in_w / out_w) / kPow2Cells;
+        float value = 0.f;
+        // the reads of the next block are issued before the additions of the current one (two register sets, the blocks of
+        // a chain taken in pairs: R >= 64 means an even number of them)
+        auto load = [&](float4 (&dst)[kPow2Cells / 4], int b) {
+            const float4* __restrict__ block = reinterpret_cast<const float4*>(row + pow2_lds_index((g * blocks + b) * kPow2Cells));
+#pragma unroll
+            for (int q = 0; q < kPow2Cells / 4; ++q) dst[q] = block[q];
+        };
+        auto add = [&](const float4 (&src)[kPow2Cells / 4]) {
+#pragma unroll
+            for (int q = 0; q < kPow2Cells / 4; ++q) {
+                value += src[q].x;
+                value += src[q].y;
+                value += src[q].z;
+                value += src[q].w;
+            }
+        };
+        float4 a[kPow2Cells / 4], n[kPow2Cells / 4];
+        // (the scheduling barriers keep the reads where they are written: left alone, the scheduler sinks them below the
+        //  additions of the block before, right in front of their first use, and every block waits for its read latency)
+        load(a, 0);
+        for (int b = 0; b < blocks; b += 2) {
+            load(n, b + 1);
+            __builtin_amdgcn_sched_barrier(0);
+            add(a);
+            __builtin_amdgcn_sched_barrier(0);
+            load(a, min(b + 2, blocks - 1));  // (after the last pair: a read nothing uses)
+            __builtin_amdgcn_sched_barrier(0);
+            add(n);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        out[line + lv.col[level] + g] = value * (static_cast<float>(out_w) / static_cast<float>(in_w));
     }
 }
 
@@ -811,8 +958,26 @@ int flow2d_resample_x_levels(flow2d_context* ctx, const float* input_a, float* p
         lv.out_w[l] = static_cast<int>(out_widths[l]);
         lv.col[l] = static_cast<int>(column_offsets[l]);
     }
-    const size_t lds_bytes = (in_width + in_width / 32 + 1) * sizeof(float);
     const unsigned planes = pair ? 2 : 1;
+    {   // every ratio a power of two, the frame a whole number of 32-cell threads of one workgroup: the register kernel
+        bool pow2 = in_width % kPow2Cells == 0 && in_width <= 256 * kPow2Cells && (pitch % 4) == 0;
+        int deep_total = 0;
+        for (size_t l = 0; l < level_count && pow2; ++l) {
+            const size_t ratio = in_width / out_widths[l];
+            pow2 = ratio >= 2 && ratio * out_widths[l] == in_width && (ratio & (ratio - 1)) == 0;
+            if (ratio > kPow2Cells) deep_total += static_cast<int>(out_widths[l]);
+        }
+        if (pow2) {
+            const size_t words = in_width + 4 * (in_width / 32 + in_width / 256) + 8;
+            resample_x_levels_pow2_kernel<<<dim3(static_cast<unsigned>(height), 1, flow2d::batch_z(ctx, planes)), 256,
+                                            deep_total ? words * sizeof(float) : 0, ctx->stream>>>(
+                input_a, packed_a, input_b, packed_b, static_cast<int>(in_width), static_cast<int>(pitch), lv, deep_total,
+                flow2d::batch_arg(ctx, planes));
+            FLOW2D_CHECK_LAUNCH();
+            return FLOW2D_OK;
+        }
+    }
+    const size_t lds_bytes = (in_width + in_width / 32 + 1) * sizeof(float);
     resample_x_levels_kernel<<<dim3(static_cast<unsigned>(height), 1, flow2d::batch_z(ctx, planes)), 256, lds_bytes,
                                ctx->stream>>>(input_a, packed_a, input_b, packed_b, static_cast<int>(in_width),
                                               static_cast<int>(pitch), lv, flow2d::batch_arg(ctx, planes));

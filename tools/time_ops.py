@@ -46,6 +46,21 @@ def main():
         ("resample x and y from 1/2 (two planes, one launch)", lambda: ctx.resample_xy(a, out, n // 2, n // 2, n, n, b, tmp), 2.5),
         ("median 5 of a + b (two planes)", lambda: ctx.add_median(a, b, n, n, 5, out, c, d, tmp), 6),
     ]
+    # the x pass of every level of a 0.5 pyramid for both frames in one trip (flow2d_resample_x_levels), then the y passes of
+    # the coarsest levels out of the packed plane (long chains of rows, a handful of outputs)
+    widths, w = [], n
+    while w // 2 >= 4:
+        w //= 2
+        widths.append(w)
+    columns, col = [], 0
+    for lw in widths:
+        columns.append(col)
+        col += (lw + 3) // 4 * 4
+    pa, pb = ctx.plane(n, n), ctx.plane(n, n)
+    rows.append(("resample x, %d levels (%d..%d), two frames" % (len(widths), widths[0], widths[-1]),
+                 lambda: ctx.resample_x_levels(a, pa, n, n, widths, columns, b, pb), 2 + 2.0 * sum(widths) / n))
+    for lw in widths[-3:]:
+        rows.append(("resample y to %d at width %d" % (lw, lw), lambda lw=lw: ctx.resample_y(pa, out, lw, lw, n), lw / n))
     for name, fn, planes in rows:
         us = timed(ctx, fn)
         print("%-42s %8.1f us  %6.2f TB/s algorithmic" % (name, us, planes * plane_mb / us))
