@@ -130,7 +130,8 @@ def hip_lib():
         L.flow2d_solve_level.argtypes = [vp] * 11 + [C.POINTER(SolveParams), C.POINTER(i)]
         L.flow2d_timing_enable.argtypes = [vp, i]
         L.flow2d_fused_fallbacks.argtypes = [vp, C.POINTER(C.c_ulonglong)]
-        L.flow2d_fused_plain_waves.argtypes = [vp, C.POINTER(C.c_ulonglong)]
+        if hasattr(L, "flow2d_fused_plain_waves"):  # (absent from libraries of earlier rounds loaded for an A/B)
+            L.flow2d_fused_plain_waves.argtypes = [vp, C.POINTER(C.c_ulonglong)]
         L.flow2d_timing_launch_filter.argtypes = [vp, sz, sz]
         L.flow2d_timing_count.argtypes = [vp, C.POINTER(sz)]
         L.flow2d_timing_get.argtypes = [vp, sz, C.POINTER(TimingRecord)]

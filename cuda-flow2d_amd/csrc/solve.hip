@@ -12,6 +12,9 @@
 // once: 40 B per pixel-sweep, 32 B per pixel for phi/ksi.  With the plain 2-D grid of rounds 1-2 the x
 // neighbours of a tile sat on other XCDs and the kernels moved 1.69x their algorithmic bytes.  Arithmetic keeps the reference's order of operations; the file is
 // built with -ffp-contract=off so no multiply-add is fused.
+#include <algorithm>
+#include <cstdlib>
+
 #include "common.hpp"
 #include "solver_math.hpp"
 
@@ -134,6 +137,127 @@ __global__ __launch_bounds__(256) void sweep_grey_kernel(const float* __restrict
     image_derivatives(f0, f1, n, hx, hy, fx, fy, ft);
     jacobi_update(u, v, du, dv, phi, ksi, n, x, y, w, h, hx, hy, alpha, fx * fx, fy * fy, fx * fy, fx * ft, fy * ft,
                   tdu, tdv);
+}
+
+// ---- solve_2d, streaming form (round 4) -----------------------------------------------------------------------------
+// The tile form above lives for one row segment: 35 loads, a wait, the update, two stores, and the wave is gone -- its
+// 672 MB per 4096^2 sweep take 165 us (4.1 TB/s) however little of them is re-read, the same time in which the rounds-1/2
+// grid moved 1.7x the bytes.  Here a wave owns a strip of 62 columns (one halo lane on either side) and walks down
+// `rows` image rows: every plane row is ONE load per lane (a 256-byte segment per wave), requested kSweepAhead rows
+// before it is needed; the y neighbours are the 3-row windows in the lane's registers, the x neighbours come from the
+// adjacent lanes by DPP.  The reflect rule needs no selects: the row above the image IS row 1 and the column left of it
+// IS column 1, so the halo rows / lanes simply load the mirrored address (mirror_index) and everything else follows.
+// Same expressions as jacobi_update (solve_2d.cu:311-374) in the same order: bit-identical.
+// Where it pays (same box, tile form / streaming form, us per sweep): 4096^2 190 / 166 (another box: 165 / 164), 8192^2 651 /
+// 661, but 2048^2 30 / 35 and 1920 x 1080 15.8 / 19.5 -- ten planes of a level up to about 6 Mpixel live in the 256 MB
+// Infinity Cache, where the short-lived waves of the tile form reach 5.4-5.6 TB/s; beyond it both forms are held at
+// 4.0-4.4 TB/s by HBM itself (ten separate plane streams; skewing the planes' base addresses against each other buys 3 %:
+// profiles/r04_experiments).  The streaming form takes the levels of 8 Mpixel and more.
+constexpr int kSweepValid = 62;
+constexpr int kSweepAhead = 3;
+constexpr size_t kSweepStreamMinPixels = size_t(8) << 20;
+
+__device__ __forceinline__ float sweep_from_left(float v)  // lane i <- lane i-1
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x138, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float sweep_from_right(float v)  // lane i <- lane i+1
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x130, 0xf, 0xf, true));
+}
+
+struct SweepRow {  // one image row of the planes a sweep reads, as loaded
+    float f0, f1, u, v, du, dv, phi, ksi;
+};
+
+struct SweepPlanes {
+    const float* f0;
+    const float* f1;
+    const float* u;
+    const float* v;
+    const float* du;
+    const float* dv;
+    const float* phi;
+    const float* ksi;
+};
+
+__device__ __forceinline__ SweepRow sweep_load(const SweepPlanes& p, int row, int h, int pitch, int xm)
+{
+    const size_t at = static_cast<size_t>(min(max(mirror_index(row, h), 0), h - 1)) * pitch + xm;
+    return SweepRow{p.f0[at], p.f1[at], p.u[at], p.v[at], p.du[at], p.dv[at], p.phi[at], p.ksi[at]};
+}
+
+__global__ __launch_bounds__(256) void sweep_grey_stream_kernel(SweepPlanes p, XcdTiles tiles, int w, int h, int pitch, int rows,
+                                                                float hx, float hy, float alpha, float* __restrict__ tdu,
+                                                                float* __restrict__ tdv)
+{
+    unsigned tile_x, tile_y;
+    if (!xcd_tile(tiles, blockIdx.x, tile_x, tile_y)) return;
+    const int lane = threadIdx.x & 63;
+    const int strip = tile_x * 4 + (threadIdx.x >> 6);
+    if (strip * kSweepValid >= w) return;  // whole wave
+    const int x = strip * kSweepValid - 1 + lane;
+    const int xm = min(max(mirror_index(x, w), 0), w - 1);
+    const bool stores = lane >= 1 && lane <= kSweepValid && x < w;
+    const int y0 = tile_y * rows, y1 = min(y0 + rows, h);
+    using namespace flow2d_math;
+    const float hx_2 = alpha / (hx * hx);
+    const float hy_2 = alpha / (hy * hy);
+    const float xp = static_cast<float>(x < w - 1) * hx_2;
+    const float xm_w = static_cast<float>(x > 0) * hx_2;
+
+    // window slot = (row + 1) mod 3; rows y0 - 1 and y0 first, then the rows in flight
+    SweepRow win[3];
+    SweepRow ahead[kSweepAhead];
+    win[0] = sweep_load(p, y0 - 1, h, pitch, xm);
+    win[1] = sweep_load(p, y0, h, pitch, xm);
+#pragma unroll
+    for (int i = 0; i < kSweepAhead; ++i) ahead[i] = sweep_load(p, y0 + 1 + i, h, pitch, xm);
+
+    auto step = [&](int y, const SweepRow& up, const SweepRow& c, const SweepRow& down) {
+        // frame derivatives, solve_2d.cu:311-321
+        const float fx = diff4(sweep_from_right(c.f0), sweep_from_left(c.f0), sweep_from_right(c.f1), sweep_from_left(c.f1), 4.f * hx);
+        const float fy = diff4(down.f0, up.f0, down.f1, up.f1, 4.f * hy);
+        const float ft = c.f1 - c.f0;
+        const float J11 = fx * fx, J22 = fy * fy, J12 = fx * fy, J13 = fx * ft, J23 = fy * ft;
+        // jacobi_update, value form
+        const float yp = static_cast<float>(y < h - 1) * hy_2;
+        const float ym = static_cast<float>(y > 0) * hy_2;
+        const float pc = c.phi;
+        const float wxp = face_phi(sweep_from_right(pc), pc) * xp;
+        const float wxm = face_phi(sweep_from_left(pc), pc) * xm_w;
+        const float wyp = face_phi(down.phi, pc) * yp;
+        const float wym = face_phi(up.phi, pc) * ym;
+        const float sumH = sum_weights(wxp, wxm, wyp, wym);
+        const float su = c.u + c.du, sv = c.v + c.dv;  // the neighbours' full flow, formed once per pixel
+        const float sumU = sum_flux(wxp, wxm, wyp, wym, sweep_from_right(su), sweep_from_left(su), down.u + down.du,
+                                    up.u + up.du, c.u);
+        const float sumV = sum_flux(wxp, wxm, wyp, wym, sweep_from_right(sv), sweep_from_left(sv), down.v + down.dv,
+                                    up.v + up.dv, c.v);
+        float r_du, r_dv;
+        const float k = c.ksi;
+        point_update(k, update_denominator(k, J11, sumH), update_denominator(k, J22, sumH), J12, J13, J23, sumU, sumV, c.dv,
+                     r_du, r_dv);
+        if (stores) {
+            const size_t at = static_cast<size_t>(y) * pitch + x;
+            tdu[at] = r_du;
+            tdv[at] = r_dv;
+        }
+    };
+
+    // three rows per trip, so that every window slot is a compile-time index
+    for (int y = y0; y < y1; y += 3) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            if (y + j >= y1) break;  // wave-uniform
+            // row y + j + 1 arrives: the oldest of the rows in flight; request row y + j + 1 + kSweepAhead
+            win[(j + 2) % 3] = ahead[0];
+#pragma unroll
+            for (int i = 0; i + 1 < kSweepAhead; ++i) ahead[i] = ahead[i + 1];
+            ahead[kSweepAhead - 1] = sweep_load(p, y + j + 1 + kSweepAhead, h, pitch, xm);
+            step(y + j, win[j % 3], win[(j + 1) % 3], win[(j + 2) % 3]);
+        }
+    }
 }
 
 // ---- solve_2d_grad: src/kernels/solve_2d.cu:683-952 ----------------------------------------------
@@ -445,6 +569,19 @@ int launch_sweep(flow2d_context* ctx, int constancy, const float* f0, const floa
         const dim3 grid(xcd_grid(tiles));
         sweep_grad_untiled_kernel<<<grid, dim3(kBlockX, kBlockY), 0, ctx->stream>>>(
             f0, f1, u, v, du, dv, phi, ksi, tiles, (int)w, (int)h, (int)(pitch_bytes / 4), hx, hy, alpha, tdu, tdv);
+    } else if (w >= 2 * kSweepValid && h >= 8 && w * h >= kSweepStreamMinPixels) {
+        // streaming form: strips of 62 columns, four to a workgroup; strip heights so that the launch is some eight
+        // waves per SIMD over the chip (more, shorter strips re-read more halo rows: 2 per strip)
+        const unsigned strips_x = div_up(w, kSweepValid), tiles_x = div_up(strips_x, 4);
+        const unsigned target_waves = 8u * 4u * static_cast<unsigned>(ctx->num_cus > 0 ? ctx->num_cus : 256);
+        unsigned rows = static_cast<unsigned>(std::max<size_t>(16, std::min<size_t>(256, (h * strips_x + target_waves - 1) / target_waves)));
+#ifdef FLOW2D_DEV_BUILD
+        if (const char* e = std::getenv("FLOW2D_SWEEP_ROWS")) rows = static_cast<unsigned>(std::atoi(e));
+#endif
+        const XcdTiles tiles = xcd_tiles(tiles_x, div_up(h, rows));
+        sweep_grey_stream_kernel<<<dim3(xcd_grid(tiles)), 256, 0, ctx->stream>>>(
+            SweepPlanes{f0, f1, u, v, du, dv, phi, ksi}, tiles, (int)w, (int)h, (int)(pitch_bytes / 4), (int)rows, hx, hy, alpha,
+            tdu, tdv);
     } else {
         const XcdTiles tiles = xcd_tiles(div_up(w, kBlockX), div_up(h, kBlockY));
         const dim3 grid(xcd_grid(tiles));

@@ -6,11 +6,11 @@
 # Steps are joined so that a failed or timed-out GPU step starts no further GPU step.
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$R/gpurun_out
-ROUND=${ROUND:-r03}
+ROUND=${ROUND:-r04}
 mkdir -p "$OUT"
 cd "$R" || exit 1
 WHAT=${@:-tests bench trace}
-WLS="cfg3_4096_gradient cfg3_4096_grey cfg2_1024_grey cfg4_1080p_batch cfg5_8192_grey"
+WLS=${WLS:-"cfg3_4096_gradient cfg3_4096_grey cfg2_1024_grey cfg4_1080p_batch cfg5_8192_grey cfg1_rub"}
 set -e
 for what in $WHAT; do
     case $what in
@@ -24,7 +24,7 @@ for what in $WHAT; do
                 || { tail -5 "$OUT/${ROUND}_${wl}_bench.err"; exit 1; }
             python3 -c "
 import json; d=json.load(open('$OUT/${ROUND}_${wl}_bench_line.json'))
-print('$wl', 'value', d['value'], 'pairs/s', d['pairs_per_s'], 'ms/step', d['ms_per_step'], 'launch_ms', d['roofline']['avg_launch_ms'], 'frac', d['roofline']['frac'], 'check', d['output_check']['ok'])"
+print('$wl', 'value', d['value'], 'pairs/s', d['pairs_per_s'], 'single', d['pairs_per_s_single'], 'incl_h2d', d['pairs_per_s_incl_h2d'], 'ms/step', d['ms_per_step'], 'launch_ms', d['roofline']['avg_launch_ms'], 'frac', d['roofline']['frac'], 'per_sweep', (d['roofline']['per_sweep'] or {}).get('avg_launch_ms'), (d['roofline']['per_sweep'] or {}).get('frac'), 'check', d['output_check']['ok'])"
         done ;;
     trace)
         export TMPDIR=/tmp
