@@ -570,11 +570,11 @@ int launch_sweep(flow2d_context* ctx, int constancy, const float* f0, const floa
         sweep_grad_untiled_kernel<<<grid, dim3(kBlockX, kBlockY), 0, ctx->stream>>>(
             f0, f1, u, v, du, dv, phi, ksi, tiles, (int)w, (int)h, (int)(pitch_bytes / 4), hx, hy, alpha, tdu, tdv);
     } else if (w >= 2 * kSweepValid && h >= 8 && w * h >= kSweepStreamMinPixels) {
-        // streaming form: strips of 62 columns, four to a workgroup; strip heights so that the launch is some eight
-        // waves per SIMD over the chip (more, shorter strips re-read more halo rows: 2 per strip)
+        // streaming form: strips of 62 columns, four to a workgroup, 16 rows to a strip: the two halo rows of a strip are
+        // its y neighbours' rows, which the XCD-aware tile order keeps in the same L2.  (us per 4096^2 / 8192^2 sweep by strip
+        // height, one box: 8 rows 169 / 570, 16 160 / 564, 24 160 / 615, 33 167 / 610, 64 168 / 617, 128 171 / 599, 256 190 / 630.)
         const unsigned strips_x = div_up(w, kSweepValid), tiles_x = div_up(strips_x, 4);
-        const unsigned target_waves = 8u * 4u * static_cast<unsigned>(ctx->num_cus > 0 ? ctx->num_cus : 256);
-        unsigned rows = static_cast<unsigned>(std::max<size_t>(16, std::min<size_t>(256, (h * strips_x + target_waves - 1) / target_waves)));
+        unsigned rows = 16;
 #ifdef FLOW2D_DEV_BUILD
         if (const char* e = std::getenv("FLOW2D_SWEEP_ROWS")) rows = static_cast<unsigned>(std::atoi(e));
 #endif
