@@ -372,6 +372,190 @@ __global__ __launch_bounds__(256) void median5_stream_kernel(const float* __rest
         median5_strip<false, ADD>(in, out, w, h, pitch, x, y0, y1, lane_stores);
 }
 
+// ---- r = 7, streaming (round 4) -----------------------------------------------------------------------------------
+// The same scheme one size up: a lane loads ONE value per image row, takes three neighbours per side from the adjacent
+// lanes (DPP), sorts the 7-tuple (16 comparators) and keeps the sorted tuples of eight consecutive rows in registers.  Two
+// vertically adjacent medians share six of their seven rows: median7_pair_network.inc (generated and verified exhaustively
+// over the 8^8 sorted 0-1 inputs by tools/gen_median7_network.py) merges the six shared tuples once and finishes both.
+// The generic kernel gathers 49 values per pixel and sorts them with a pruned Batcher network: 412 us per 4096^2 plane.
+#include "median7_pair_network.inc"
+
+template <size_t... I>
+__device__ __forceinline__ void run_pair7_program(float (&v)[kMedian7PairWires], std::index_sequence<I...>)
+{
+    (
+        [&] {
+            constexpr MedianPairOp op = kMedian7PairProgram[I];
+            if constexpr (op.copy) {
+                v[op.b] = v[op.a];
+            } else {
+                const float lo = fminf(v[op.a], v[op.b]);
+                const float hi = fmaxf(v[op.a], v[op.b]);
+                v[op.a] = lo;
+                v[op.b] = hi;
+            }
+        }(),
+        ...);
+}
+
+__device__ __forceinline__ void sort7(float (&t)[7])
+{
+    auto cx = [&](int a, int b) {
+        const float lo = fminf(t[a], t[b]), hi = fmaxf(t[a], t[b]);
+        t[a] = lo;
+        t[b] = hi;
+    };
+    // 16 comparators, 6 layers (checked over the 128 0-1 inputs)
+    cx(0, 6); cx(2, 3); cx(4, 5); cx(0, 2); cx(1, 4); cx(3, 6); cx(0, 1); cx(2, 5); cx(3, 4); cx(1, 2); cx(4, 6); cx(2, 3); cx(4, 5);
+    cx(1, 2); cx(3, 4); cx(5, 6);
+}
+
+constexpr int kStream7Valid = 58;  // lanes 3..60 of a wave have three neighbours on either side
+
+template <bool EDGE, bool ADD>
+struct Row7Load {
+    float v[EDGE ? 7 : 1];
+    float a[ADD ? (EDGE ? 7 : 1) : 1];
+};
+
+template <bool EDGE, bool ADD>
+__device__ __forceinline__ Row7Load<EDGE, ADD> load_row7(const Source<ADD> in, int row, int h, int pitch, int xc,
+                                                         const int (&xm)[7])
+{
+    const size_t line = static_cast<size_t>(min(max(mirror_index(row, h), 0), h - 1)) * pitch;
+    Row7Load<EDGE, ADD> r;
+    r.a[0] = 0.f;
+#pragma unroll
+    for (int i = 0; i < (EDGE ? 7 : 1); ++i) {
+        const size_t at = line + (EDGE ? xm[i] : xc);
+        r.v[i] = in.in[at];
+        if (ADD) r.a[i] = in.add[at];
+    }
+    return r;
+}
+
+template <bool EDGE, bool ADD>
+__device__ __forceinline__ void sorted_tuple7(const Row7Load<EDGE, ADD>& r, float (&t)[7], bool& special)
+{
+    if (EDGE) {
+#pragma unroll
+        for (int i = 0; i < 7; ++i) {
+            t[i] = ADD ? r.v[i] + r.a[i] : r.v[i];
+            special |= is_special(t[i]);
+        }
+    } else {
+        const float c = ADD ? r.v[0] + r.a[0] : r.v[0];
+        special |= is_special(c);
+        const float l1 = lane_left(c), r1 = lane_right(c);
+        const float l2 = lane_left(l1), r2 = lane_right(r1);
+        t[0] = lane_left(l2);
+        t[1] = l2;
+        t[2] = l1;
+        t[3] = c;
+        t[4] = r1;
+        t[5] = r2;
+        t[6] = lane_right(r2);
+    }
+    sort7(t);
+}
+
+// Step I of four: the ring of eight row slots advances by two rows per step.
+template <bool EDGE, int I, bool ADD>
+__device__ __forceinline__ void median7_step(float (&ring)[8][7], Row7Load<EDGE, ADD> (&next)[4], const Source<ADD> in,
+                                             float* __restrict__ out, int ya, int y1, int h, int pitch, int x, int xc,
+                                             const int (&xm)[7], bool lane_stores, bool& special)
+{
+    // rows ya+3 and ya+4 were requested two steps ago; request rows ya+7, ya+8
+    sorted_tuple7<EDGE, ADD>(next[0], ring[(2 * I + 6) % 8], special);
+    sorted_tuple7<EDGE, ADD>(next[1], ring[(2 * I + 7) % 8], special);
+    next[0] = next[2];
+    next[1] = next[3];
+    next[2] = load_row7<EDGE, ADD>(in, ya + 7, h, pitch, xc, xm);
+    next[3] = load_row7<EDGE, ADD>(in, ya + 8, h, pitch, xc, xm);
+    float v[kMedian7PairWires];
+#pragma unroll
+    for (int g = 0; g < 8; ++g)
+#pragma unroll
+        for (int e = 0; e < 7; ++e) v[7 * g + e] = ring[(2 * I + g) % 8][e];
+#pragma unroll
+    for (int i = 56; i < kMedian7PairWires; ++i) v[i] = 0.f;
+    run_pair7_program(v, std::make_index_sequence<kMedian7PairOps>{});
+    if (lane_stores) {
+        out[static_cast<size_t>(ya) * pitch + x] = v[kMedian7PairOutA];
+        if (ya + 1 < y1) out[static_cast<size_t>(ya + 1) * pitch + x] = v[kMedian7PairOutB];
+    }
+}
+
+template <bool EDGE, bool ADD>
+__device__ __forceinline__ void median7_strip(const Source<ADD> in, float* __restrict__ out, int w, int h, int pitch,
+                                              int x, int y0, int y1, bool lane_stores)
+{
+    const int xc = min(max(x, 0), w - 1);
+    int xm[7];
+#pragma unroll
+    for (int i = 0; i < 7; ++i) xm[i] = min(max(mirror_index(x + i - 3, w), 0), w - 1);
+    float ring[8][7];
+    bool special = false;
+    // rows y0-3 .. y0+2 fill slots 0..5; rows y0+3, y0+4 are the first pair in flight
+    {
+        Row7Load<EDGE, ADD> first[6];
+#pragma unroll
+        for (int g = 0; g < 6; ++g) first[g] = load_row7<EDGE, ADD>(in, y0 - 3 + g, h, pitch, xc, xm);
+#pragma unroll
+        for (int g = 0; g < 6; ++g) sorted_tuple7<EDGE, ADD>(first[g], ring[g], special);
+#pragma unroll
+        for (int e = 0; e < 7; ++e) ring[6][e] = ring[7][e] = 0.f;
+    }
+    Row7Load<EDGE, ADD> next[4] = {load_row7<EDGE, ADD>(in, y0 + 3, h, pitch, xc, xm), load_row7<EDGE, ADD>(in, y0 + 4, h, pitch, xc, xm),
+                                   load_row7<EDGE, ADD>(in, y0 + 5, h, pitch, xc, xm), load_row7<EDGE, ADD>(in, y0 + 6, h, pitch, xc, xm)};
+    for (int ya = y0; ya < y1; ya += 8) {
+        median7_step<EDGE, 0, ADD>(ring, next, in, out, ya, y1, h, pitch, x, xc, xm, lane_stores, special);
+        if (ya + 2 >= y1) break;
+        median7_step<EDGE, 1, ADD>(ring, next, in, out, ya + 2, y1, h, pitch, x, xc, xm, lane_stores, special);
+        if (ya + 4 >= y1) break;
+        median7_step<EDGE, 2, ADD>(ring, next, in, out, ya + 4, y1, h, pitch, x, xc, xm, lane_stores, special);
+        if (ya + 6 >= y1) break;
+        median7_step<EDGE, 3, ADD>(ring, next, in, out, ya + 6, y1, h, pitch, x, xc, xm, lane_stores, special);
+    }
+    // a NaN or a -0 somewhere in what the wave loaded: the windows that hold one are redone the way the reference's sort would
+    if (__builtin_amdgcn_ballot_w64(special) != 0 && lane_stores) {
+        for (int y = y0; y < y1; ++y) {
+            bool hit = false;
+            for (int j = -3; j <= 3; ++j) {
+                const size_t line = static_cast<size_t>(mirror_index(y + j, h)) * pitch;
+                for (int i = -3; i <= 3; ++i) hit |= is_special(in[line + mirror_index(x + i, w)]);
+            }
+            if (hit) out[static_cast<size_t>(y) * pitch + x] = exact_median<7, ADD>(in, x, y, w, h, pitch);
+        }
+    }
+}
+
+template <bool ADD>
+__global__ __launch_bounds__(256) void median7_stream_kernel(const float* __restrict__ in_a,
+                                                             const float* __restrict__ in_b,
+                                                             const float* __restrict__ add_a,
+                                                             const float* __restrict__ add_b, int w, int h, int pitch,
+                                                             int rows_per_strip, float* __restrict__ out_a,
+                                                             float* __restrict__ out_b, BatchArg batch)
+{
+    const Source<ADD> in{(batch_plane(batch) ? in_b : in_a) + batch_offset(batch),
+                         ADD ? (batch_plane(batch) ? add_b : add_a) + batch_offset(batch) : nullptr};
+    float* __restrict__ out = (batch_plane(batch) ? out_b : out_a) + batch_offset(batch);
+    const int lane = threadIdx.x & 63;
+    const int strip = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int x_first = strip * kStream7Valid - 3;
+    if (strip * kStream7Valid >= w) return;
+    const int x = x_first + lane;
+    const int y0 = blockIdx.y * rows_per_strip;
+    const int y1 = min(y0 + rows_per_strip, h);
+    const bool lane_stores = lane >= 3 && lane < 61 && x < w;
+    const bool edge = x_first < 0 || x_first + 63 > w - 1;
+    if (__builtin_amdgcn_readfirstlane(edge))
+        median7_strip<true, ADD>(in, out, w, h, pitch, x, y0, y1, lane_stores);
+    else
+        median7_strip<false, ADD>(in, out, w, h, pitch, x, y0, y1, lane_stores);
+}
+
 // rows per strip: even, tall enough that the four start-up rows are noise, short enough to fill the chip
 int median5_rows_per_strip(const flow2d_context* ctx, size_t w, size_t h)
 {
@@ -415,6 +599,14 @@ static int launch_median(flow2d_context* ctx, const float* input, const float* i
         const int rows = median5_rows_per_strip(ctx, width, height);
         const dim3 sgrid(flow2d::div_up(flow2d::div_up(width, kStreamValid), 4), flow2d::div_up(height, rows), z);
         median5_stream_kernel<ADD><<<sgrid, 256, 0, ctx->stream>>>(input, input_b, addend, addend_b, w, h, pitch, rows, output,
+                                                                   output_b, batch);
+        FLOW2D_CHECK_LAUNCH();
+        return FLOW2D_OK;
+    }
+    if (window == 7 && width >= 12 && height >= 12) {  // mirrored rows/columns up to 5 beyond the border stay inside
+        const int rows = median5_rows_per_strip(ctx, width, height);
+        const dim3 sgrid(flow2d::div_up(flow2d::div_up(width, kStream7Valid), 4), flow2d::div_up(height, rows), z);
+        median7_stream_kernel<ADD><<<sgrid, 256, 0, ctx->stream>>>(input, input_b, addend, addend_b, w, h, pitch, rows, output,
                                                                    output_b, batch);
         FLOW2D_CHECK_LAUNCH();
         return FLOW2D_OK;

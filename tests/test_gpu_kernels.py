@@ -186,6 +186,36 @@ def test_median(ctx, oracle, w, h, cw, ch, window):
     assert np.array_equal(dst.download(w, h), oracle.median(u, w, h, window))
 
 
+@pytest.mark.parametrize("w,h,cw,ch", [(700, 133, 704, 140), (1000, 300, 1024, 300), (61, 200, 64, 200), (12, 12, 16, 16),
+                                        (59, 13, 64, 16), (117, 67, 128, 70)])
+def test_median7_streaming_strips(ctx, flow2d, oracle, w, h, cw, ch):
+    """Window 7 runs a streaming kernel too (round 4): sorted 7-tuples by lane shifts, eight rows in registers, the generated
+    pair network for two vertically adjacent medians.  Interior strips (lane neighbours), border strips (mirrored loads),
+    odd heights, strip ends inside a pair of rows, many ties, NaNs and -0 (windows redone in the reference's sort order);
+    and the add-in-median form (the pyramid's u += du folded into the filter)."""
+    _, _, u, v, du, dv = level_fields(oracle, w, h, 17)
+    u[::7, ::3] = 0.0
+    u[1::5, :] = np.round(u[1::5, :] * 4) / 4  # many ties
+    src, dst = up(ctx, u, cw, ch, -5.0), ctx.plane(cw, ch).fill_bytes(0x7f)
+    ctx.median(src, w, h, 7, dst)
+    assert np.array_equal(dst.download(w, h), oracle.median(u, w, h, 7))
+    full = dst.download()
+    assert np.all(full[h:, :].view(np.uint32) == 0x7f7f7f7f) and np.all(full[:h, w:].view(np.uint32) == 0x7f7f7f7f)
+    u2 = u.copy()
+    u2[h // 2, w // 3] = np.nan
+    u2[h // 3, :: 11] = -0.0
+    u2[0, 0] = np.nan
+    src2 = up(ctx, u2, cw, ch, 1.0)
+    ctx.median(src2, w, h, 7, dst)
+    assert np.array_equal(dst.download(w, h).view(np.uint32), oracle.median(u2, w, h, 7).view(np.uint32))
+    # u + du and v + dv through the filter in one launch
+    a, b, da, db = (up(ctx, q, cw, ch, 2.0) for q in (u, v, du, dv))
+    oa, ob = ctx.plane(cw, ch), ctx.plane(cw, ch)
+    ctx.add_median(a, da, w, h, 7, oa, b, db, ob)
+    assert np.array_equal(oa.download(w, h), oracle.median(u + du, w, h, 7))
+    assert np.array_equal(ob.download(w, h), oracle.median(v + dv, w, h, 7))
+
+
 @pytest.mark.parametrize("w,h,cw,ch", [(700, 133, 704, 140), (1000, 300, 1024, 300), (61, 200, 64, 200), (8, 8, 8, 8)])
 def test_median5_streaming_strips(ctx, oracle, w, h, cw, ch):
     """Window 5 runs the streaming kernel: interior strips (lane neighbours), border strips (mirrored loads),
