@@ -181,24 +181,36 @@ struct SweepPlanes {
     const float* ksi;
 };
 
+// FRAMES_AHEAD: the frames of row `row + 1` with the other planes of row `row` (the gradient term)
+template <bool FRAMES_AHEAD>
 __device__ __forceinline__ SweepRow sweep_load(const SweepPlanes& p, int row, int h, int pitch, int xm)
 {
     const size_t at = static_cast<size_t>(min(max(mirror_index(row, h), 0), h - 1)) * pitch + xm;
-    return SweepRow{p.f0[at], p.f1[at], p.u[at], p.v[at], p.du[at], p.dv[at], p.phi[at], p.ksi[at]};
+    const size_t af = FRAMES_AHEAD ? static_cast<size_t>(min(max(mirror_index(row + 1, h), 0), h - 1)) * pitch + xm : at;
+    return SweepRow{p.f0[af], p.f1[af], p.u[at], p.v[at], p.du[at], p.dv[at], p.phi[at], p.ksi[at]};
 }
 
-__global__ __launch_bounds__(256) void sweep_grey_stream_kernel(SweepPlanes p, XcdTiles tiles, int w, int h, int pitch, int rows,
-                                                                float hx, float hy, float alpha, float* __restrict__ tdu,
-                                                                float* __restrict__ tdv)
+// GRAD: solve_2d_grad (solve_2d.cu:683-952).  Its tensor needs fx, fy, ft of the rows y-1, y, y+1 (second derivatives inside
+// the reference's 16x8 blocks, the block's own edge value replicated: :816-841), i.e. the frames one row further ahead than
+// the other planes: a window slot of row q then carries the frames' row q + 1, the derivatives of row y + 1 are formed when
+// slot y + 1 arrives and kept in a 3-row window of their own.  Strips start on multiples of 16 rows, so the derivative row
+// above a strip's first row is never read (y % 8 == 0 takes the pixel's own value).
+template <bool GRAD>
+__global__ __launch_bounds__(256) void sweep_stream_kernel(SweepPlanes p, XcdTiles tiles, int w, int h, int pitch, int rows,
+                                                           float hx, float hy, float alpha, float* __restrict__ tdu,
+                                                           float* __restrict__ tdv)
 {
     unsigned tile_x, tile_y;
     if (!xcd_tile(tiles, blockIdx.x, tile_x, tile_y)) return;
+    // halo lanes per side: one for the x neighbours of the planes; the gradient term also differentiates fx and ft in x, whose
+    // own x neighbours must be true values, so it keeps two
+    constexpr int kHalo = GRAD ? 2 : 1, kValid = 64 - 2 * kHalo;
     const int lane = threadIdx.x & 63;
     const int strip = tile_x * 4 + (threadIdx.x >> 6);
-    if (strip * kSweepValid >= w) return;  // whole wave
-    const int x = strip * kSweepValid - 1 + lane;
+    if (strip * kValid >= w) return;  // whole wave
+    const int x = strip * kValid - kHalo + lane;
     const int xm = min(max(mirror_index(x, w), 0), w - 1);
-    const bool stores = lane >= 1 && lane <= kSweepValid && x < w;
+    const bool stores = lane >= kHalo && lane < 64 - kHalo && x < w;
     const int y0 = tile_y * rows, y1 = min(y0 + rows, h);
     using namespace flow2d_math;
     const float hx_2 = alpha / (hx * hx);
@@ -209,17 +221,55 @@ __global__ __launch_bounds__(256) void sweep_grey_stream_kernel(SweepPlanes p, X
     // window slot = (row + 1) mod 3; rows y0 - 1 and y0 first, then the rows in flight
     SweepRow win[3];
     SweepRow ahead[kSweepAhead];
-    win[0] = sweep_load(p, y0 - 1, h, pitch, xm);
-    win[1] = sweep_load(p, y0, h, pitch, xm);
+    win[0] = sweep_load<GRAD>(p, y0 - 1, h, pitch, xm);
+    win[1] = sweep_load<GRAD>(p, y0, h, pitch, xm);
 #pragma unroll
-    for (int i = 0; i < kSweepAhead; ++i) ahead[i] = sweep_load(p, y0 + 1 + i, h, pitch, xm);
+    for (int i = 0; i < kSweepAhead; ++i) ahead[i] = sweep_load<GRAD>(p, y0 + 1 + i, h, pitch, xm);
 
-    auto step = [&](int y, const SweepRow& up, const SweepRow& c, const SweepRow& down) {
-        // frame derivatives, solve_2d.cu:311-321
-        const float fx = diff4(sweep_from_right(c.f0), sweep_from_left(c.f0), sweep_from_right(c.f1), sweep_from_left(c.f1), 4.f * hx);
-        const float fy = diff4(down.f0, up.f0, down.f1, up.f1, 4.f * hy);
-        const float ft = c.f1 - c.f0;
-        const float J11 = fx * fx, J22 = fy * fy, J12 = fx * fy, J13 = fx * ft, J23 = fy * ft;
+    // frame derivatives of one row from the frames' rows above / at / below it, solve_2d.cu:311-321 (:798-808)
+    auto derivatives = [&](float f0u, float f1u, float f0c, float f1c, float f0d, float f1d, float& fx, float& fy, float& ft) {
+        fx = diff4(sweep_from_right(f0c), sweep_from_left(f0c), sweep_from_right(f1c), sweep_from_left(f1c), 4.f * hx);
+        fy = diff4(f0d, f0u, f1d, f1u, 4.f * hy);
+        ft = f1c - f0c;
+    };
+    // GRAD: (fx, fy, ft) of the rows y-1, y, y+1; slot of row q = (q + 1) mod 3 like the plane windows
+    float dfx[3] = {0.f, 0.f, 0.f}, dfy[3] = {0.f, 0.f, 0.f}, dft[3] = {0.f, 0.f, 0.f};
+    const float hx_1 = 1.0 / (2.0 * hx);  // evaluated in double, rounded to float (solve_2d.cu:868-869)
+    const float hy_1 = 1.0 / (2.0 * hy);
+    const bool x_lo = (x & 15) == 0, x_hi = (x & 15) == 15 || x == w - 1;
+    if (GRAD) {  // row y0: the frames' rows y0 - 1 (loaded here), y0 (in slot y0 - 1) and y0 + 1 (in slot y0)
+        const size_t at = static_cast<size_t>(min(max(mirror_index(y0 - 1, h), 0), h - 1)) * pitch + xm;
+        derivatives(p.f0[at], p.f1[at], win[0].f0, win[0].f1, win[1].f0, win[1].f1, dfx[1], dfy[1], dft[1]);
+        dfx[0] = dfx[1], dfy[0] = dfy[1], dft[0] = dft[1];  // (row y0 - 1: never read, y0 % 8 == 0)
+    }
+
+    auto step = [&](int y, int sy, const SweepRow& up, const SweepRow& c, const SweepRow& down) {
+        float J11, J22, J12, J13, J23;
+        if (!GRAD) {
+            float fx, fy, ft;
+            derivatives(up.f0, up.f1, c.f0, c.f1, down.f0, down.f1, fx, fy, ft);
+            J11 = fx * fx, J22 = fy * fy, J12 = fx * fy, J13 = fx * ft, J23 = fy * ft;
+        } else {
+            // sy = slot of row y; derivatives of row y + 1 from the frames' rows y (slot y - 1), y + 1 (slot y), y + 2 (slot y + 1)
+            const int su = (sy + 2) % 3, sd = (sy + 1) % 3;
+            derivatives(up.f0, up.f1, c.f0, c.f1, down.f0, down.f1, dfx[sd], dfy[sd], dft[sd]);
+            const float fxc = dfx[sy], fyc = dfy[sy], ftc = dft[sy];
+            // cross-lane reads with every lane active, the block rule as selects afterwards (solve_2d.cu:816-841)
+            const float fx_l0 = sweep_from_left(fxc), fx_r0 = sweep_from_right(fxc);
+            const float ft_l0 = sweep_from_left(ftc), ft_r0 = sweep_from_right(ftc);
+            const bool y_lo = (y & 7) == 0, y_hi = (y & 7) == 7 || y == h - 1;
+            const float fx_l = x_lo ? fxc : fx_l0, fx_r = x_hi ? fxc : fx_r0;
+            const float ft_l = x_lo ? ftc : ft_l0, ft_r = x_hi ? ftc : ft_r0;
+            const float fx_u = y_lo ? fxc : dfx[su], fx_d = y_hi ? fxc : dfx[sd];
+            const float fy_u = y_lo ? fyc : dfy[su], fy_d = y_hi ? fyc : dfy[sd];
+            const float ft_u = y_lo ? ftc : dft[su], ft_d = y_hi ? ftc : dft[sd];
+            const float fxx = (fx_r - fx_l) * hx_1;
+            const float fxy = (fx_d - fx_u) * hy_1;
+            const float fyy = (fy_d - fy_u) * hy_1;
+            const float fxt = (ft_r - ft_l) * hx_1;
+            const float fyt = (ft_d - ft_u) * hy_1;
+            gradient_tensor(fxx, fxy, fyy, fxt, fyt, J11, J22, J12, J13, J23);
+        }
         // jacobi_update, value form
         const float yp = static_cast<float>(y < h - 1) * hy_2;
         const float ym = static_cast<float>(y > 0) * hy_2;
@@ -254,8 +304,8 @@ __global__ __launch_bounds__(256) void sweep_grey_stream_kernel(SweepPlanes p, X
             win[(j + 2) % 3] = ahead[0];
 #pragma unroll
             for (int i = 0; i + 1 < kSweepAhead; ++i) ahead[i] = ahead[i + 1];
-            ahead[kSweepAhead - 1] = sweep_load(p, y + j + 1 + kSweepAhead, h, pitch, xm);
-            step(y + j, win[j % 3], win[(j + 1) % 3], win[(j + 2) % 3]);
+            ahead[kSweepAhead - 1] = sweep_load<GRAD>(p, y + j + 1 + kSweepAhead, h, pitch, xm);
+            step(y + j, (j + 1) % 3, win[j % 3], win[(j + 1) % 3], win[(j + 2) % 3]);
         }
     }
 }
@@ -554,7 +604,27 @@ int launch_sweep(flow2d_context* ctx, int constancy, const float* f0, const floa
         ctx->batch_count = n;
         return st;
     }
-    if (constancy == FLOW2D_CONSTANCY_GRADIENT) {
+    const bool streaming = w >= 2 * kSweepValid && h >= 8 && w * h >= kSweepStreamMinPixels;
+    if (streaming && (constancy == FLOW2D_CONSTANCY_GRADIENT || constancy == FLOW2D_CONSTANCY_GREY)) {
+        // streaming form: strips of 62 columns, four to a workgroup, 16 rows to a strip: the two halo rows of a strip are
+        // its y neighbours' rows, which the XCD-aware tile order keeps in the same L2.  (us per 4096^2 / 8192^2 Grey sweep by
+        // strip height, one box: 8 rows 169 / 570, 16 160 / 564, 24 160 / 615, 33 167 / 610, 64 168 / 617, 128 171 / 599, 256 190 / 630.)
+        const unsigned valid = constancy == FLOW2D_CONSTANCY_GRADIENT ? kSweepValid - 2 : kSweepValid;
+        const unsigned strips_x = div_up(w, valid), tiles_x = div_up(strips_x, 4);
+        unsigned rows = 16;
+#ifdef FLOW2D_DEV_BUILD
+        if (const char* e = std::getenv("FLOW2D_SWEEP_ROWS")) rows = static_cast<unsigned>(std::atoi(e)) / 16 * 16;
+        if (rows == 0) rows = 16;
+#endif
+        const XcdTiles tiles = xcd_tiles(tiles_x, div_up(h, rows));
+        const SweepPlanes planes{f0, f1, u, v, du, dv, phi, ksi};
+        if (constancy == FLOW2D_CONSTANCY_GRADIENT)
+            sweep_stream_kernel<true><<<dim3(xcd_grid(tiles)), 256, 0, ctx->stream>>>(planes, tiles, (int)w, (int)h, (int)(pitch_bytes / 4),
+                                                                                   (int)rows, hx, hy, alpha, tdu, tdv);
+        else
+            sweep_stream_kernel<false><<<dim3(xcd_grid(tiles)), 256, 0, ctx->stream>>>(planes, tiles, (int)w, (int)h, (int)(pitch_bytes / 4),
+                                                                                    (int)rows, hx, hy, alpha, tdu, tdv);
+    } else if (constancy == FLOW2D_CONSTANCY_GRADIENT) {
         const XcdTiles tiles = xcd_tiles(div_up(w, kBlockX), div_up(h, kGradTileY));
         const dim3 grid(xcd_grid(tiles));
         sweep_grad_kernel<<<grid, dim3(kBlockX, kGradTileY), 0, ctx->stream>>>(
@@ -569,19 +639,6 @@ int launch_sweep(flow2d_context* ctx, int constancy, const float* f0, const floa
         const dim3 grid(xcd_grid(tiles));
         sweep_grad_untiled_kernel<<<grid, dim3(kBlockX, kBlockY), 0, ctx->stream>>>(
             f0, f1, u, v, du, dv, phi, ksi, tiles, (int)w, (int)h, (int)(pitch_bytes / 4), hx, hy, alpha, tdu, tdv);
-    } else if (w >= 2 * kSweepValid && h >= 8 && w * h >= kSweepStreamMinPixels) {
-        // streaming form: strips of 62 columns, four to a workgroup, 16 rows to a strip: the two halo rows of a strip are
-        // its y neighbours' rows, which the XCD-aware tile order keeps in the same L2.  (us per 4096^2 / 8192^2 sweep by strip
-        // height, one box: 8 rows 169 / 570, 16 160 / 564, 24 160 / 615, 33 167 / 610, 64 168 / 617, 128 171 / 599, 256 190 / 630.)
-        const unsigned strips_x = div_up(w, kSweepValid), tiles_x = div_up(strips_x, 4);
-        unsigned rows = 16;
-#ifdef FLOW2D_DEV_BUILD
-        if (const char* e = std::getenv("FLOW2D_SWEEP_ROWS")) rows = static_cast<unsigned>(std::atoi(e));
-#endif
-        const XcdTiles tiles = xcd_tiles(tiles_x, div_up(h, rows));
-        sweep_grey_stream_kernel<<<dim3(xcd_grid(tiles)), 256, 0, ctx->stream>>>(
-            SweepPlanes{f0, f1, u, v, du, dv, phi, ksi}, tiles, (int)w, (int)h, (int)(pitch_bytes / 4), (int)rows, hx, hy, alpha,
-            tdu, tdv);
     } else {
         const XcdTiles tiles = xcd_tiles(div_up(w, kBlockX), div_up(h, kBlockY));
         const dim3 grid(xcd_grid(tiles));

@@ -154,8 +154,8 @@ def test_phi_ksi_and_sweeps(ctx, flow2d, oracle, w, h, cw, ch, hx, hy):
 
 @pytest.mark.parametrize("w,h,cw,ch,hx,hy", [(4096, 2050, 4096, 2050, 1.0, 1.0), (2777, 3100, 2816, 3104, 1.25, 1.1),
                                               (16000, 530, 16000, 530, 7.3, 5.5), (1000, 300, 1024, 300, 1.0, 1.0)])
-def test_sweep_grey_streaming_strips(ctx, flow2d, oracle, w, h, cw, ch, hx, hy):
-    """solve_2d at level sizes that take the streaming form (8 Mpixel and more: strips of 62 columns walking down the level,
+def test_sweep_streaming_strips(ctx, flow2d, oracle, w, h, cw, ch, hx, hy):
+    """solve_2d and solve_2d_grad at level sizes that take the streaming form (8 Mpixel and more: strips of 62 columns walking down the level,
     windows in registers, lane shifts for the x neighbours, mirrored halo loads instead of border selects): partial last
     strips, strip heights that do not divide the level, levels inside larger containers, spacings that are no powers of
     two -- bit-identical to the oracle's sweep, two sweeps in a row (the second reads what the first wrote).  (The last
@@ -165,15 +165,18 @@ def test_sweep_grey_streaming_strips(ctx, flow2d, oracle, w, h, cw, ch, hx, hy):
     phi, ksi, tdu, tdv = (ctx.plane(cw, ch).fill_bytes(0x7f) for _ in range(4))
     ctx.compute_phi_ksi(*d, w, h, hx, hy, 0.001, 0.001, phi, ksi)
     ophi, oksi = oracle.compute_phi_ksi(f0, f1, u, v, du, dv, w, h, hx, hy, 0.001, 0.001)
-    ctx.solve_sweep(*d, phi, ksi, w, h, hx, hy, 35.0, tdu, tdv, flow2d.GREY)
-    odu, odv = oracle.solve_sweep(f0, f1, u, v, du, dv, ophi, oksi, w, h, hx, hy, 35.0, flow2d.GREY)
-    assert np.array_equal(tdu.download(w, h), odu) and np.array_equal(tdv.download(w, h), odv)
-    # nothing outside the level is written
-    full = tdu.download()
-    assert np.all(full[h:, :].view(np.uint32) == 0x7f7f7f7f) and np.all(full[:h, w:].view(np.uint32) == 0x7f7f7f7f)
-    ctx.solve_sweep(d[0], d[1], d[2], d[3], tdu, tdv, phi, ksi, w, h, hx, hy, 35.0, d[4], d[5], flow2d.GREY)
-    odu2, odv2 = oracle.solve_sweep(f0, f1, u, v, odu, odv, ophi, oksi, w, h, hx, hy, 35.0, flow2d.GREY)
-    assert np.array_equal(d[4].download(w, h), odu2) and np.array_equal(d[5].download(w, h), odv2)
+    for constancy in (flow2d.GREY, flow2d.GRADIENT):
+        d[4].upload(in_container(du, cw, ch, 3.0)), d[5].upload(in_container(dv, cw, ch, 3.0))
+        tdu.fill_bytes(0x7f), tdv.fill_bytes(0x7f)
+        ctx.solve_sweep(*d, phi, ksi, w, h, hx, hy, 35.0, tdu, tdv, constancy)
+        odu, odv = oracle.solve_sweep(f0, f1, u, v, du, dv, ophi, oksi, w, h, hx, hy, 35.0, constancy)
+        assert np.array_equal(tdu.download(w, h), odu) and np.array_equal(tdv.download(w, h), odv), constancy
+        # nothing outside the level is written
+        full = tdu.download()
+        assert np.all(full[h:, :].view(np.uint32) == 0x7f7f7f7f) and np.all(full[:h, w:].view(np.uint32) == 0x7f7f7f7f)
+        ctx.solve_sweep(d[0], d[1], d[2], d[3], tdu, tdv, phi, ksi, w, h, hx, hy, 35.0, d[4], d[5], constancy)
+        odu2, odv2 = oracle.solve_sweep(f0, f1, u, v, odu, odv, ophi, oksi, w, h, hx, hy, 35.0, constancy)
+        assert np.array_equal(d[4].download(w, h), odu2) and np.array_equal(d[5].download(w, h), odv2), constancy
 
 
 @pytest.mark.parametrize("window", [3, 5, 7])
