@@ -24,7 +24,7 @@ for what in $WHAT; do
                 || { tail -5 "$OUT/${ROUND}_${wl}_bench.err"; exit 1; }
             python3 -c "
 import json; d=json.load(open('$OUT/${ROUND}_${wl}_bench_line.json'))
-print('$wl', 'value', d['value'], 'pairs/s', d['pairs_per_s'], 'single', d['pairs_per_s_single'], 'incl_h2d', d['pairs_per_s_incl_h2d'], 'ms/step', d['ms_per_step'], 'launch_ms', d['roofline']['avg_launch_ms'], 'frac', d['roofline']['frac'], 'per_sweep', (d['roofline']['per_sweep'] or {}).get('avg_launch_ms'), (d['roofline']['per_sweep'] or {}).get('frac'), 'check', d['output_check']['ok'])"
+print('$wl', 'value', d['value'], 'pairs/s', d['pairs_per_s'], 'single', d['pairs_per_s_single'], 'incl_h2d', d['pairs_per_s_incl_h2d'], 'ms/step', d['ms_per_step'], 'launch_ms', d['roofline']['avg_launch_ms'], 'frac', d['roofline']['frac'], 'per_sweep', (d['roofline']['per_sweep'] or {}).get('avg_launch_ms'), (d['roofline']['per_sweep'] or {}).get('frac'), (d['roofline']['per_sweep'] or {}).get('effective_frac'), 'check', d['output_check']['ok'])"
         done ;;
     trace)
         export TMPDIR=/tmp
