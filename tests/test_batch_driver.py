@@ -16,6 +16,15 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 TOOL = os.path.join(ROOT, "cuda-flow2d_amd", "host", "flow2d_batch_selftest")
 
 
+@pytest.fixture(scope="module", autouse=True)
+def selftest_binary():
+    """Built by `make -C cuda-flow2d_amd/host` (__graft_entry__.build()); a checkout without it builds just this target
+    (g++ only: it links neither HIP nor RCCL)."""
+    if not os.path.exists(TOOL):
+        subprocess.check_call(["make", "-s", "-C", os.path.dirname(TOOL), "flow2d_batch_selftest"])
+    assert os.path.exists(TOOL)
+
+
 def run(args, timeout=60):
     return subprocess.run([TOOL] + [str(a) for a in args], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
                           timeout=timeout)
