@@ -164,7 +164,7 @@ int RunBatchRank(const BatchOptions& opt, BatchComm& comm, BatchDevice& device)
     const std::vector<size_t> mine = PairsOfRank(total, world, rank);
     const size_t per_rank = PairsPerBlock(total, world);  // block size of the gather (ranks with fewer pairs pad)
     group = std::min(group, std::max<size_t>(1, mine.size()));
-    size_t pitch = 0, plane_bytes = 0;
+    size_t pitch = 0, plane_bytes = 0, sets = 1;
     if (width == 0 || height == 0 ||
         !device.Initialize(width, height, static_cast<int>(block.constancy), static_cast<size_t>(block.lanes), group)) {
         std::fprintf(stderr, "flow2d_batch: rank %d: the device side could not be initialised (%zu x %zu, %zu lanes, groups of %zu)\n",
@@ -174,9 +174,11 @@ int RunBatchRank(const BatchOptions& opt, BatchComm& comm, BatchDevice& device)
         mem.initialized = true;
         pitch = device.PitchBytes();
         plane_bytes = pitch * height;
-        // frames: one container per plane; flows: ONE allocation [per_rank][2][height][pitch], the block the gather moves
+        // frames: one container per plane; flows: `sets` blocks [per_rank][2][height][pitch] in ONE allocation -- a block is
+        // what the gather moves; with repeated passes every lane's worth of passes in flight writes a block of its own
+        sets = repeat > 1 ? std::max<size_t>(1, device.Lanes()) : 1;
         mem.frames.assign(2 * mine.size(), nullptr);
-        mem.flows = device.Alloc(std::max<size_t>(1, per_rank) * 2 * plane_bytes);
+        mem.flows = device.Alloc(sets * std::max<size_t>(1, per_rank) * 2 * plane_bytes);
         if (!mem.flows) status = 1;
         Data2D f0(width, height, device.StagingMemory()), f1(width, height, device.StagingMemory());
         for (size_t i = 0; i < mine.size() && status == 0; ++i) {
@@ -219,33 +221,50 @@ int RunBatchRank(const BatchOptions& opt, BatchComm& comm, BatchDevice& device)
     params.PushValuePtr("median_radius", &median);
     params.PushValuePtr("gaussian_sigma", &sigma);
 
-    std::vector<void*> f0s, f1s, us, vs;
+    const size_t block_bytes = per_rank * 2 * plane_bytes;
+    const size_t set_stride = std::max<size_t>(1, per_rank) * 2 * plane_bytes;
+    const size_t lanes = std::max<size_t>(1, device.Lanes());
+    const size_t groups = (mine.size() + group - 1) / group;  // lock-step groups of a pass, one lane each
+    std::vector<void*> f0s, f1s;
     for (size_t i = 0; i < mine.size(); ++i) {
         f0s.push_back(mem.frames[2 * i]);
         f1s.push_back(mem.frames[2 * i + 1]);
-        us.push_back(static_cast<char*>(mem.flows) + (2 * i) * plane_bytes);
-        vs.push_back(static_cast<char*>(mem.flows) + (2 * i + 1) * plane_bytes);
     }
-    auto pass = [&]() { return device.Pass(mine.size(), f0s.data(), f1s.data(), us.data(), vs.data(), params); };
+    // pass r: flow-buffer set r mod sets, first group on lane (r x groups) mod lanes -- a function of r mod lanes when
+    // sets == lanes, so the graphs the warm-up records are the ones the timed passes replay
+    auto queue_pass = [&](size_t r) {
+        char* base = static_cast<char*>(mem.flows) + (r % sets) * set_stride;
+        std::vector<void*> us, vs;
+        for (size_t i = 0; i < mine.size(); ++i) {
+            us.push_back(base + (2 * i) * plane_bytes);
+            vs.push_back(base + (2 * i + 1) * plane_bytes);
+        }
+        return device.QueuePass(mine.size(), f0s.data(), f1s.data(), us.data(), vs.data(), params, (r * groups) % lanes);
+    };
 
     // ---- 3. warm-up (records the graphs), 4. the timed passes; the agreements are the barriers around them ------------------
-    status = pass() ? 0 : 1;
+    device.BeginPhase("warmup");
+    for (size_t r = 0; r < sets && status == 0; ++r)
+        if (!queue_pass(r)) status = 1;
+    if (!device.Synchronize()) status = std::max(status, 1);
     if (int all = agree(status)) return all;
+    device.BeginPhase("timed");
     const auto t0 = std::chrono::steady_clock::now();
     for (size_t r = 0; r < repeat && status == 0; ++r)
-        if (!pass()) status = 1;
+        if (!queue_pass(r)) status = 1;
+    if (!device.Synchronize()) status = std::max(status, 1);
     if (int all = agree(status)) return all;
     const double seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    const char* result_block = static_cast<char*>(mem.flows) + ((repeat - 1) % sets) * set_stride;  // the last pass's flows
 
     // ---- 5. gather: every rank's block of flow fields to rank 0 ----------------------------------------------------------------
-    const size_t block_bytes = per_rank * 2 * plane_bytes;
     if (rank == 0) {
         mem.gathered = device.Alloc(std::max<size_t>(1, block_bytes) * static_cast<size_t>(world));
         if (!mem.gathered) status = 1;
     }
     if (int all = agree(status)) return all;
     const auto g0 = std::chrono::steady_clock::now();
-    if (!comm.GatherToRoot(mem.flows, mem.gathered, block_bytes)) {
+    if (!comm.GatherToRoot(result_block, mem.gathered, block_bytes)) {
         std::fprintf(stderr, "flow2d_batch: rank %d: the gather failed\n", rank);
         return 1;
     }
@@ -287,10 +306,10 @@ int RunBatchRank(const BatchOptions& opt, BatchComm& comm, BatchDevice& device)
                 layout += "]";
             }
             std::printf("{\"tool\": \"flow2d_batch\", \"world\": %d, \"pairs\": %zu, \"repeat\": %zu, \"width\": %zu, \"height\": %zu, "
-                        "\"lanes\": %zu, \"group\": %zu, \"seconds\": %.6f, \"pairs_per_s\": %.3f, \"mpixel_iters_per_s\": %.1f, "
+                        "\"lanes\": %zu, \"group\": %zu, \"passes_in_flight\": %zu, \"seconds\": %.6f, \"pairs_per_s\": %.3f, \"mpixel_iters_per_s\": %.1f, "
                         "\"gather\": \"every rank's block to rank 0\", \"pairs_per_block\": %zu, \"pitch_bytes\": %zu, "
                         "\"gather_bytes_per_rank\": %zu, \"gather_ms\": %.3f, \"flows_fnv1a\": \"%016llx\"%s}\n",
-                        world, total, repeat, width, height, device.Lanes(), group, seconds, pairs / seconds,
+                        world, total, repeat, width, height, device.Lanes(), group, sets, seconds, pairs / seconds,
                         pairs * static_cast<double>(width * height) * static_cast<double>(outer * inner) / seconds / 1e6, per_rank,
                         pitch, block_bytes, gather_seconds * 1e3, static_cast<unsigned long long>(digest), layout.c_str());
             std::fflush(stdout);

@@ -9,8 +9,9 @@
 // Protocol of a rank (RunBatchRank):
 //   1. broadcast of rank 0's parameter block: every rank solves with rank 0's parameters
 //   2. pair k -> rank k mod world; the rank loads (or generates) its pairs and uploads them          -> agreement
-//   3. warm-up pass (records the graphs)                                                           -> agreement
-//   4. `repeat` timed passes                                                                       -> agreement
+//   3. warm-up passes (record the graphs: one pass per flow-buffer set)                             -> agreement
+//   4. `repeat` timed passes, queued back to back -- pass r starts on lane (r x groups) mod lanes and writes flow-buffer
+//      set r mod lanes, so consecutive passes overlap on the GPU like the steps of bench.py -- one wait at the end  -> agreement
 //   5. gather: every rank's block [per_rank][2][height][pitch] of flow fields to rank 0 (ranks with fewer pairs pad)
 //   6. rank 0 writes flow_%04d_{u,v}.raw, prints one JSON line                                      -> agreement
 // An "agreement" is a one-word all-reduce (maximum) of the ranks' status codes: it is the barrier of the timed region,
@@ -59,9 +60,12 @@ public:
     virtual bool Download(void* host, const void* src, size_t bytes) = 0;
     virtual bool UploadPlane(void* dst_plane, Data2D& image) = 0;          // tight host rows -> pitched rows
     virtual bool DownloadPlane(Data2D& image, const void* src_plane) = 0;  // and back
-    // the flows of `count` independent pairs (planes of PitchBytes() x height); returns once they are in memory
-    virtual bool Pass(size_t count, void* const* frames_0, void* const* frames_1, void* const* flows_u, void* const* flows_v,
-                      OperationParameters& params) = 0;
+    // Queues the flows of `count` independent pairs (planes of PitchBytes() x height), the first group of them on lane
+    // `first_lane`, the following groups on the following lanes; nothing is waited for until Synchronize().
+    virtual bool QueuePass(size_t count, void* const* frames_0, void* const* frames_1, void* const* flows_u,
+                           void* const* flows_v, OperationParameters& params, size_t first_lane) = 0;
+    virtual bool Synchronize() = 0;
+    virtual void BeginPhase(const char* name) { (void)name; }  // "warmup" / "timed": a hook for the self-test's failure injection
     virtual void Destroy() = 0;
 };
 

@@ -168,8 +168,8 @@ public:
                                        image.Height(), hipMemcpyDeviceToHost, stream_)) &&
                HIP_OK(hipStreamSynchronize(stream_));
     }
-    bool Pass(size_t count, void* const* frames_0, void* const* frames_1, void* const* flows_u, void* const* flows_v,
-              OperationParameters& params) override
+    bool QueuePass(size_t count, void* const* frames_0, void* const* frames_1, void* const* flows_u, void* const* flows_v,
+                   OperationParameters& params, size_t first_lane) override
     {
         auto as_ptr = [](void* p) { return static_cast<DevicePtr>(reinterpret_cast<uintptr_t>(p)); };
         std::vector<DevicePtr> f0s, f1s, us, vs;
@@ -179,8 +179,9 @@ public:
             us.push_back(as_ptr(flows_u[i]));
             vs.push_back(as_ptr(flows_v[i]));
         }
-        return batch_.ComputeFlowBatchDeviceGrouped(count, f0s.data(), f1s.data(), us.data(), vs.data(), params) && batch_.Synchronize();
+        return batch_.ComputeFlowBatchDeviceGrouped(count, f0s.data(), f1s.data(), us.data(), vs.data(), params, first_lane);
     }
+    bool Synchronize() override { return batch_.Synchronize(); }
     void Destroy() override { batch_.Destroy(); }
 
 private:

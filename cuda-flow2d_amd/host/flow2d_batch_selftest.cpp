@@ -150,10 +150,12 @@ public:
             std::memcpy(image.DataPtr() + y * image.Width(), static_cast<const char*>(src_plane) + y * pitch_, image.Width() * 4);
         return true;
     }
-    bool Pass(size_t count, void* const* frames_0, void* const* frames_1, void* const* flows_u, void* const* flows_v,
-              OperationParameters& params) override
+    void BeginPhase(const char* name) override { phase_ = name; }
+    bool Synchronize() override { return true; }
+    bool QueuePass(size_t count, void* const* frames_0, void* const* frames_1, void* const* flows_u, void* const* flows_v,
+                   OperationParameters& params, size_t first_lane) override
     {
-        if (Fails(passes_ == 0 ? "warmup" : "pass")) return false;
+        if (Fails(phase_ == "warmup" ? "warmup" : "pass") || first_lane >= lanes_) return false;
         ++passes_;
         size_t levels = 0;
         if (!params.Read("warp_levels_count", levels)) return false;
@@ -177,6 +179,7 @@ private:
     Failure failure_;
     size_t width_ = 0, height_ = 0, lanes_ = 0, group_ = 0, pitch_ = 0;
     int passes_ = 0, allocations_ = 0;
+    std::string phase_;
 };
 
 struct SelfTestFlags {
