@@ -166,7 +166,7 @@ int flow2d_synchronize(flow2d_context* ctx)
     return FLOW2D_OK;
 }
 
-// word 0: guard trips, word 1: waves of plain-only launches (solve_fused.hip)
+// word 0: guard trips, word 1: waves of plain-only launches (solve_fused_kernel.hpp)
 static int read_fused_counter(flow2d_context* ctx, int word, unsigned long long* waves)
 {
     FLOW2D_ENTER(ctx);

@@ -1,0 +1,70 @@
+// Arguments of the fused outer-iteration kernel (solve_fused_kernel.hpp), shared by its instance translation units
+// (solve_fused_instance.hip, one object per data term and spacing kind) and the launcher (solve_fused.hip).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+namespace flow2d {
+
+struct FusedArgs {
+    const float* f0;
+    const float* f1;
+    const float* u;
+    const float* v;
+    const float* du;
+    const float* dv;
+    float* out_du;
+    float* out_dv;
+    int w, h, pitch;
+    // Strip heights (FusedPlan): a wave whose strip touches an image border runs the EDGE body, about a fifth more
+    // instructions per row than an interior wave's, and a launch is one round of waves -- as long as its slowest wave.
+    // So border strips are shorter: the first and the last strip of every column of strips hold rows_edge rows, the ones
+    // between them rows_interior (strips_interior strips per column in all); the first and the last BLOCK in x (they
+    // hold the strips on the left / right border) are cut into strips of rows_edge throughout.  rows_interior ==
+    // rows_edge: uniform strips.
+    int rows_interior, rows_edge, strips_interior;
+    // The grid is one-dimensional over the blocks that have a strip (a two-dimensional grid would hold empty blocks,
+    // and with blocks dealt to the eight XCDs in turn the working ones would pile up on some of them): block id ->
+    // (block column, strip) by blocks_x, the block columns of the image.
+    int blocks_x;
+    int zero_increment;  // first outer iteration: du = dv = 0, the planes are not read (and need no memset)
+    // More sweeps per outer iteration than one launch holds: a later launch of the same outer iteration rebuilds
+    // the coefficients from the same du/dv (identical arithmetic, identical values) and continues the sweeps
+    // from the previous launch's result in start_du/start_dv.
+    const float* start_du;
+    const float* start_dv;
+    int continue_sweeps;
+    float hx, hy, alpha, e_smooth, e_data;
+    // Wave-uniform constants of the level, evaluated on the HOST in the reference's float / double arithmetic (the same
+    // IEEE operations the kernel would perform) so that they arrive as kernel arguments in scalar registers: computed in
+    // the kernel they are vector-ALU results, which the compiler broadcasts into vector register pairs, hoists out of the
+    // row loop and -- the register file being full -- spills, one scratch reload per use and row step.
+    float two_hx, two_hy, four_hx, four_hy;          // 2h, 4h (solve_2d.cu:141-171)
+    float inv_two_hx, inv_two_hy, inv_four_hx, inv_four_hy;  // their reciprocals (exact when h is a power of two)
+    float hx_1, hy_1;                                // float(1.0 / (2.0 * h)), solve_2d.cu:868-869
+    float hx_2, hy_2;                                // alpha / (h * h), solve_2d.cu:337-340
+    int plain_only;                   // a grid spacing outside the range the three-step division is proven for: every wave
+                                      // takes the fallback pass (plain divisions) at once
+    int blocks, blocks_per_xcd;       // working blocks of the plan; ceil(blocks / 8), or 0 for the plain block order
+    unsigned long long batch_stride;  // floats between the instances of a batched launch (blockIdx.z)
+#ifdef FLOW2D_FUSED_STAMPS  // developer builds: per-wave time stamps (8 words per wave) and their counter
+    unsigned long long* stamps;
+    unsigned int* stamp_count;
+#endif
+    unsigned int* fallback_count;     // [0] waves that repeated their strip with the plain division, [1] waves of plain_only
+                                      // launches (diagnostics; may be null)
+};
+
+// One entry per instance object: launches fused_outer_kernel<inner, GRAD, POW2, CONT> (CONT from a.continue_sweeps); returns
+// non-zero when the object holds no such instantiation (inner outside 1..5, or a developer build's reduced set).
+#define FLOW2D_FUSED_LAUNCHER(g, p) int fused_launch_g##g##_p##p(int inner, dim3 grid, hipStream_t stream, const FusedArgs& a)
+FLOW2D_FUSED_LAUNCHER(0, 0);
+FLOW2D_FUSED_LAUNCHER(0, 1);
+FLOW2D_FUSED_LAUNCHER(1, 0);
+FLOW2D_FUSED_LAUNCHER(1, 1);
+FLOW2D_FUSED_LAUNCHER(2, 0);
+FLOW2D_FUSED_LAUNCHER(2, 1);
+FLOW2D_FUSED_LAUNCHER(3, 0);
+FLOW2D_FUSED_LAUNCHER(3, 1);
+
+}  // namespace flow2d

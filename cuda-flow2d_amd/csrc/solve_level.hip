@@ -194,7 +194,7 @@ int flow2d_solve_level(flow2d_context* ctx, const float* frame_0, const float* f
 #else
     const int rows_env = 0;
 #endif
-    // Fused path: one launch per outer iteration does phi/ksi and up to 5 sweeps (solve_fused.hip); phi and ksi
+    // Fused path: one launch per outer iteration does phi/ksi and up to 5 sweeps (solve_fused_kernel.hpp); phi and ksi
     // are not materialised, so their planes serve as a third (du, dv) pair.  More than 5 sweeps per outer
     // iteration are split into equal chunks: every chunk rebuilds the coefficients from the outer iteration's
     // starting pair (same arithmetic, same values) and continues the sweeps from the previous chunk's result.

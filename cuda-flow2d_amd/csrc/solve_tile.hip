@@ -1,7 +1,7 @@
 // One outer iteration of the variational solver on small LDS tiles: the kernel shape for the MID-SIZE and small
 // pyramid levels (64 x 33 ... 896 x 896 pixels).
 //
-// The fused strip kernel (solve_fused.hip) gives a wave a 64-column strip and lets it walk down the image; a wave
+// The fused strip kernel (solve_fused_kernel.hpp) gives a wave a 64-column strip and lets it walk down the image; a wave
 // issues one instruction every ~4 cycles whatever it is, so a launch lasts (rows + halo) x ~1.1 us however few strips
 // there are -- at 256 x 256 twelve microseconds for work that would occupy the chip's vector ALUs for half a
 // microsecond.  Here the same outer iteration (compute_phi_ksi + `inner` Jacobi sweeps, solve_2d.cu:43-377) is cut into

@@ -1,5 +1,5 @@
 // Pointwise arithmetic of the variational solver, shared by the per-sweep kernels (solve.hip) and the
-// fused outer-iteration kernel (solve_fused.hip) so both evaluate literally the same expressions.
+// fused outer-iteration kernel (solve_fused_kernel.hpp) so both evaluate literally the same expressions.
 // Operation order and float/double promotions are those of the reference's src/kernels/solve_2d.cu
 // (lines cited per function); built with -ffp-contract=off, so nothing is fused.
 #pragma once

@@ -1,7 +1,7 @@
 """Developer tool (round 4): where does a launch of the fused strip kernel spend its time, wave by wave?
 
 Needs a developer build of the library with the wave stamps compiled in:
-    make -C cuda-flow2d_amd/csrc BUILD=build_stamps LIB=$PWD/ab/stamps.so EXTRA="-DFLOW2D_DEV_BUILD -DFLOW2D_FUSED_STAMPS -DFLOW2D_FUSED_DEV"
+    make -C cuda-flow2d_amd/csrc BUILD=build_stamps LIB=$PWD/ab/stamps.so EXTRA="-DFLOW2D_DEV_BUILD -DFLOW2D_FUSED_STAMPS -DFLOW2D_FUSED_DEV"   (add -j8)
     FLOW2D_HIP_LIB=$PWD/ab/stamps.so python tools/fused_wave_stamps.py [WxH[*instances]] [grey|grad]
 Every wave records its start and end on the 100 MHz clock, its shader cycles, where it ran (XCC, SE, CU, SIMD) and which
 strip it had.  Printed per launch: the span of the launch, the distribution of the waves' lifetimes, the spread of their

@@ -1,4 +1,4 @@
-// Proof by exhaustion for the three-instruction division of the fused solver kernel (solve_fused.hip):
+// Proof by exhaustion for the three-instruction division of the fused solver kernel (solve_fused_kernel.hpp):
 //
 //     y  = RN(1 / d)                 once per pixel and outer iteration (a true, correctly rounded division)
 //     q0 = RN(n * y)
@@ -76,7 +76,7 @@ __device__ __forceinline__ unsigned long long lcg(unsigned long long& s)
     return s;
 }
 
-// the run-time guard of the kernel (solve_fused.hip, DivGuard): tiny numerators by an integer test on the bit pattern
+// the run-time guard of the kernel (solve_fused_kernel.hpp, DivGuard): tiny numerators by an integer test on the bit pattern
 // -- the shift drops the sign, the decrement sends a zero to the top -- and non-finite results
 __device__ __forceinline__ bool guard_ok(float n, float q)
 {

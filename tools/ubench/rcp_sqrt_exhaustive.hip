@@ -1,4 +1,4 @@
-// Proof by exhaustion for the short forms of the coefficient stage of the fused solver kernel (solve_fused.hip):
+// Proof by exhaustion for the short forms of the coefficient stage of the fused solver kernel (solve_fused_kernel.hpp):
 //
 //   reciprocal   y0 = v_rcp_f32(d);  e = fma(-d, y0, 1);  y = fma(e, y0, y0)             == 1.0f / d ?
 //   square root  g0 = v_sqrt_f32(s); h = 0.5f * v_rsq_f32(s); r = fma(-g0, g0, s); g = fma(r, h, g0)   == sqrtf(s) ?
