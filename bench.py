@@ -1030,6 +1030,10 @@ def main():
             "valu_instr_per_launch": valu,
             "valu_issue_frac": round(valu_frac, 4) if valu_frac else None,  # of one wave64 instruction per 2 cycles per SIMD
             "valu_peak_instr_per_s": SIMDS * CLOCK_HZ / VALU_ISSUE_CYCLES,
+            # SIMD cycles (at the nominal 2.4 GHz; the kernel holds 2.05-2.3) per wave64 VALU instruction of the launch: two
+            # waves of this kernel's instruction mix on a SIMD get through one per about 4.3 cycles when both are busy
+            # (per-wave stamps, profiles/r04_experiments/README.md sections 2-3) -- that, not one per 2 cycles, is its ceiling
+            "valu_cycles_per_instr_per_simd": round(SIMDS * CLOCK_HZ * kernel_ms * 1e-3 / valu, 2) if valu else None,
             # SURVEY 8(d) metric 1, second half -- "the pure inner-sweep rate (events around K7 only)": the per-sweep Jacobi
             # kernel (one launch per reference launch of solve_2d*) at this workload's finest level, alone on the GPU.  It is
             # the path of inner = 1, red-black SOR and planes of 4 GiB and more, and the literal subject of north_star's
