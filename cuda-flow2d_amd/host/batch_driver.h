@@ -1,7 +1,7 @@
 // The rank logic of flow2d_batch -- independent image pairs over the GPUs of one node (BASELINE.json
 // configs[3]) -- written against two small interfaces, so that the very same code runs with
 //   * librccl + HIP + OpticalFlowBatch2D          (the product: flow2d_batch.cpp), and
-//   * an in-process loopback + host memory + stamps (flow2d_batch_selftest.cpp: world sizes 2, 3, 8 on a machine without
+//   * an in-process loopback + host memory + stamps (tests/c/flow2d_batch_selftest.cpp: world sizes 2, 3, 8 on a machine without
 //     a GPU; the pair -> rank mapping, the padded gather blocks and the failure protocol are what is under test).
 // The reference has no counterpart: it holds one context on device 0 (src/utils/cuda_utils.cpp:43) and computes one
 // pair per process run (src/main.cpp).

@@ -6,7 +6,7 @@
 // This file is the product front end: the librccl back end of BatchComm, the HIP / OpticalFlowBatch2D back end of
 // BatchDevice, and the two ways of starting ranks.  The rank logic itself -- parameter broadcast, pair -> rank mapping,
 // padded gather blocks, status agreements, output files -- is batch_driver.cpp, which the CPU self-test
-// (flow2d_batch_selftest.cpp) runs at world sizes 2, 3 and 8 over an in-process loopback.
+// (tests/c/flow2d_batch_selftest.cpp) runs at world sizes 2, 3 and 8 over an in-process loopback.
 //
 // Collectives (librccl, directly): ncclBroadcast of rank 0's parameter block; a one-word ncclAllReduce (maximum) as the
 // barrier around the timed region and as the status agreement before every phase; grouped ncclSend / ncclRecv of every
