@@ -50,11 +50,12 @@
 //   FLOW2D_FUSED_EDGE_COST=x     border / interior body cost ratio of the strip planner (default 1.22)
 //   FLOW2D_FUSED_NO_SPLIT        a lock-step group's finest level as one launch of several rounds
 //   FLOW2D_FUSED_PLAIN_ORDER     blocks in plain order instead of one contiguous run per XCD
+//   FLOW2D_FUSED_NO_PACKED       the face products as plain multiplies (with -Xclang -target-feature -Xclang -packed-fp32-ops: no packed arithmetic at all)
 //   FLOW2D_FUSED_COMPUTE_ONLY, FLOW2D_FUSED_MEMORY_ONLY   timing probes that compute WRONG results
 #if (defined(FLOW2D_FUSED_STAMPS) || defined(FLOW2D_FUSED_COMPUTE_ONLY) || defined(FLOW2D_FUSED_MEMORY_ONLY) ||          \
      defined(FLOW2D_FUSED_TURN_SHIFT) || defined(FLOW2D_FUSED_PLAIN_DIVISION) || defined(FLOW2D_FUSED_NO_PINS) ||          \
      defined(FLOW2D_FUSED_DEV) || defined(FLOW2D_FUSED_EDGE_COST) || defined(FLOW2D_FUSED_NO_SPLIT) ||                    \
-     defined(FLOW2D_FUSED_PLAIN_ORDER)) &&                                                                               \
+     defined(FLOW2D_FUSED_PLAIN_ORDER) || defined(FLOW2D_FUSED_NO_PACKED)) &&                                                                               \
     !defined(FLOW2D_DEV_BUILD)
 #error "the fused kernel's timing probes need -DFLOW2D_DEV_BUILD: they are not part of the product library"
 #endif
@@ -247,12 +248,18 @@ __device__ __forceinline__ bool guard_tripped(const DivGuard& g)
 // transcendental instruction, which on gfx950 needs a wait state before an ordinary VALU instruction may read it.)
 __device__ __forceinline__ v2f mul_by_x(v2f w, v2f d)
 {
+#ifdef FLOW2D_FUSED_NO_PACKED
+    return v2f{w.x * d.x, w.x * d.y};
+#endif
     v2f r;
     asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]" : "=v"(r) : "v"(w), "v"(d));
     return r;
 }
 __device__ __forceinline__ v2f mul_by_y(v2f w, v2f d)
 {
+#ifdef FLOW2D_FUSED_NO_PACKED
+    return v2f{w.y * d.x, w.y * d.y};
+#endif
     v2f r;
     asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,0]" : "=v"(r) : "v"(w), "v"(d));
     return r;
