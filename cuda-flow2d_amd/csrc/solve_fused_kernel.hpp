@@ -176,7 +176,10 @@ __device__ __forceinline__ float half_inverse_root(float s, float& twice_root)
 //         harmless is a numerator of exactly -0, whose quotient is -0 while the three steps give +0; it takes a -0 in the
 //         flow planes to produce one (the sum of the four face terms is -0 only if all four are):
 //   zero: signed min of the raw bits of every flow value read: INT_MIN exactly when one of them is a -0
-//   den : max of bits(den) - bits(2^-30): above kDenSpan for a denominator outside [2^-30, 2^40], negative or NaN
+//   den : float minimum and maximum of the denominators (v_min3_f32 / v_max3_f32: two instructions for a pair instead of
+//         two integer subtractions and a v_max3_u32): outside [2^-30, 2^40] for a denominator that is too small, too
+//         large, zero, negative or infinite.  A NaN passes both (minNum / maxNum return the other operand) -- and turns
+//         du, dv of its pixel into NaN in the first sweep, in either form of the division, which `out` sees
 //   out : max of bits(du, dv) << 1 over the stored results: above kOutLimit for an infinity or a NaN
 #ifdef FLOW2D_FUSED_NO_PINS
 #define FLOW2D_GUARD_PIN(x) ((void)0)
@@ -184,11 +187,12 @@ __device__ __forceinline__ float half_inverse_root(float s, float& twice_root)
 #define FLOW2D_GUARD_PIN(x) asm volatile("" : "+v"(x))
 #endif
 struct DivGuard {
-    unsigned tiny, den, out;
+    unsigned tiny, out;
+    float den_lo, den_hi;
     int zero;
 };
 constexpr unsigned kTinyLimit = 2u * 0x17800000u - 1u;         // 2^-80 = 0x17800000
-constexpr unsigned kDenLow = 0x30800000u, kDenSpan = 0x53800000u - 0x30800000u;  // 2^-30, 2^40
+constexpr float kDenLow = 0x1p-30f, kDenHigh = 0x1p40f;
 constexpr unsigned kOutLimit = 0xfefffffeu;                    // FLT_MAX << 1
 // (the empty asm pins each update where it is written: left alone, the compiler sinks all updates of a ring turn to the
 //  loop latch and keeps the sixty numerators of the turn alive until then)
@@ -207,8 +211,9 @@ __device__ __forceinline__ void guard_flow_row(DivGuard& g, v2f uv, v2f duv)
 }
 __device__ __forceinline__ void guard_denominators(DivGuard& g, float du, float dv)
 {
-    g.den = max(g.den, max(__float_as_uint(du) - kDenLow, __float_as_uint(dv) - kDenLow));
-    FLOW2D_GUARD_PIN(g.den);
+    // (the operands are results of ordinary arithmetic, never the direct result of a transcendental instruction: see mul_by_x)
+    asm("v_min3_f32 %0, %0, %1, %2" : "+v"(g.den_lo) : "v"(du), "v"(dv));
+    asm("v_max3_f32 %0, %0, %1, %2" : "+v"(g.den_hi) : "v"(du), "v"(dv));
 }
 __device__ __forceinline__ void guard_results(DivGuard& g, float du, float dv)
 {
@@ -238,7 +243,7 @@ __device__ __forceinline__ v2f spacing_quotient2(DivGuard& g, v2f n, float d, fl
 
 __device__ __forceinline__ bool guard_tripped(const DivGuard& g)
 {
-    return g.tiny < kTinyLimit || g.den > kDenSpan || g.out > kOutLimit || g.zero == static_cast<int>(0x80000000u);
+    return g.tiny < kTinyLimit || !(g.den_lo >= kDenLow) || !(g.den_hi <= kDenHigh) || g.out > kOutLimit || g.zero == static_cast<int>(0x80000000u);
 }
 
 // (w.x * d.x, w.x * d.y) and (w.y * d.x, w.y * d.y): v_pk_mul_f32 reading ONE half of w for both products (op_sel).  The
@@ -672,7 +677,7 @@ __device__ __forceinline__ bool run_strip(const FusedArgs& a, int x, int xc, boo
         s.C[i].den = s.C[i].rden = v2f{1.f, 1.f};
     }
     s.p_fx = s.p_fy = s.p_ft = s.p_ksi = 0.f;
-    s.guard = DivGuard{0xffffffffu, 0u, 0u, 0x7fffffff};
+    s.guard = DivGuard{0xffffffffu, 0u, 1.f, 1.f, 0x7fffffff};
     s.turn_parity = turn_parity();
     s.turn_clock = kTurnShift >= 0 ? __builtin_amdgcn_s_memtime() : 0ull;
 
