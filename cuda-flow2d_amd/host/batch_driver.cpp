@@ -156,6 +156,15 @@ int RunBatchRank(const BatchOptions& opt, BatchComm& comm, BatchDevice& device)
         std::fprintf(stderr, "flow2d_batch: rank %d: the parameter broadcast failed\n", rank);
         return 1;
     }
+    // every rank judges the same block, so they all leave together (3: the code of a bad command line)
+    auto whole = [](double v, double low, double high) { return v >= low && v <= high && v == std::floor(v); };
+    if (!whole(block.width, 1, 1 << 20) || !whole(block.height, 1, 1 << 20) || !whole(block.pairs_total, 0, 1e9) ||
+        !whole(block.lanes, 1, 64) || !whole(block.group, 1, 1e9) || !whole(block.repeat, 1, 1e9) || !whole(block.levels, 1, 64) ||
+        !whole(block.outer, 1, 1e6) || !whole(block.inner, 1, 1e6) || !whole(block.median, 0, 64) || !whole(block.constancy, 0, 2) ||
+        !(block.scale > 0.0 && block.scale < 1.0)) {
+        if (rank == 0) std::fprintf(stderr, "flow2d_batch: parameters out of range\nusage: flow2d_batch %s", BatchUsage());
+        return 3;
+    }
     const size_t width = static_cast<size_t>(block.width), height = static_cast<size_t>(block.height);
     const size_t total = static_cast<size_t>(block.pairs_total), repeat = std::max<size_t>(1, static_cast<size_t>(block.repeat));
     size_t group = std::max<size_t>(1, static_cast<size_t>(block.group));
@@ -165,8 +174,7 @@ int RunBatchRank(const BatchOptions& opt, BatchComm& comm, BatchDevice& device)
     const size_t per_rank = PairsPerBlock(total, world);  // block size of the gather (ranks with fewer pairs pad)
     group = std::min(group, std::max<size_t>(1, mine.size()));
     size_t pitch = 0, plane_bytes = 0, sets = 1;
-    if (width == 0 || height == 0 ||
-        !device.Initialize(width, height, static_cast<int>(block.constancy), static_cast<size_t>(block.lanes), group)) {
+    if (!device.Initialize(width, height, static_cast<int>(block.constancy), static_cast<size_t>(block.lanes), group)) {
         std::fprintf(stderr, "flow2d_batch: rank %d: the device side could not be initialised (%zu x %zu, %zu lanes, groups of %zu)\n",
                      rank, width, height, static_cast<size_t>(block.lanes), group);
         status = 1;

@@ -107,6 +107,10 @@ def test_exit_codes_of_a_job(tmp_path):
     p = run(["--world", 2, "--pairs", 3, "--width", w, "--height", h, "--out-dir", tmp_path / "nope"], timeout=30)
     assert p.returncode == 255
     assert run(["--no-such-flag"]).returncode == 3
+    # parameters out of range: judged after the broadcast, on rank 0's block, by every rank alike
+    for bad in (["--pairs", -1], ["--width", 0], ["--height", 2.5], ["--lanes", 0], ["--scale", 1.5], ["--repeat", 0]):
+        p = run(["--world", 3] + bad, timeout=30)
+        assert p.returncode == 3 and "out of range" in p.stderr, (bad, p.returncode, p.stderr[-300:])
 
 
 def test_more_ranks_than_pairs(tmp_path):
