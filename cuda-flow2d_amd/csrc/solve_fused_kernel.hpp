@@ -147,25 +147,28 @@ __device__ __forceinline__ float div3(float n, float d, float y)
 // 1.0f / d in three instructions: the hardware approximation and one fma pair.  RN(1 / d) for EVERY normal d whose
 // reciprocal is normal -- all 2 113 929 217 bit patterns of [2^-126, 2^126] tried on the device
 // (tools/ubench/rcp_sqrt_exhaustive.hip; the compiler's correctly rounded division is eleven, five of them quarter-rate).
-__device__ __forceinline__ float rcp3(float d)
+// The kernel only ever needs two of them side by side -- the two denominators of a pixel, the two robustifiers of a pixel --
+// so the fma steps are packed instructions (v_pk_fma_f32), each half the scalar sequence bit for bit.
+__device__ __forceinline__ v2f fma2(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ v2f rcp3_pair(v2f d)
 {
-    const float y0 = __builtin_amdgcn_rcpf(d);
-    const float e = __builtin_fmaf(-d, y0, 1.0f);
-    return __builtin_fmaf(e, y0, y0);
+    const v2f y0 = v2f{__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y)};
+    const v2f e = fma2(-d, y0, v2f{1.f, 1.f});
+    return fma2(e, y0, y0);
 }
 
 // 1.f / (2.f * sqrtf(s)) in nine instructions instead of 28: the hardware root corrected by its residual times half the
 // hardware reciprocal root is RN(sqrt(s)), and rcp3 of twice that (exact) is the quotient -- for every s whose
 // 2 sqrt(s) lies within the guarded denominator range (every bit pattern tried, same ubench).  twice_root goes to the
 // guard: a zero, an infinity, a NaN or a negative argument leave a NaN or an out-of-range value there.
-__device__ __forceinline__ float half_inverse_root(float s, float& twice_root)
+__device__ __forceinline__ v2f half_inverse_root_pair(v2f s, v2f& twice_root)
 {
-    const float g0 = __builtin_amdgcn_sqrtf(s);
-    const float h = 0.5f * __builtin_amdgcn_rsqf(s);
-    const float r = __builtin_fmaf(-g0, g0, s);
-    const float g = __builtin_fmaf(r, h, g0);
+    const v2f g0 = v2f{__builtin_amdgcn_sqrtf(s.x), __builtin_amdgcn_sqrtf(s.y)};
+    const v2f h = 0.5f * v2f{__builtin_amdgcn_rsqf(s.x), __builtin_amdgcn_rsqf(s.y)};
+    const v2f r = fma2(-g0, g0, s);
+    const v2f g = fma2(r, h, g0);
     twice_root = 2.f * g;
-    return rcp3(twice_root);
+    return rcp3_pair(twice_root);
 }
 
 // What the proof does not cover is recorded per lane in four integer accumulators -- integer min / max on the operands'
@@ -238,7 +241,19 @@ __device__ __forceinline__ v2f spacing_quotient2(DivGuard& g, v2f n, float d, fl
     if (POW2) return n * y;
     if (!FAST) return v2f{n.x / d, n.y / d};
     guard_numerators(g, n.x, n.y);
-    return v2f{div3(n.x, d, y), div3(n.y, d, y)};
+    const v2f q0 = n * y;  // div3 on both halves
+    return fma2(fma2(-q0, v2f{d, d}, n), v2f{y, y}, q0);
+}
+
+// (n.x / d.x, n.y / d.y): the x and the y spacing's quotients of one pixel
+template <bool POW2, bool FAST>
+__device__ __forceinline__ v2f spacing_quotient_pair(DivGuard& g, v2f n, v2f d, v2f y)
+{
+    if (POW2) return n * y;
+    if (!FAST) return v2f{n.x / d.x, n.y / d.y};
+    guard_numerators(g, n.x, n.y);
+    const v2f q0 = n * y;  // div3 on both halves
+    return fma2(fma2(-q0, d, n), y, q0);
 }
 
 __device__ __forceinline__ bool guard_tripped(const DivGuard& g)
@@ -274,6 +289,21 @@ __device__ __forceinline__ float scalar_only(float v)
 {
     asm("" : "+v"(v));
     return v;
+}
+// ksi_argument (solver_math.hpp) with the rows of the brightness tensor as pairs -- 15 instructions instead of 26; every
+// product and every sum is one of the scalar form's, in its order (J12 = fx fy is formed as fy fx in one of its two copies)
+__device__ __forceinline__ float ksi_argument_packed(float fx, float fy, float ft, v2f duv, float e_data)
+{
+    const v2f fxy = v2f{fx, fy};
+    const v2f J11_12 = mul_by_x(fxy, fxy), J12_22 = mul_by_y(fxy, fxy);  // (fx fx, fx fy), (fy fx, fy fy)
+    const v2f J13_23 = fxy * v2f{ft, ft};
+    const float J33 = ft * ft;
+    // ((J11 du + J12 dv + J13) du, (J12 du + J22 dv + J23) dv) and (J13 du, J23 dv)
+    const v2f rows = (mul_by_x(duv, J11_12) + mul_by_y(duv, J12_22) + J13_23) * duv;
+    const v2f last = J13_23 * duv;
+    float s = rows.x + rows.y + (last.x + last.y + J33);
+    s = static_cast<float>(s > 0) * s;
+    return s + e_data * e_data;
 }
 // sum_flux2 (solver_math.hpp) over the four neighbour differences, same order of additions
 __device__ __forceinline__ v2f flux_of_differences(v2f wx, v2f wy, v2f dR, v2f dL, v2f dD, v2f dU)
@@ -417,25 +447,38 @@ __device__ __forceinline__ void strip_step(Strip<INNER, GRAD>& s, const FusedArg
         const v2f dx = spacing_quotient2<POW2, FAST>(s.guard, xnum, a.two_hx, a.inv_two_hx);
         const v2f dy = spacing_quotient2<POW2, FAST>(s.guard, ynum, a.two_hy, a.inv_two_hy);
         float t_phi = 1.f, t_ksi = 1.f;  // 2 sqrt(.) of the two robustifiers, for the guard
-        if (FAST) s.phiw[s1] = half_inverse_root(phi_argument(dx.x, dy.x, dx.y, dy.y, a.e_smooth), t_phi);
-        else s.phiw[s1] = phi_value(dx.x, dy.x, dx.y, dy.y, a.e_smooth);
+        float phi_arg = 0.f;
+        if (FAST) {  // phi_argument (solver_math.hpp), the four squares as two packed products; the root follows with ksi's
+            const v2f dx2 = dx * dx, dy2 = dy * dy;
+            phi_arg = dx2.x + dy2.x + dx2.y + dy2.y + a.e_smooth * a.e_smooth;
+        } else {
+            s.phiw[s1] = phi_value(dx.x, dy.x, dx.y, dy.y, a.e_smooth);
+        }
 
         const float f0c = s.f0w[s1], f1c = s.f1w[s1];
+        float fx_num;
         if (!EDGE) {
-            const float fx_num = scalar_only(scalar_only(scalar_only(from_right(f0c) - from_left(f0c)) + from_right(f1c)) - from_left(f1c));
-            fx = spacing_quotient<POW2, FAST>(s.guard, fx_num, a.four_hx, a.inv_four_hx);
+            fx_num = scalar_only(scalar_only(scalar_only(from_right(f0c) - from_left(f0c)) + from_right(f1c)) - from_left(f1c));
         } else {
             const float f0l0 = from_left(f0c), f0r0 = from_right(f0c), f1l0 = from_left(f1c), f1r0 = from_right(f1c);
             const float f0L = at_l ? f0r0 : f0l0, f0R = at_r ? f0l0 : f0r0;
             const float f1L = at_l ? f1r0 : f1l0, f1R = at_r ? f1l0 : f1r0;
-            fx = spacing_quotient<POW2, FAST>(s.guard, f0R - f0L + f1R - f1L, a.four_hx, a.inv_four_hx);
+            fx_num = f0R - f0L + f1R - f1L;
         }
         const float f0U = top ? s.f0w[s0] : s.f0w[s2], f0D = bot ? s.f0w[s2] : s.f0w[s0];
         const float f1U = top ? s.f1w[s0] : s.f1w[s2], f1D = bot ? s.f1w[s2] : s.f1w[s0];
-        fy = spacing_quotient<POW2, FAST>(s.guard, f0D - f0U + f1D - f1U, a.four_hy, a.inv_four_hy);
+        {  // the two quotients side by side (the numerators' last operations write whichever registers the pair needs)
+            const v2f fxy = spacing_quotient_pair<POW2, FAST>(s.guard, v2f{fx_num, f0D - f0U + f1D - f1U}, v2f{a.four_hx, a.four_hy},
+                                                              v2f{a.inv_four_hx, a.inv_four_hy});
+            fx = fxy.x, fy = fxy.y;
+        }
         ft = f1c - f0c;
         if (FAST) {
-            ksi = half_inverse_root(ksi_argument(fx, fy, ft, s.duvw[s1].x, s.duvw[s1].y, a.e_data), t_ksi);
+            v2f twice;
+            const v2f roots = half_inverse_root_pair(v2f{phi_arg, ksi_argument_packed(fx, fy, ft, s.duvw[s1], a.e_data)}, twice);
+            s.phiw[s1] = roots.x;
+            ksi = roots.y;
+            t_phi = twice.x, t_ksi = twice.y;
             guard_denominators(s.guard, t_phi, t_ksi);
         } else {
             ksi = ksi_value(fx, fy, ft, s.duvw[s1].x, s.duvw[s1].y, a.e_data);
@@ -524,21 +567,25 @@ __device__ __forceinline__ void strip_step(Strip<INNER, GRAD>& s, const FusedArg
                 fy_u = top ? s.fyw[s1] : s.fyw[s0], fy_d = bot ? s.fyw[s0] : s.fyw[s1];
                 ft_u = top ? s.ftw[s1] : s.ftw[s0], ft_d = bot ? s.ftw[s0] : s.ftw[s1];
             }
-            const float hx_1 = a.hx_1, hy_1 = a.hy_1;  // float(1.0 / (2.0 * h)): double, rounded to float (solve_2d.cu:868-869)
-            const float fxx = (fx_r - fx_l) * hx_1;
-            const float fxy = (fx_d - fx_u) * hy_1;
-            const float fyy = (fy_d - fy_u) * hy_1;
-            const float fxt = (ft_r - ft_l) * hx_1;
-            const float fyt = (ft_d - ft_u) * hy_1;
-            float J11, J22, J13, J23;
-            gradient_tensor(fxx, fxy, fyy, fxt, fyt, J11, J22, c_J12, J13, J23);
-            J11_22 = v2f{J11, J22};
-            c_J13_23 = v2f{J13, J23};
+            // float(1.0 / (2.0 * h)): double, rounded to float (solve_2d.cu:868-869)
+            const v2f hxy_1 = v2f{a.hx_1, a.hy_1};
+            // The second derivatives as pairs -- the selected neighbours land in whichever registers the pairs need -- and
+            // gradient_tensor (solver_math.hpp) on them: A = (fxx, fxy), B = (fxy, fyy), Ft = (fxt, fyt);
+            // (J11, J22) = A A + B B, J12 = A.x B.x + A.y B.y, (J13, J23) = Ft.x A + Ft.y B: the scalar form's products and sums
+            // in its order, 15 instructions instead of 24.
+            const v2f A = (v2f{fx_r, fx_d} - v2f{fx_l, fx_u}) * hxy_1;
+            const v2f Ft = (v2f{ft_r, ft_d} - v2f{ft_l, ft_u}) * hxy_1;
+            const float fyy = (fy_d - fy_u) * a.hy_1;
+            const v2f B = v2f{A.y, fyy};
+            J11_22 = A * A + B * B;
+            const v2f AB = A * B;
+            c_J12 = AB.x + AB.y;
+            c_J13_23 = mul_by_x(Ft, A) + mul_by_y(Ft, B);
         }
         const v2f c_den = c_ksi * J11_22 + sumH;  // update_denominator for u and v
         v2f c_rden = v2f{0.f, 0.f};
         if (FAST) {
-            c_rden = v2f{rcp3(c_den.x), rcp3(c_den.y)};
+            c_rden = rcp3_pair(c_den);
             guard_denominators(s.guard, c_den.x, c_den.y);
         }
         c.den = c_den;
