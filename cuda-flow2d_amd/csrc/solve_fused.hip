@@ -74,9 +74,22 @@ FusedPlan fused_plan(const flow2d_context* ctx, size_t w, size_t h, size_t inner
     for (int k = 1; k <= (int)inner; ++k) saved += 46.0 * std::min(3 + 2 * k, peel);
     const double halo = (double)(2 * (long)inner + 3) - saved / (138.0 + 46.0 * (double)inner);  // the last ring turn is partial
     const long batch = instances;  // the instances of a batched launch share the chip
+    // What a plan costs: the launch's duration on an empty chip (rounds of waves, below) PLUS kWorkWeight x its total work in
+    // rounds of the full chip.  The first term alone gives a small level many short strips -- every wave slot filled, and every
+    // strip paying its 2 inner + 3 start-up rows again -- which is the fastest lone launch, but in a pipeline of lanes the chip
+    // is saturated by the other lanes' launches and the redundant rows are vector instructions somebody waits for.  Weights
+    // 0 / 1 / 2 / 3 on one box (profiles/r04_experiments/plan_work_weight_ab.txt): config 2 3 993-4 103 / 4 107-4 120 / 4 199-4 211 /
+    // 4 220-4 266 pairs/s, rub1-rub2 1 535-1 540 / 1 586-1 591 / 1 622-1 630 / 1 622-1 625, configs 3, 4, 5 unchanged; a lone 1080p
+    // pair 1.10 / 1.09 / 1.11 / 1.14 ms, a lone 1024^2 pair 0.67 / 0.65 / 0.65 / 0.67 ms: two.
+#ifdef FLOW2D_DEV_BUILD
+    static const double bias = std::getenv("FLOW2D_FUSED_PLAN_BIAS") ? std::atof(std::getenv("FLOW2D_FUSED_PLAN_BIAS")) : 2.0;
+#else
+    const double bias = 2.0;
+#endif
     auto rounds = [&](long blocks, double slowest) {
         const long full = blocks / cap, rem = blocks % cap;
-        return full * 2.0 * slowest + (rem == 0 ? 0.0 : (rem <= cus ? 1.3 * slowest : 2.0 * slowest));
+        return full * 2.0 * slowest + (rem == 0 ? 0.0 : (rem <= cus ? 1.3 * slowest : 2.0 * slowest)) +
+               bias * 2.0 * slowest * (double)blocks / (double)cap;
     };
     double best = 1e300;
     FusedPlan plan{1, 1, (int)h, (int)blocks_x, (int)(blocks_x * (long)h)};
