@@ -50,12 +50,14 @@
 //   FLOW2D_FUSED_EDGE_COST=x     border / interior body cost ratio of the strip planner (default 1.22)
 //   FLOW2D_FUSED_NO_SPLIT        a lock-step group's finest level as one launch of several rounds
 //   FLOW2D_FUSED_PLAIN_ORDER     blocks in plain order instead of one contiguous run per XCD
+//   FLOW2D_FUSED_INJECT=k        24 extra instructions of one class per steady-state row step (1 plain, 2 packed, 3 DPP, 4 transcendental, 5 s_nop):
+//                                what an instruction of that class costs in this kernel's own stream (tools/fused_price_list.sh)
 //   FLOW2D_FUSED_NO_PACKED       the face products as plain multiplies (with -Xclang -target-feature -Xclang -packed-fp32-ops: no packed arithmetic at all)
 //   FLOW2D_FUSED_COMPUTE_ONLY, FLOW2D_FUSED_MEMORY_ONLY   timing probes that compute WRONG results
 #if (defined(FLOW2D_FUSED_STAMPS) || defined(FLOW2D_FUSED_COMPUTE_ONLY) || defined(FLOW2D_FUSED_MEMORY_ONLY) ||          \
      defined(FLOW2D_FUSED_TURN_SHIFT) || defined(FLOW2D_FUSED_PLAIN_DIVISION) || defined(FLOW2D_FUSED_NO_PINS) ||          \
      defined(FLOW2D_FUSED_DEV) || defined(FLOW2D_FUSED_EDGE_COST) || defined(FLOW2D_FUSED_NO_SPLIT) ||                    \
-     defined(FLOW2D_FUSED_PLAIN_ORDER) || defined(FLOW2D_FUSED_NO_PACKED)) &&                                                                               \
+     defined(FLOW2D_FUSED_PLAIN_ORDER) || defined(FLOW2D_FUSED_NO_PACKED) || defined(FLOW2D_FUSED_INJECT)) &&                                                                               \
     !defined(FLOW2D_DEV_BUILD)
 #error "the fused kernel's timing probes need -DFLOW2D_DEV_BUILD: they are not part of the product library"
 #endif
@@ -345,10 +347,39 @@ struct Strip {
     // continue_sweeps only: the sweeps' starting increment of row r-2 (start_cur) and the row fetched for the
     // next step (n_start)
     v2f start_cur, n_start;
+#ifdef FLOW2D_FUSED_INJECT
+    v2f inj[4];  // developer probe: registers of the injected instructions
+#endif
     DivGuard guard;  // three-step division: operands outside the proven range leave their mark here
     unsigned long long turn_clock;  // take_turns: the shader clock a step ago, the wave's slot on its SIMD (both wave-uniform)
     unsigned turn_parity;
 };
+
+#ifdef FLOW2D_FUSED_INJECT
+// developer probe: six independent instructions of one class (four registers in rotation, so none waits for its predecessor)
+template <int INNER, int GRAD>
+__device__ __forceinline__ void inject_six(Strip<INNER, GRAD>& s)
+{
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        v2f& d = s.inj[i & 3];
+#if FLOW2D_FUSED_INJECT == 1
+        asm volatile("v_add_f32 %0, %0, %0" : "+v"(d.x));
+#elif FLOW2D_FUSED_INJECT == 2
+        asm volatile("v_pk_add_f32 %0, %0, %0" : "+v"(d));
+#elif FLOW2D_FUSED_INJECT == 3
+        asm volatile("v_mov_b32_dpp %0, %0 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "+v"(d.x));
+#elif FLOW2D_FUSED_INJECT == 4
+        asm volatile("v_rcp_f32 %0, %0" : "+v"(d.x));
+#elif FLOW2D_FUSED_INJECT == 5
+        asm volatile("s_nop 0" : "+v"(d.x));
+#endif
+    }
+}
+#define FLOW2D_INJECT_SIX(s) do { if (T < 0) inject_six(s); } while (0)
+#else
+#define FLOW2D_INJECT_SIX(s) ((void)0)
+#endif
 
 // EDGE = false: the strip touches no image border, so the reflect substitutions (a v_cndmask per
 // neighbour fetch) are compiled out; EDGE = true keeps them.  Chosen per wave (wave-uniform branch).
@@ -502,6 +533,7 @@ __device__ __forceinline__ void strip_step(Strip<INNER, GRAD>& s, const FusedArg
         }
     }
 
+    FLOW2D_INJECT_SIX(s);
     // ---- stage W, row rw = r-2: face weights and the motion tensor -> coefficient ring --------------------
     // phi ring: slot s1 holds row r-1 (just written), s2 row r-2, s0 row r-3
     const int rw = r - 2;
@@ -602,11 +634,13 @@ __device__ __forceinline__ void strip_step(Strip<INNER, GRAD>& s, const FusedArg
     s.p_ft = ft;
     s.p_ksi = ksi;
 
+    FLOW2D_INJECT_SIX(s);
     // ---- sweeps k = 1..INNER, row rk = r-2-k (solve_2d.cu:349-367) ------------------------------------------
     float dv_in = dv_row3;  // dv^0 of row r-3
 #pragma unroll
     for (int k = 1; k <= INNER; ++k) {
         if (T >= 0 && T < 3 + 2 * k) continue;  // start-up: this sweep's row feeds nothing yet
+        if (k == 3 || k == 5) FLOW2D_INJECT_SIX(s);
         const int rk = r - 2 - k;
         // window slots of rows rk-1, rk, rk+1 (rk = r-2-k  ->  slot (J - 2 - k) mod 3)
         const int sc = (J + 3 * 8 - 2 - k) % 3, su = (sc + 2) % 3, sd = (sc + 1) % 3;
@@ -723,6 +757,9 @@ __device__ __forceinline__ bool run_strip(const FusedArgs& a, int x, int xc, boo
         s.C[i] = Coef{};
         s.C[i].den = s.C[i].rden = v2f{1.f, 1.f};
     }
+#ifdef FLOW2D_FUSED_INJECT
+    for (int i = 0; i < 4; ++i) s.inj[i] = v2f{1.f, 1.f};
+#endif
     s.p_fx = s.p_fy = s.p_ft = s.p_ksi = 0.f;
     s.guard = DivGuard{0xffffffffu, 0u, 1.f, 1.f, 0x7fffffff};
     s.turn_parity = turn_parity();
