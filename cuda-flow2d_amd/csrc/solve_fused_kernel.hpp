@@ -895,10 +895,17 @@ __global__ __launch_bounds__(256, 2) void fused_outer_kernel(FusedArgs a)
 #endif
 }
 
-#define FUSED_LAUNCH(N)                                                      \
-    do {                                                                     \
-        fused_outer_kernel<N, GRAD, POW2, CONT><<<grid, 256, 0, stream>>>(a); \
-        return 0;                                                            \
+// (developer builds: FLOW2D_FUSED_LDS_PAD bytes of dynamic LDS per workgroup, unused -- fewer workgroups per CU, for occupancy
+//  experiments on one binary: tools/occupancy_exp.sh)
+#ifdef FLOW2D_DEV_BUILD
+static const unsigned kFusedLdsPad = std::getenv("FLOW2D_FUSED_LDS_PAD") ? static_cast<unsigned>(std::atoi(std::getenv("FLOW2D_FUSED_LDS_PAD"))) : 0u;
+#else
+constexpr unsigned kFusedLdsPad = 0u;
+#endif
+#define FUSED_LAUNCH(N)                                                                 \
+    do {                                                                                \
+        fused_outer_kernel<N, GRAD, POW2, CONT><<<grid, 256, kFusedLdsPad, stream>>>(a); \
+        return 0;                                                                       \
     } while (0)
 
 template <int GRAD, bool POW2, bool CONT>
@@ -907,6 +914,7 @@ int launch_for_inner_cont(int inner, dim3 grid, hipStream_t stream, const FusedA
 #ifdef FLOW2D_FUSED_DEV  // developer builds (A/B timing): only the instantiations of the 4096^2 benchmark, compiled in a minute
     if constexpr (GRAD <= 1 && POW2 && !CONT) {
         if (inner == 5) FUSED_LAUNCH(5);
+        if (inner == 2) FUSED_LAUNCH(2);
     }
     return 1;
 #else
