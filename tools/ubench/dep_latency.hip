@@ -78,6 +78,21 @@ BENCH_KERNEL(k_dpp_1in16, REP4(P15 DP(4, 5)))
 BENCH_KERNEL(k_tr_1in16, REP4(P15 TR(6)))
 BENCH_KERNEL(k_pk_only, REP16(PK(8) PK(9) PK(10) PK(11)))
 BENCH_KERNEL(k_pk_dpp, REP16(PK(8) DP(4, 5) PK(9) DP(5, 4)))
+// lower densities, clumps, and the other instruction kinds of the kernel
+#define P31 P15 PL(3) P15
+#define P63 P31 PL(3) P31
+#define IN3(i) "v_min3_u32 %" #i ", %" #i ", %5, %6\n"
+#define CND(i) "v_cndmask_b32 %" #i ", %5, %6, vcc\n"
+#define LDS(i) "ds_swizzle_b32 %" #i ", %5 offset:0x1f\n"
+BENCH_KERNEL(k_pk_1in32, P31 PK(8) P31 PK(8))
+BENCH_KERNEL(k_pk_1in64, P63 PK(8))
+BENCH_KERNEL(k_clump_48_16, P31 P15 PL(0) PL(1) REP4(PK(8) PK(9) PK(10) PK(11)))
+BENCH_KERNEL(k_min3_1in8, REP8(P7 IN3(4)))
+BENCH_KERNEL(k_cnd_1in8, REP8(P7 CND(4)))
+BENCH_KERNEL(k_lds_1in16, REP4(P15 LDS(4)) "s_waitcnt lgkmcnt(0)\n")
+BENCH_KERNEL(k_fma_only, REP16("v_fma_f32 %0, %0, %12, %13\nv_fma_f32 %1, %1, %12, %13\nv_fma_f32 %2, %2, %12, %13\nv_fma_f32 %3, %3, %12, %13\n"))
+BENCH_KERNEL(k_fma_pk_1in8, REP8("v_fma_f32 %0, %0, %12, %13\nv_fma_f32 %1, %1, %12, %13\nv_fma_f32 %2, %2, %12, %13\nv_fma_f32 %3, %3, %12, %13\n" \
+                                 "v_fma_f32 %0, %0, %12, %13\nv_fma_f32 %1, %1, %12, %13\nv_fma_f32 %2, %2, %12, %13\n" PK(8)))
 
 typedef void (*kern_t)(float*, Stamp*, int);
 
@@ -134,6 +149,14 @@ int main()
         {"15 plain + 1 transcendental", k_tr_1in16},
         {"packed only", k_pk_only},
         {"packed, DPP, packed, DPP ...", k_pk_dpp},
+        {"31 plain + 1 packed", k_pk_1in32},
+        {"63 plain + 1 packed", k_pk_1in64},
+        {"48 plain, then 16 packed", k_clump_48_16},
+        {"7 plain + 1 v_min3_u32", k_min3_1in8},
+        {"7 plain + 1 v_cndmask_b32", k_cnd_1in8},
+        {"15 plain + 1 ds_swizzle_b32 (waited for once per 64)", k_lds_1in16},
+        {"v_fma_f32 only (four chains)", k_fma_only},
+        {"7 v_fma_f32 + 1 packed", k_fma_pk_1in8},
     };
     const int iters = 20000;
     for (int i = 0; i < 100; ++i) k_indep8<<<cus, 512>>>(out, stamps, iters);
