@@ -100,20 +100,36 @@ def synthetic_pair(w, h, dx, dy):
     return img(x, y).astype(np.float32), img(x - dx, y - dy).astype(np.float32)
 
 
-def workload_pair(workload, cfg, k):
+def workload_pair(workload, cfg, k, world=1):
     """Global pair k of a workload: the SURVEY 8(d) synthetic pair, or (cfg1_rub) the reference's sample frames rub1 / rub2
-    (tests/data, 584 x 388 u8 raws widened to float like Data2D::ReadRAWFromFileU8 does)."""
+    (tests/data, 584 x 388 u8 raws widened to float like Data2D::ReadRAWFromFileU8 does; the further pairs a rank keeps in
+    flight are the same frames rolled by j rows and columns, so that every plane set holds data of its own)."""
     if cfg.get("frames") == "rub":
         d = os.path.join(ROOT, "tests", "data")
-        return tuple(np.fromfile(os.path.join(d, n), np.uint8).reshape(cfg["h"], cfg["w"]).astype(np.float32)
-                     for n in ("rub1.raw", "rub2.raw"))
-    return synthetic_pair(cfg["w"], cfg["h"], *pair_shift(workload, cfg, k))
+        j = k // max(world, 1)
+        return tuple(np.roll(np.fromfile(os.path.join(d, n), np.uint8).reshape(cfg["h"], cfg["w"]).astype(np.float32),
+                             (j, 2 * j), axis=(0, 1)) for n in ("rub1.raw", "rub2.raw"))
+    return synthetic_pair(cfg["w"], cfg["h"], *pair_shift(workload, cfg, k, world))
 
 
-def pair_shift(workload, cfg, k):
+def workload_pairs(workload, cfg, ks, world=1):
+    """Several pairs at once, generated side by side (numpy releases the GIL in its transcendental loops)."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    if len(ks) <= 1:
+        return [workload_pair(workload, cfg, k, world) for k in ks]
+    with ThreadPoolExecutor(max_workers=min(8, len(ks))) as pool:
+        return list(pool.map(lambda k: workload_pair(workload, cfg, k, world), ks))
+
+
+def pair_shift(workload, cfg, k, world=1):
+    """Displacement of global pair k.  Config 4: SURVEY 8d's (2 cos k, 2 sin k).  The single-pair workloads keep a rank's
+    first pair (k < world) at the workload's own (dx, dy) -- the pair the CPU oracle checks -- and move the further pairs a
+    rank keeps in flight (k = rank + world * j: plane set j of the rank) by j quarter / eighth pixels more."""
     if workload == BATCH_WORKLOAD:
-        return 2.0 * np.cos(k), 2.0 * np.sin(k)  # SURVEY 8d config 4: pair k moves by (2 cos k, 2 sin k)
-    return cfg["dx"], cfg["dy"]
+        return 2.0 * np.cos(k), 2.0 * np.sin(k)
+    j = k // max(world, 1)
+    return cfg["dx"] + 0.25 * j, cfg["dy"] - 0.125 * j
 
 
 def cpu_baseline(cfg, budget_s=20.0, full_run=None):
@@ -269,8 +285,9 @@ def pmc_passes(args, cfg):
     process touches the GPU, three child processes `rocprofv3 --kernel-trace --pmc <counters> -- python3 bench.py
     --pmc-child ...` (FETCH_SIZE and WRITE_SIZE do not fit one pass: MI355X_MICROARCH.md, rocprofv3 PMC slots; no other
     trace domain is combined with --pmc).  Bytes = FETCH_SIZE x correction + WRITE_SIZE (KiB): on gfx950 FETCH_SIZE tallies
-    128-byte requests as 64 (same guide, HBM section), so the correction is 2; it is re-measured here on the pyramid's own
-    full-resolution add_2d launches, whose traffic is known exactly (4 planes read, 2 written).  Returns {} when
+    128-byte requests as 64 (same guide, HBM section), so the correction is 2; it is re-measured here on the
+    PMC_CALIBRATION_ADDS explicit full-resolution add_2d launches the child makes after its pyramids, whose traffic is
+    known exactly (2 planes read, 1 written; the pyramid itself launches no add_2d since its u += du rides in the median).  Returns {} when
     rocprofv3 is missing or a pass fails (the line then falls back to profiles/traffic.json and says so)."""
     import csv
     import glob
@@ -343,7 +360,8 @@ def pmc_select(collected, cfg, algorithm_used):
 
     add_fetch, _ = extras("FETCH_SIZE", "add_2d_kernel", PMC_CALIBRATION_ADDS)
     add_write, _ = extras("WRITE_SIZE", "add_2d_kernel", PMC_CALIBRATION_ADDS)
-    # small frames live in the caches: the calibration needs planes well beyond the 256 MiB Infinity Cache
+    # small frames live in the caches: the calibration takes planes of 32 MiB and more (three of them per add_2d launch,
+    # re-used launch after launch, then no longer sit in the XCDs' 4 MiB L2s; smaller frames take the guide's x 2)
     calibrate = bool(add_fetch and add_write) and plane >= 32 * 2 ** 20
     corr = 2 * plane / (np.mean(add_fetch) * 1024) if calibrate else 2.0
     wcorr = plane / (np.mean(add_write) * 1024) if calibrate else 1.0
@@ -382,21 +400,26 @@ def per_sweep_block(cfg, sweep_ms, pmc):
     w, h = cfg["w"], cfg["h"]
     algorithmic = 40.0 * w * h  # 8 planes read, 2 written
     phys = (pmc.get("hbm_read_bytes_per_launch") or 0) + (pmc.get("hbm_write_bytes_per_launch") or 0) or None
+    alg_gbs = algorithmic / (sweep_ms * 1e-3) / 1e9
+    phys_gbs = phys / (sweep_ms * 1e-3) / 1e9 if phys else None
     return {
         "kernel": pmc.get("kernel") or {0: "sweep_grey_kernel", 1: "sweep_grad_kernel", 3: "sweep_log_kernel"}.get(cfg["constancy"], "sweep kernel"),
         "bound": "hbm",
         "avg_launch_ms": round(sweep_ms, 5),
         "algorithmic_bytes_per_launch": algorithmic,
+        # achieved / frac: the contract's ALGORITHMIC bytes (40 B per pixel, every plane once) over the launch
+        # time -- what the sweep is worth, whatever the kernel re-reads
+        "achieved": round(alg_gbs, 1),
+        "achieved_is": "algorithmic bytes (40 B per pixel) over the launch time",
+        "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "frac": round(alg_gbs / HBM_PEAK_GBS, 4),
+        # the counters' view of the same launches: FETCH_SIZE x correction + WRITE_SIZE.  Above the algorithmic bytes the
+        # difference is halo rows and lanes that were re-read -- partly from the Infinity Cache, so physical_frac is a
+        # fraction of memory-side traffic, not of HBM throughput
         "traffic": phys,
         "traffic_over_algorithmic": round(phys / algorithmic, 4) if phys else None,
-        "achieved": round((phys or algorithmic) / (sweep_ms * 1e-3) / 1e9, 1),  # physical bytes when the PMC passes have them
-        "achieved_is": "physical (PMC) bytes" if phys else "algorithmic bytes (no PMC figures in this run)",
-        "peak": HBM_PEAK_GBS, "unit": "GB/s",
-        "frac": round((phys or algorithmic) / (sweep_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-        # the contract's ALGORITHMIC bytes (40 B per pixel: every plane once) over the same time: what the sweep is worth,
-        # whatever the kernel re-reads (the streaming form re-reads its strips' halo rows and lanes: traffic_over_algorithmic)
-        "effective_achieved": round(algorithmic / (sweep_ms * 1e-3) / 1e9, 1),
-        "effective_frac": round(algorithmic / (sweep_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+        "physical_achieved": round(phys_gbs, 1) if phys_gbs else None,
+        "physical_frac": round(phys_gbs / HBM_PEAK_GBS, 4) if phys_gbs else None,
         "mpix_sweeps_per_s": round(w * h / (sweep_ms * 1e-3) / 1e6, 1),
     }
 
@@ -451,17 +474,21 @@ class Job:
                                          block[6], int(block[7]), block[8], int(block[9]))
         # this rank's pairs, resident in HBM before any timed region; pair k -> rank k mod world
         self.owned = batch.pairs_of_rank(cfg["pairs_per_rank"] * world, rank, world)
-        frames = [workload_pair(workload, cfg, gk) for gk in self.owned]
+        frames = [workload_pair(workload, cfg, gk, world) for gk in self.owned]
         self.first_pair = frames[0]
         self.touched = set()  # plane sets written since the last poison()
         c, G = self.ctx, self.group
         # entries: (frame 0, frame 1, u, v, [global pair indices]); planes are G containers tall
         self.sets = []
-        if self.step_group > 1:  # per lane: step_group output pairs; the input pair is shared (read only)
-            f0, f1 = c.plane(w, h, frames[0][0]), c.plane(w, h, frames[0][1])
-            for lane in range(self.n_lanes):
-                for _ in range(self.step_group):
-                    self.sets.append((f0, f1, c.plane(w, h), c.plane(w, h), list(self.owned)))
+        if self.step_group > 1:
+            # per lane: step_group plane sets, every one of them a pair of its own (global pair rank + world * j for the
+            # rank's set j; j = 0 is the workload's pair, which the CPU oracle checks) -- n_lanes x step_group DIFFERENT
+            # pairs are in flight, not copies of one
+            ids = [self.owned[0] + world * j for j in range(self.n_lanes * self.step_group)]
+            more = workload_pairs(workload, cfg, ids[1:], world)
+            for j, (a, b) in enumerate([frames[0]] + more):
+                self.sets.append((c.plane(w, h, a), c.plane(w, h, b), c.plane(w, h), c.plane(w, h), [ids[j]]))
+            del more
         elif self.rotate:
             stacked = (np.vstack([f[0] for f in frames]), np.vstack([f[1] for f in frames]))
             for lane in range(self.n_lanes):
@@ -566,7 +593,9 @@ class _Borrowed:
         return importlib.import_module("cuda-flow2d_amd").Plane.fill_bytes(self, value)
 
 
-def timed_region(job, batch, torch, steps, warmup):
+def timed_region(job, batch, torch, steps, warmup, repeats=1):
+    """Warm-up, poison, then `repeats` timed regions of EXACTLY `steps` steps each (barrier + device synchronise on both
+    sides, max over ranks); returns the list of their wall times."""
     def barrier():
         batch.barrier()
         job.sync()
@@ -585,13 +614,16 @@ def timed_region(job, batch, torch, steps, warmup):
     # the flow planes are poisoned between warm-up and the timed region: the digests the output check takes afterwards
     # are of values the K timed steps wrote (a replay that launched nothing would leave 0x7f7f7f7f behind)
     job.poison()
-    barrier()
-    t0 = time.perf_counter()
-    for k in range(steps):
-        job.step(k)
-    job.flush()
-    barrier()
-    return batch.max_over_ranks(time.perf_counter() - t0)
+    times = []
+    for _ in range(max(1, repeats)):
+        barrier()
+        t0 = time.perf_counter()
+        for k in range(steps):
+            job.step(k)
+        job.flush()
+        barrier()
+        times.append(batch.max_over_ranks(time.perf_counter() - t0))
+    return times
 
 
 def output_check(job):
@@ -613,9 +645,10 @@ def output_check(job):
         "graph_replay_equals_eager": bool(replayed == eager),
         "planes_poisoned_before_timed_region": True,
         "plane_sets_written_by_timed_steps": len(touched),
-        "streams_identical": bool(lanes_identical) if job.rotate else None,
+        "streams_identical": bool(lanes_identical) if job.rotate and job.step_group == 1 else None,
+        "distinct_pairs_in_flight": len({gk for (_, gk) in replayed}),
         "fields_hashed": 2 * len(replayed),
-        "sha256_u_v_first_pair": list(replayed[min(replayed)]),
+        "sha256_u_v_first_pair": list(replayed[min(replayed)]) if replayed else None,
     }
 
 
@@ -628,7 +661,7 @@ def host_entry_leg(job, batch, torch, steps):
     reused round-robin).  Timed like the main region: barrier + synchronise on both sides, max over ranks."""
     flow2d, cfg = job.flow2d, job.cfg
     w, h, G = cfg["w"], cfg["h"], cfg["pairs_per_rank"]
-    frames = [workload_pair(job.workload, cfg, gk) for gk in job.owned]
+    frames = [workload_pair(job.workload, cfg, gk, job.world) for gk in job.owned]
     f0s = [flow2d.HostImage(w, h, True, f[0]) for f in frames]
     f1s = [flow2d.HostImage(w, h, True, f[1]) for f in frames]
     N = job.step_group  # steps handed over together (config 2: the batch object forms a lock-step group of them)
@@ -663,7 +696,7 @@ def host_entry_leg(job, batch, torch, steps):
         barrier()
         elapsed = batch.max_over_ranks(time.perf_counter() - t0)
         # every delivered flow image against the device-resident result of the same pair (sha of the timed region's fields)
-        want = {gk: d for (si, gk), d in job.digests().items()}
+        want = {gk: d for (si, gk), d in sorted(job.digests().items(), reverse=True)}  # (a pair on several sets: the first set's)
         same = all((sha(us[i].array), sha(vs[i].array)) == want[gk]
                    for us, vs in outs[:min(n_sets, steps)] for i, gk in enumerate(job.owned))
         pairs = steps * G * job.world
@@ -781,8 +814,10 @@ def batch_leg(flow2d, batch, torch, args, rank, local_rank, world):
     # u planes of the rank's pairs, then their v planes: [2, pairs, H, pitch] (a lock-step group's tall containers)
     local = torch.zeros((2, n_local, h, pitch_floats), dtype=torch.float32, device=torch.device("cuda", local_rank))
     job = Job(flow2d, batch, BATCH_WORKLOAD, cfg, args, rank, local_rank, world, out_tensor=local)
-    steps = max(3, min(args.steps, 20))
-    elapsed = timed_region(job, batch, torch, steps, 1)
+    # at least 64 steps (like the host-entry leg): over 20 steps the fill and drain of the four lanes weigh 12 % (round 4:
+    # 2 092 pairs/s in the driver's line against 2 388 for the same workload at 100 steps)
+    steps = max(64, args.steps)
+    elapsed = timed_region(job, batch, torch, steps, 1)[0]
     check = output_check(job)
     # gather: every rank's [2, 8, H, pitch] block -> [world, 2, 8, H, pitch]; pair k = [k % world, :, k // world].  Two forms,
     # each run once untimed and once timed: to every rank (all_gather) and to rank 0 only (gather: what BASELINE.json asks)
@@ -883,6 +918,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--repeats", type=int, default=5,
+                    help="timed regions of K steps each after the one warm-up; the line reports their median")
     ap.add_argument("--workload", default=DEFAULT_WORKLOAD, choices=sorted(WORKLOADS))
     ap.add_argument("--algorithm", type=int, default=0, help="flow2d_solver_algorithm: 0 auto, 1 per-sweep, 2 fused")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -953,7 +990,10 @@ def main():
         "what": "%d lanes x 14 planes of %d container(s) each, plus the bench's own frame / flow planes (every lane works "
                 "on planes of its own)" % (job.n_lanes, job.group if job.step_group == 1 else job.step_group),
     }
-    elapsed = timed_region(job, batch, torch, args.steps, args.warmup)   # <- the number
+    # <- the number: the timed region of exactly K steps, run `--repeats` times back to back after ONE warm-up; the line
+    # reports the MEDIAN region (ms_per_step, value, pairs_per_s) with the fastest and slowest beside it
+    regions = timed_region(job, batch, torch, args.steps, args.warmup, args.repeats)
+    elapsed = float(np.median(regions))
     check = output_check(job)
     oracle_timing = None
     if rank == 0 and not args.no_oracle_check:
@@ -1056,6 +1096,9 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+            "ms_per_step_min": round(min(regions) / args.steps * 1e3, 4),
+            "ms_per_step_max": round(max(regions) / args.steps * 1e3, 4),
+            "timed_regions": len(regions),  # each of exactly `steps` steps; ms_per_step is their median
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,

@@ -1,8 +1,10 @@
 // Launcher of the fused outer-iteration kernel: strip plan, arguments, dispatch to the instance objects
 // (solve_fused_instance.hip; the kernel itself is solve_fused_kernel.hpp).
 #include <algorithm>
+#include <array>
 #include <cmath>
 #include <cstdlib>
+#include <map>
 
 #include "common.hpp"
 #include "solve_fused_args.hpp"
@@ -62,7 +64,23 @@ static const double kEdgeCost = FLOW2D_FUSED_EDGE_COST;
 static const double kEdgeCost = 1.22;
 #endif
 
+static FusedPlan fused_plan_search(const flow2d_context* ctx, size_t w, size_t h, size_t inner, long instances);
+
+// The plan is a pure function of (w, h, inner, instances, CUs) and its search walks O(h) candidates: memoised per host thread
+// (a thread drives the lanes of one device; eager paths -- no graph, timing modes -- call this before every launch).
 FusedPlan fused_plan(const flow2d_context* ctx, size_t w, size_t h, size_t inner, long instances)
+{
+    thread_local std::map<std::array<long, 5>, FusedPlan> cache;
+    const std::array<long, 5> key{(long)w, (long)h, (long)inner, instances, (long)ctx->num_cus};
+    auto it = cache.find(key);
+    if (it == cache.end()) {
+        if (cache.size() > 4096) cache.clear();
+        it = cache.emplace(key, fused_plan_search(ctx, w, h, inner, instances)).first;
+    }
+    return it->second;
+}
+
+static FusedPlan fused_plan_search(const flow2d_context* ctx, size_t w, size_t h, size_t inner, long instances)
 {
     const int valid = 64 - 2 * ((int)inner + 1);
     const long blocks_x = (div_up(w, valid) + 3) / 4;

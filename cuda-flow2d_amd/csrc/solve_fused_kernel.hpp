@@ -54,7 +54,13 @@
 //                                what an instruction of that class costs in this kernel's own stream (tools/fused_price_list.sh)
 //   FLOW2D_FUSED_NO_PACKED       the face products as plain multiplies (with -Xclang -target-feature -Xclang -packed-fp32-ops: no packed arithmetic at all)
 //   FLOW2D_FUSED_COMPUTE_ONLY, FLOW2D_FUSED_MEMORY_ONLY   timing probes that compute WRONG results
-#if (defined(FLOW2D_FUSED_STAMPS) || defined(FLOW2D_FUSED_COMPUTE_ONLY) || defined(FLOW2D_FUSED_MEMORY_ONLY) ||          \
+//   FLOW2D_FUSED_SHORT_RING=n    timing probe, WRONG results: a coefficient ring of n (3) entries and one input row in flight instead of
+//                                two, so that the five-sweep kernel fits FLOW2D_FUSED_WAVES=3 waves per SIMD (168 registers): what
+//                                would a third wave buy the full kernel's instruction stream?  (tools/occupancy5_exp.sh)
+//   FLOW2D_FUSED_WAVES=n         __launch_bounds__(256, n)
+//   FLOW2D_FUSED_ORDER=1 / 2     stage W (2: and stage P) of a row step after its sweeps instead of before them: the step as two
+//                                chains that do not depend on each other (round 5's A/B for "independent stages")
+#if (defined(FLOW2D_FUSED_STAMPS) || defined(FLOW2D_FUSED_SHORT_RING) || defined(FLOW2D_FUSED_WAVES) || defined(FLOW2D_FUSED_COMPUTE_ONLY) || defined(FLOW2D_FUSED_MEMORY_ONLY) ||          \
      defined(FLOW2D_FUSED_TURN_SHIFT) || defined(FLOW2D_FUSED_PLAIN_DIVISION) || defined(FLOW2D_FUSED_NO_PINS) ||          \
      defined(FLOW2D_FUSED_DEV) || defined(FLOW2D_FUSED_EDGE_COST) || defined(FLOW2D_FUSED_NO_SPLIT) ||                    \
      defined(FLOW2D_FUSED_PLAIN_ORDER) || defined(FLOW2D_FUSED_NO_PACKED) || defined(FLOW2D_FUSED_INJECT)) &&                                                                               \
@@ -107,6 +113,11 @@ __device__ __forceinline__ float from_right(float v)
 // (profiles/r04_experiments/README.md).
 #ifndef FLOW2D_FUSED_TURN_SHIFT
 #define FLOW2D_FUSED_TURN_SHIFT (-1)
+#endif
+#ifndef FLOW2D_FUSED_ORDER
+#define FLOW2D_FUSED_ORDER 0
+#elif !defined(FLOW2D_DEV_BUILD)
+#error "FLOW2D_FUSED_ORDER is a developer experiment (-DFLOW2D_DEV_BUILD)"
 #endif
 constexpr int kTurnShift = FLOW2D_FUSED_TURN_SHIFT;  // < 0: never
 // the wave's slot on its SIMD (0 or 1 with two waves per SIMD)
@@ -326,7 +337,11 @@ template <int INNER, int GRAD>
 struct Strip {
     static constexpr int kHalo = INNER + 1;
     static constexpr int kValid = 64 - 2 * kHalo;
+#ifdef FLOW2D_FUSED_SHORT_RING
+    static constexpr int kRing = FLOW2D_FUSED_SHORT_RING;  // developer probe (timing only): the sweeps read other rows' coefficients
+#else
     static constexpr int kRing = ((INNER + 1 + 2) / 3) * 3;  // coefficient ring, a multiple of the 3-row windows
+#endif
 
     // 3-row sliding windows, slot = row mod 3; (u, v) and (du, dv) travel as pairs
     float f0w[3], f1w[3];
@@ -423,17 +438,26 @@ __device__ __forceinline__ void strip_step(Strip<INNER, GRAD>& s, const FusedArg
         s.lf1w[s0] = log1p_frame(s.n_f1);
     }
     {  // row r+1 arrived a step ago; fetch row r+2 (clamped: rows outside the image are never used by a stored pixel)
+#ifndef FLOW2D_FUSED_SHORT_RING
         s.n_f0 = s.m_f0, s.n_f1 = s.m_f1, s.n_uv = s.m_uv, s.n_duv = s.m_duv;
+#endif
 #ifdef FLOW2D_FUSED_COMPUTE_ONLY  // developer probe (timing only, wrong results): every row folded onto eight cache-resident rows
         const int rn = (r + 2) & 7;
 #else
         const int rn = min(max(r + 2, 0), h - 1);
 #endif
         const unsigned off = (static_cast<unsigned>(rn) * static_cast<unsigned>(a.pitch) + static_cast<unsigned>(xc)) * 4u;
+#ifdef FLOW2D_FUSED_SHORT_RING  // (probe: one row in flight)
+        s.n_f0 = plane_load(a.f0, off);
+        s.n_f1 = plane_load(a.f1, off);
+        s.n_uv = v2f{plane_load(a.u, off), plane_load(a.v, off)};
+        s.n_duv = a.zero_increment ? v2f{0.f, 0.f} : v2f{plane_load(a.du, off), plane_load(a.dv, off)};
+#else
         s.m_f0 = plane_load(a.f0, off);
         s.m_f1 = plane_load(a.f1, off);
         s.m_uv = v2f{plane_load(a.u, off), plane_load(a.v, off)};
         s.m_duv = a.zero_increment ? v2f{0.f, 0.f} : v2f{plane_load(a.du, off), plane_load(a.dv, off)};
+#endif
     }
 
 #ifdef FLOW2D_FUSED_MEMORY_ONLY  // developer probe (timing only, wrong results): the strip's loads and stores without its arithmetic
@@ -454,6 +478,7 @@ __device__ __forceinline__ void strip_step(Strip<INNER, GRAD>& s, const FusedArg
     // ---- stage P, row rp = r-1: phi, brightness derivatives, ksi (solve_2d.cu:138-197) -------------------
     const int rp = r - 1;
     float fx = 0.f, fy = 0.f, ft = 0.f, ksi = 0.f;
+    auto stage_P = [&]() {
     if (run_P) {
         const bool top = EDGE && (rp == 0), bot = EDGE && (rp == h - 1);
         v2f xnum, ynum;  // numerators of (dux, dvx) and (duy, dvy): aP - aM + bP - bM, solve_2d.cu:141-157
@@ -532,11 +557,19 @@ __device__ __forceinline__ void strip_step(Strip<INNER, GRAD>& s, const FusedArg
             s.ftw[s1] = ft;
         }
     }
+    };
+#if FLOW2D_FUSED_ORDER != 2
+    stage_P();
+#endif
 
     FLOW2D_INJECT_SIX(s);
     // ---- stage W, row rw = r-2: face weights and the motion tensor -> coefficient ring --------------------
     // phi ring: slot s1 holds row r-1 (just written), s2 row r-2, s0 row r-3
     const int rw = r - 2;
+    // (developer builds, -DFLOW2D_FUSED_ORDER=1 / 2: the coefficients of row r-2 are first read by sweep 1 in the NEXT step and
+    //  nothing in this step but stage P feeds them, so stage W can also run after the sweeps -- two chains that do not depend
+    //  on each other within a step, {P, W} and {sweep 1 .. sweep INNER}; 2: stage P after the sweeps as well)
+    auto stage_W = [&]() {
     if (run_W) {
         constexpr int cw = (J + 2 * kRing - 2) % kRing;
         Coef& c = s.C[cw];
@@ -625,14 +658,18 @@ __device__ __forceinline__ void strip_step(Strip<INNER, GRAD>& s, const FusedArg
         c.J13_23 = c_J13_23;
         c.ksi = c_ksi;
         c.J12 = c_J12;
-        // (u + du, v + dv) of row r-2 enters sweep 1's window
-        s.UV[0][s2] = s.uvw[s2] + (cont ? s.start_cur : s.duvw[s2]);
     }
+    };
+    // (u + du, v + dv) of row r-2 enters sweep 1's window
+    if (run_W) s.UV[0][s2] = s.uvw[s2] + (cont ? s.start_cur : s.duvw[s2]);
+#if FLOW2D_FUSED_ORDER == 0
+    stage_W();
     // stage P's outputs of this step are what stage W consumes in the next one
     s.p_fx = fx;
     s.p_fy = fy;
     s.p_ft = ft;
     s.p_ksi = ksi;
+#endif
 
     FLOW2D_INJECT_SIX(s);
     // ---- sweeps k = 1..INNER, row rk = r-2-k (solve_2d.cu:349-367) ------------------------------------------
@@ -693,6 +730,16 @@ __device__ __forceinline__ void strip_step(Strip<INNER, GRAD>& s, const FusedArg
             plane_store(a.out_dv, off, dv_new);
         }
     }
+#if FLOW2D_FUSED_ORDER != 0
+#if FLOW2D_FUSED_ORDER == 2
+    stage_P();
+#endif
+    stage_W();
+    s.p_fx = fx;
+    s.p_fy = fy;
+    s.p_ft = ft;
+    s.p_ksi = ksi;
+#endif
     if (T < 0 && kTurnShift >= 0) s.turn_clock = __builtin_amdgcn_s_memtime();
 }
 
@@ -809,8 +856,11 @@ constexpr bool kThreeStepDivision = false;
 constexpr bool kThreeStepDivision = true;
 #endif
 
+#ifndef FLOW2D_FUSED_WAVES
+#define FLOW2D_FUSED_WAVES 2
+#endif
 template <int INNER, int GRAD, bool POW2, bool CONT>
-__global__ __launch_bounds__(256, 2) void fused_outer_kernel(FusedArgs a)
+__global__ __launch_bounds__(256, FLOW2D_FUSED_WAVES) void fused_outer_kernel(FusedArgs a)
 {
     using S = Strip<INNER, GRAD>;
     const int lane = threadIdx.x & 63;

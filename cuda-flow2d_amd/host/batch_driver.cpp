@@ -2,11 +2,17 @@
 #include "batch_driver.h"
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
+#include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
+#include <thread>
+
+#include <unistd.h>
 
 std::vector<size_t> PairsOfRank(size_t total, int world, int rank)
 {
@@ -48,7 +54,7 @@ uint64_t Fnv1a(const void* data, size_t bytes, uint64_t h)
 
 const char* BatchUsage()
 {
-    return "[--gpus N | --rank R --world N --id-file PATH [--device D]] [--pairs K] [--width W] [--height H]\n"
+    return "[--gpus N | --rank R --world N --id-file PATH [--run-id NONCE] [--device D]] [--pairs K] [--width W] [--height H]\n"
            "       [--lanes L] [--group G] [--repeat R] [--levels n] [--scale s] [--outer n] [--inner n] [--alpha a] [--median m]\n"
            "       [--sigma s] [--e-smooth e] [--e-data e] [--constancy c] [--pairs-dir DIR] [--out-dir DIR] [--print-layout]\n";
 }
@@ -84,12 +90,13 @@ bool ParseBatchArgs(int argc, char** argv, BatchOptions& o, int (*extra)(int, ch
         else if (a == "--e-data") ok = value(o.p.e_data);
         else if (a == "--median") ok = value(o.p.median);
         else if (a == "--sigma") ok = value(o.p.sigma);
-        else if (a == "--constancy") ok = value(o.p.constancy);  // enum class DataConstancy: 0 Grey, 1 Gradient, 2 LogDerivatives
+        else if (a == "--constancy") ok = value(o.p.constancy);  // enum class DataConstancy: 0 Grey, 1 Gradient, 2 LogDerivatives, 3 GradientUntiled
         else if (a == "--gpus") { ok = value(d); o.gpus = static_cast<int>(d); }
         else if (a == "--rank") { ok = value(d); o.rank = static_cast<int>(d); }
         else if (a == "--world") { ok = value(d); o.world = static_cast<int>(d); }
         else if (a == "--device") { ok = value(d); o.device = static_cast<int>(d); }
         else if (a == "--id-file") ok = text(o.id_file);
+        else if (a == "--run-id") ok = text(o.run_id);
         else if (a == "--pairs-dir") ok = text(o.pairs_dir);
         else if (a == "--out-dir") ok = text(o.out_dir);
         else if (a == "--print-layout") o.print_layout = true;
@@ -104,6 +111,150 @@ bool ParseBatchArgs(int argc, char** argv, BatchOptions& o, int (*extra)(int, ch
         }
     }
     return true;
+}
+
+// ---- the side channel ---------------------------------------------------------------------------------------------------
+struct ThreadRendezvous::State {
+    int world;
+    double timeout;
+    std::mutex mutex;
+    std::condition_variable cv;
+    int arrived = 0;
+    bool all = true, result = false;
+    unsigned long long round = 0;
+    std::atomic<bool> raised{false};
+};
+
+ThreadRendezvous::ThreadRendezvous(int world, double timeout_seconds) : state_(new State)
+{
+    state_->world = world;
+    state_->timeout = timeout_seconds;
+}
+ThreadRendezvous::~ThreadRendezvous() { delete state_; }
+
+bool ThreadRendezvous::AllOk(int /*stage*/, bool ok)
+{
+    State& s = *state_;
+    std::unique_lock<std::mutex> lock(s.mutex);
+    s.all = s.all && ok;
+    const unsigned long long round = s.round;
+    if (++s.arrived == s.world) {
+        s.result = s.all;
+        s.arrived = 0;
+        s.all = true;
+        ++s.round;
+        s.cv.notify_all();
+        return s.result && !s.raised.load();
+    }
+    const auto deadline = std::chrono::steady_clock::now() + std::chrono::duration<double>(s.timeout);
+    while (s.round == round) {
+        if (s.raised.load() || std::chrono::steady_clock::now() >= deadline) {
+            // a rank that never arrives, or one that left outside an agreement: nobody may count this or a later round as agreed
+            s.raised.store(true);
+            s.cv.notify_all();
+            return false;
+        }
+        // (a system_clock deadline: pthread_cond_timedwait, which ThreadSanitizer knows; wait_for goes through pthread_cond_clockwait)
+        s.cv.wait_until(lock, std::chrono::system_clock::now() + std::chrono::milliseconds(5));
+    }
+    return s.result && !s.raised.load();
+}
+void ThreadRendezvous::Raise()
+{
+    state_->raised.store(true);
+    state_->cv.notify_all();
+}
+bool ThreadRendezvous::Raised() const { return state_->raised.load(); }
+
+FileRendezvous::FileRendezvous(const std::string& prefix, const std::string& run_id, int rank, int world, double timeout_seconds)
+    : prefix_(prefix), run_id_(run_id.empty() ? "0" : run_id), rank_(rank), world_(world), timeout_(timeout_seconds)
+{
+}
+FileRendezvous::~FileRendezvous()
+{
+    // after a failed agreement or a raised flag the files stay: a slower rank must still be able to read them (they carry the
+    // run id, so a later run ignores them; tools/run_batch8.sh works in a directory of its own and removes it)
+    if (!failed_)
+        for (const std::string& f : written_) std::remove(f.c_str());
+}
+
+namespace {
+bool WriteWhole(const std::string& path, const std::string& text)
+{
+    const std::string tmp = path + ".tmp";
+    std::FILE* f = std::fopen(tmp.c_str(), "wb");
+    if (!f) return false;
+    const bool ok = std::fwrite(text.data(), 1, text.size(), f) == text.size();
+    return std::fclose(f) == 0 && ok && std::rename(tmp.c_str(), path.c_str()) == 0;
+}
+// "<run id> <0|1>": 1 / 0, or -1 for a missing, foreign or unfinished file
+int ReadPost(const std::string& path, const std::string& run_id)
+{
+    std::FILE* f = std::fopen(path.c_str(), "rb");
+    if (!f) return -1;
+    char buffer[256] = {0};
+    const size_t n = std::fread(buffer, 1, sizeof(buffer) - 1, f);
+    std::fclose(f);
+    const std::string text(buffer, n);
+    if (text == run_id + " 1") return 1;
+    if (text == run_id + " 0") return 0;
+    return -1;
+}
+}  // namespace
+
+bool FileRendezvous::AllOk(int stage, bool ok)
+{
+    auto name = [&](int r) { return prefix_ + ".s" + std::to_string(stage) + ".r" + std::to_string(r); };
+    const std::string mine = name(rank_);
+    if (!WriteWhole(mine, run_id_ + (ok ? " 1" : " 0"))) {
+        Raise();
+        return false;
+    }
+    written_.push_back(mine);
+    if (!ok) failed_ = true;
+    const auto deadline = std::chrono::steady_clock::now() + std::chrono::duration<double>(timeout_);
+    bool all = ok;
+    for (int r = 0; r < world_; ++r) {
+        if (r == rank_) continue;
+        int post = -1;
+        while ((post = ReadPost(name(r), run_id_)) < 0) {
+            if (Raised() || std::chrono::steady_clock::now() >= deadline) {
+                Raise();
+                return false;
+            }
+            usleep(2000);
+        }
+        all = all && post == 1;
+    }
+    all = all && !Raised();
+    if (!all) failed_ = true;
+    return all;
+}
+void FileRendezvous::Raise()
+{
+    failed_ = true;
+    const std::string flag = prefix_ + ".abort." + run_id_;
+    if (WriteWhole(flag, run_id_)) written_.push_back(flag);
+}
+bool FileRendezvous::Raised() const { return access((prefix_ + ".abort." + run_id_).c_str(), F_OK) == 0; }
+
+int StartBatchRank(const BatchOptions& options, RankRendezvous& rendezvous, CommConnector& connector, BatchDevice& device)
+{
+    // (a) local prerequisites, agreed on before anybody enters the communicator's own rendezvous
+    const bool prepared = connector.Prepare();
+    if (!rendezvous.AllOk(0, prepared)) {
+        std::fprintf(stderr, "flow2d_batch: %s before the communicator was set up; no rank enters it\n",
+                     prepared ? "another rank failed" : "this rank failed");
+        return 1;
+    }
+    // (b) the communicator; a rank that is connected while a peer is not must not use what it has
+    const bool connected = connector.Connect();
+    if (!rendezvous.AllOk(1, connected)) {
+        std::fprintf(stderr, "flow2d_batch: the communicator did not come up on %s\n", connected ? "another rank" : "this rank");
+        if (connected) connector.Abort();
+        return 1;
+    }
+    return RunBatchRank(options, connector.Comm(), device);
 }
 
 namespace {
@@ -152,15 +303,19 @@ int RunBatchRank(const BatchOptions& opt, BatchComm& comm, BatchDevice& device)
     mem.dev_block = device.Alloc(sizeof(block));
     if (!mem.dev_block || !device.Upload(mem.dev_block, &block, sizeof(block))) status = 1;
     if (int all = agree(status)) return all;
+    // a broadcast (or the download behind it) that fails HERE after the rank took part is a local failure: the peers are
+    // on their way into the next agreement, and so is this rank (a collective this rank never entered is the back end's
+    // business: it raises the side channel's flag, and the agreement below fails on every rank)
     if (!comm.Broadcast(mem.dev_block, sizeof(block), 0) || !device.Download(&block, mem.dev_block, sizeof(block))) {
         std::fprintf(stderr, "flow2d_batch: rank %d: the parameter broadcast failed\n", rank);
-        return 1;
+        status = 1;
     }
+    if (int all = agree(status)) return all;
     // every rank judges the same block, so they all leave together (3: the code of a bad command line)
     auto whole = [](double v, double low, double high) { return v >= low && v <= high && v == std::floor(v); };
     if (!whole(block.width, 1, 1 << 20) || !whole(block.height, 1, 1 << 20) || !whole(block.pairs_total, 0, 1e9) ||
         !whole(block.lanes, 1, 64) || !whole(block.group, 1, 1e9) || !whole(block.repeat, 1, 1e9) || !whole(block.levels, 1, 64) ||
-        !whole(block.outer, 1, 1e6) || !whole(block.inner, 1, 1e6) || !whole(block.median, 0, 64) || !whole(block.constancy, 0, 2) ||
+        !whole(block.outer, 1, 1e6) || !whole(block.inner, 1, 1e6) || !whole(block.median, 0, 64) || !whole(block.constancy, 0, 3) ||
         !(block.scale > 0.0 && block.scale < 1.0)) {
         if (rank == 0) std::fprintf(stderr, "flow2d_batch: parameters out of range\nusage: flow2d_batch %s", BatchUsage());
         return 3;
@@ -261,8 +416,13 @@ int RunBatchRank(const BatchOptions& opt, BatchComm& comm, BatchDevice& device)
     for (size_t r = 0; r < repeat && status == 0; ++r)
         if (!queue_pass(r)) status = 1;
     if (!device.Synchronize()) status = std::max(status, 1);
+    // the rank's own time, taken before the closing agreement (whose all-reduce is not part of the passes); the job's time
+    // is the slowest rank's: a second one-word all-reduce (maximum) of the microseconds
+    const double own_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     if (int all = agree(status)) return all;
-    const double seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    int micros = static_cast<int>(std::min(own_seconds * 1e6, 2.0e9));
+    if (!comm.AllReduceMax(&micros)) status = 1;
+    const double seconds = std::max(1e-6, micros * 1e-6);
     const char* result_block = static_cast<char*>(mem.flows) + ((repeat - 1) % sets) * set_stride;  // the last pass's flows
 
     // ---- 5. gather: every rank's block of flow fields to rank 0 ----------------------------------------------------------------
@@ -272,14 +432,15 @@ int RunBatchRank(const BatchOptions& opt, BatchComm& comm, BatchDevice& device)
     }
     if (int all = agree(status)) return all;
     const auto g0 = std::chrono::steady_clock::now();
-    if (!comm.GatherToRoot(result_block, mem.gathered, block_bytes)) {
+    if (!comm.GatherToRoot(result_block, mem.gathered, block_bytes)) {  // (a local failure: on to the closing agreement)
         std::fprintf(stderr, "flow2d_batch: rank %d: the gather failed\n", rank);
-        return 1;
+        status = 1;
     }
+    if (int all = agree(status)) return all;  // before rank 0 writes files or prints: a failed job leaves no result line
     const double gather_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - g0).count();
 
     // ---- 6. rank 0: files and the JSON line -----------------------------------------------------------------------------------
-    if (rank == 0) {
+    if (rank == 0 && status == 0) {
         uint64_t digest = 1469598103934665603ull;
         Data2D u(width, height), v(width, height);
         for (size_t k = 0; k < total && status != 1; ++k) {

@@ -17,7 +17,20 @@
 // An "agreement" is a one-word all-reduce (maximum) of the ranks' status codes: it is the barrier of the timed region,
 // and it is how a rank that failed locally takes the others down with it instead of leaving them blocked in the next
 // collective -- every rank keeps joining the collectives until an agreement tells all of them to stop, and all of them
-// return the same non-zero code (the largest: 1 device / run, 2 frame not loadable, 255 output not writable).
+// return the same non-zero code (the largest: 1 device / run, 2 frame not loadable, 255 output not writable).  A
+// collective that fails on a rank AFTER it took part (the broadcast, the gather) is a local failure like any other: the
+// rank goes on to the next agreement with code 1.
+//
+// Bringing the communicator up (StartBatchRank) cannot use the communicator, so it goes through a SIDE CHANNEL the ranks
+// share without it (RankRendezvous: memory for ranks that are threads, small files for ranks that are processes):
+//   a. every rank's local prerequisites (device selected, stream, buffers)      -> side-channel agreement
+//   b. the communicator's own rendezvous (ncclCommInitRank), entered only when (a) succeeded everywhere
+//                                                                              -> side-channel agreement; a rank that
+//      connected while another did not aborts its communicator instead of using it
+// The side channel also carries one flag any rank can RAISE when it has to leave outside an agreement (a collective that
+// failed before the rank took part, a torn communicator): the back ends' waits poll it, so the peers of such a rank
+// leave their blocked collective within milliseconds (ncclCommAbort) instead of waiting for ever.  Every rank then
+// returns 1.
 #pragma once
 
 #include <cstddef>
@@ -43,6 +56,60 @@ public:
     // every rank's `block_bytes` at `send` to rank 0's `recv + rank * block_bytes` (rank 0's own block too);
     // `recv` is only looked at on rank 0
     virtual bool GatherToRoot(const void* send, void* recv, size_t block_bytes) = 0;
+};
+
+// ---- the side channel: agreements and the abort flag that do not need the communicator --------------------------------
+class RankRendezvous {
+public:
+    virtual ~RankRendezvous() {}
+    // Every rank posts `ok` for `stage` (0, 1, ...: in the same order on every rank); true only when ALL ranks posted true.
+    // A rank that never arrives, or a raised flag, makes the others give up (false) instead of waiting for ever.
+    virtual bool AllOk(int stage, bool ok) = 0;
+    virtual void Raise() = 0;         // "I am leaving outside an agreement": sticky, seen by every rank
+    virtual bool Raised() const = 0;  // cheap enough to poll every millisecond
+};
+
+// ranks = threads of one process: ONE object shared by all of them
+class ThreadRendezvous : public RankRendezvous {
+public:
+    explicit ThreadRendezvous(int world, double timeout_seconds = 120.0);
+    ~ThreadRendezvous() override;
+    bool AllOk(int stage, bool ok) override;
+    void Raise() override;
+    bool Raised() const override;
+
+private:
+    struct State;
+    State* state_;
+};
+
+// ranks = processes that share a directory: rank r posts stage s as the file <prefix>.s<s>.r<r> holding "<run id> <0|1>",
+// the flag is the file <prefix>.abort.<run id>.  A stale file of an earlier run carries another run id and is ignored;
+// every rank removes what it wrote when it is destroyed.
+class FileRendezvous : public RankRendezvous {
+public:
+    FileRendezvous(const std::string& prefix, const std::string& run_id, int rank, int world, double timeout_seconds = 120.0);
+    ~FileRendezvous() override;
+    bool AllOk(int stage, bool ok) override;
+    void Raise() override;
+    bool Raised() const override;
+
+private:
+    std::string prefix_, run_id_;
+    int rank_, world_;
+    double timeout_;
+    bool failed_ = false;
+    std::vector<std::string> written_;
+};
+
+// ---- bringing a rank's communicator up ---------------------------------------------------------------------------------
+class CommConnector {
+public:
+    virtual ~CommConnector() {}
+    virtual bool Prepare() = 0;  // local prerequisites of the communicator; no rendezvous inside
+    virtual bool Connect() = 0;  // the communicator's own rendezvous; entered only when every rank is prepared
+    virtual void Abort() = 0;    // a peer did not connect: tear down what Connect built, without a collective
+    virtual BatchComm& Comm() = 0;
 };
 
 // ---- memory and computation of one rank --------------------------------------------------------------------------------
@@ -77,7 +144,7 @@ struct BatchParameterBlock {  // what rank 0 broadcasts: plain numbers only
 struct BatchOptions {
     BatchParameterBlock p{1920, 1080, 8, 4, 8, 1, 8, 0.5, 10, 5, 35.0, 0.001, 0.001, 5, 1.5, 0};
     int gpus = 1, rank = -1, world = 1, device = -1;
-    std::string id_file, pairs_dir, out_dir;
+    std::string id_file, run_id, pairs_dir, out_dir;
     bool print_layout = false;  // rank 0 adds the pair -> (rank, slot, byte offset) table to its JSON line
 };
 
@@ -101,3 +168,5 @@ uint64_t Fnv1a(const void* data, size_t bytes, uint64_t h = 1469598103934665603u
 
 // One rank of the job.  Returns the job's exit code -- the same on every rank: 0, or the largest local failure code.
 int RunBatchRank(const BatchOptions& options, BatchComm& comm, BatchDevice& device);
+// The same with the communicator still to be brought up: steps (a) and (b) above, then RunBatchRank.
+int StartBatchRank(const BatchOptions& options, RankRendezvous& rendezvous, CommConnector& connector, BatchDevice& device);

@@ -13,8 +13,10 @@
 // rank's block of flow fields to rank 0.  No data-path collective: the pairs are independent.
 //
 // Ranks: `--gpus N` starts N ranks as threads of this process, rank r on device r (ncclCommInitRank with an id shared in
-// memory); `--rank R --world N --id-file PATH [--device D]` is one rank of N separate processes (rank 0 writes the
-// ncclUniqueId to PATH, the others wait for it).
+// memory); `--rank R --world N --id-file PATH [--run-id NONCE] [--device D]` is one rank of N separate processes (rank 0
+// writes run id + ncclUniqueId to PATH, the others wait for a file with their run id; tools/run_batch8.sh starts them).
+// Either way the communicator comes up under a side channel's agreements and every wait watches its flag
+// (batch_driver.h, StartBatchRank): a rank that fails before, inside or after ncclCommInitRank takes the others out with it.
 //
 // Pairs: `--pairs-dir DIR` reads DIR/pair_%04d_0.raw and _1.raw (tight little-endian float32, the reference's raw format,
 // src/data_types/data2d.cpp:140-178); without it the SURVEY 8(d) synthetic pair k (shift (2 cos k, 2 sin k)) is generated.
@@ -55,38 +57,51 @@ bool NcclOk(ncclResult_t e, const char* what)
 #define NCCL_OK(expr) NcclOk((expr), #expr)
 
 // ---- BatchComm over librccl ------------------------------------------------------------------------------------------
-class RcclComm : public BatchComm {
+// Also the CommConnector that brings it up under the side channel's agreements (batch_driver.h): Prepare() makes everything
+// that can fail locally -- stream, the all-reduce word -- BEFORE anybody enters ncclCommInitRank, so a rank that fails there
+// keeps the others out of it.  Every wait polls the side channel's flag: when a peer has left outside an agreement, or the
+// communicator reports an asynchronous error, the rank aborts the communicator (ncclCommAbort needs no peer) and returns
+// false instead of sitting in hipStreamSynchronize for ever.
+class RcclComm : public BatchComm, public CommConnector {
 public:
-    RcclComm() = default;
+    RcclComm(int rank, int world, int device, const ncclUniqueId& id, RankRendezvous& side)
+        : rank_(rank), world_(world), device_(device), id_(id), side_(side)
+    {
+    }
     ~RcclComm() override
     {
         if (word_) (void)hipFree(word_);
         if (stream_) (void)hipStreamDestroy(stream_);
         if (comm_) ncclCommDestroy(comm_);
     }
-    // the calling thread's current device is the rank's device
-    bool Init(int rank, int world, const ncclUniqueId& id)
+    bool Prepare() override
     {
-        rank_ = rank, world_ = world;
-        return NCCL_OK(ncclCommInitRank(&comm_, world, id, rank)) && HIP_OK(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking)) &&
+        return HIP_OK(hipSetDevice(device_)) && HIP_OK(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking)) &&
                HIP_OK(hipMalloc(reinterpret_cast<void**>(&word_), sizeof(int)));
     }
+    bool Connect() override { return NCCL_OK(ncclCommInitRank(&comm_, world_, id_, rank_)); }
+    void Abort() override
+    {
+        if (comm_) (void)ncclCommAbort(comm_);
+        comm_ = nullptr;
+    }
+    BatchComm& Comm() override { return *this; }
     int Rank() const override { return rank_; }
     int World() const override { return world_; }
     bool Broadcast(void* buffer, size_t bytes, int root) override
     {
-        return NCCL_OK(ncclBroadcast(buffer, buffer, bytes, ncclUint8, root, comm_, stream_)) && HIP_OK(hipStreamSynchronize(stream_));
+        return Usable() && Check(NCCL_OK(ncclBroadcast(buffer, buffer, bytes, ncclUint8, root, comm_, stream_))) && Wait();
     }
     bool AllReduceMax(int* value) override
     {
-        return HIP_OK(hipMemcpyAsync(word_, value, sizeof(int), hipMemcpyHostToDevice, stream_)) &&
-               NCCL_OK(ncclAllReduce(word_, word_, 1, ncclInt32, ncclMax, comm_, stream_)) &&
-               HIP_OK(hipMemcpyAsync(value, word_, sizeof(int), hipMemcpyDeviceToHost, stream_)) &&
-               HIP_OK(hipStreamSynchronize(stream_));
+        return Usable() && Check(HIP_OK(hipMemcpyAsync(word_, value, sizeof(int), hipMemcpyHostToDevice, stream_)) &&
+                                 NCCL_OK(ncclAllReduce(word_, word_, 1, ncclInt32, ncclMax, comm_, stream_)) &&
+                                 HIP_OK(hipMemcpyAsync(value, word_, sizeof(int), hipMemcpyDeviceToHost, stream_))) &&
+               Wait();
     }
     bool GatherToRoot(const void* send, void* recv, size_t block_bytes) override
     {
-        if (!NCCL_OK(ncclGroupStart())) return false;
+        if (!Usable() || !Check(NCCL_OK(ncclGroupStart()))) return false;
         bool ok = true;
         if (rank_ == 0) {
             for (int r = 1; r < world_ && ok; ++r)
@@ -98,11 +113,50 @@ public:
         }
         ok = NCCL_OK(ncclGroupEnd()) && ok;
         if (ok && rank_ == 0 && block_bytes) ok = HIP_OK(hipMemcpyAsync(recv, send, block_bytes, hipMemcpyDeviceToDevice, stream_));
-        return HIP_OK(hipStreamSynchronize(stream_)) && ok;
+        return Check(ok) && Wait();
     }
 
 private:
-    int rank_ = 0, world_ = 1;
+    bool Usable()
+    {
+        if (comm_ && !side_.Raised()) return true;
+        Abort();
+        return false;
+    }
+    // a collective this rank could not even enqueue: the peers are (or will be) blocked in theirs -- tell them
+    bool Check(bool enqueued)
+    {
+        if (!enqueued) {
+            side_.Raise();
+            Abort();
+        }
+        return enqueued;
+    }
+    // the stream's work, with an eye on the side channel and on the communicator's asynchronous errors
+    bool Wait()
+    {
+        for (unsigned spins = 0;; ++spins) {
+            const hipError_t e = hipStreamQuery(stream_);
+            if (e == hipSuccess) return true;
+            ncclResult_t async = ncclSuccess;
+            const bool broken = e != hipErrorNotReady || ncclCommGetAsyncError(comm_, &async) != ncclSuccess || async != ncclSuccess;
+            if (broken || ((spins & 63u) == 63u && side_.Raised())) {
+                if (broken) {
+                    std::fprintf(stderr, "flow2d_batch: rank %d: the communicator failed while a collective was in flight\n", rank_);
+                    side_.Raise();
+                } else {
+                    std::fprintf(stderr, "flow2d_batch: rank %d: another rank left; aborting the collective in flight\n", rank_);
+                }
+                Abort();
+                return false;
+            }
+            if (spins > 2000) usleep(50);  // (the first microseconds busy: the all-reduce is the barrier of the timed passes)
+        }
+    }
+
+    int rank_, world_, device_;
+    ncclUniqueId id_;
+    RankRendezvous& side_;
     ncclComm_t comm_ = nullptr;
     hipStream_t stream_ = nullptr;
     int* word_ = nullptr;
@@ -192,13 +246,12 @@ private:
     flow2d_context* context_ = nullptr;
 };
 
-int RankMain(const BatchOptions& opt, int rank, int world, int device, const ncclUniqueId& id)
+int RankMain(const BatchOptions& opt, int rank, int world, int device, const ncclUniqueId& id, RankRendezvous& side)
 {
-    if (!HIP_OK(hipSetDevice(device))) return 1;
-    RcclComm comm;
-    if (!comm.Init(rank, world, id)) return 1;
+    (void)hipSetDevice(device);  // (checked in RcclComm::Prepare, under the side channel's agreement)
+    RcclComm comm(rank, world, device, id, side);
     HipBatchDevice dev(device);
-    return RunBatchRank(opt, comm, dev);
+    return StartBatchRank(opt, side, comm, dev);
 }
 
 }  // namespace
@@ -218,35 +271,54 @@ int main(int argc, char** argv)
     if (opt.rank >= 0) {  // one rank of `world` processes: the id travels through a file
         ncclUniqueId id;
         if (opt.id_file.empty() || opt.rank >= opt.world) return 3;
+        // The file holds "<run id>\n" + the id.  Rank 0 removes whatever an earlier run left at the path before it writes,
+        // the readers skip a file that carries another run id (a run id comes from the launcher -- tools/run_batch8.sh
+        // makes a fresh one, and a fresh directory, per job; without --run-id it is "0" and only the unlink protects), and
+        // rank 0 removes the file again once every rank is past the communicator's rendezvous.
+        const std::string run_id = opt.run_id.empty() ? "0" : opt.run_id;
+        const std::string head = run_id + "\n";
+        FileRendezvous side(opt.id_file, run_id, opt.rank, opt.world);
         if (opt.rank == 0) {
+            std::remove(opt.id_file.c_str());
             if (ncclGetUniqueId(&id) != ncclSuccess) return 1;
             const std::string tmp = opt.id_file + ".tmp";
             std::FILE* f = std::fopen(tmp.c_str(), "wb");
-            if (!f || std::fwrite(&id, sizeof(id), 1, f) != 1) return 255;
+            if (!f || std::fwrite(head.data(), 1, head.size(), f) != head.size() || std::fwrite(&id, sizeof(id), 1, f) != 1) return 255;
             std::fclose(f);
             if (std::rename(tmp.c_str(), opt.id_file.c_str()) != 0) return 255;
         } else {
-            std::FILE* f = nullptr;
-            for (int tries = 0; tries < 600 && !(f = std::fopen(opt.id_file.c_str(), "rb")); ++tries) usleep(100000);
-            if (!f || std::fread(&id, sizeof(id), 1, f) != 1) return 1;
-            std::fclose(f);
+            bool have = false;
+            for (int tries = 0; tries < 1200 && !have && !side.Raised(); ++tries) {
+                std::vector<char> text(head.size() + sizeof(id));
+                std::FILE* f = std::fopen(opt.id_file.c_str(), "rb");
+                if (f) {
+                    have = std::fread(text.data(), 1, text.size(), f) == text.size() && std::memcmp(text.data(), head.data(), head.size()) == 0;
+                    std::fclose(f);
+                }
+                if (have) std::memcpy(&id, text.data() + head.size(), sizeof(id));
+                else usleep(100000);
+            }
+            if (!have) {
+                std::fprintf(stderr, "flow2d_batch: rank %d: no id file of run '%s' at %s\n", opt.rank, run_id.c_str(), opt.id_file.c_str());
+                side.Raise();
+                return 1;
+            }
         }
-        return RankMain(opt, opt.rank, opt.world, opt.device >= 0 ? opt.device : opt.rank % devices, id);
+        const int code = RankMain(opt, opt.rank, opt.world, opt.device >= 0 ? opt.device : opt.rank % devices, id, side);
+        if (opt.rank == 0) std::remove(opt.id_file.c_str());
+        return code;
     }
     if (opt.gpus < 1 || opt.gpus > devices) {
         std::fprintf(stderr, "flow2d_batch: --gpus %d with %d device(s)\n", opt.gpus, devices);
         return 1;
     }
-    // the devices are probed before any rank enters ncclCommInitRank: a rank that cannot even select its device would
-    // leave the others waiting in it
-    for (int r = 0; r < opt.gpus; ++r)
-        if (!HIP_OK(hipSetDevice(r))) return 1;
     ncclUniqueId id;
     if (ncclGetUniqueId(&id) != ncclSuccess) return 1;
+    ThreadRendezvous side(opt.gpus);  // the ranks' side channel: memory of this process
     std::vector<std::thread> threads;
     std::vector<int> codes(opt.gpus, 0);
-    for (int r = 1; r < opt.gpus; ++r) threads.emplace_back([&, r] { codes[r] = RankMain(opt, r, opt.gpus, r, id); });
-    codes[0] = RankMain(opt, 0, opt.gpus, 0, id);
+    for (int r = 1; r < opt.gpus; ++r) threads.emplace_back([&, r] { codes[r] = RankMain(opt, r, opt.gpus, r, id, side); });
+    codes[0] = RankMain(opt, 0, opt.gpus, 0, id, side);
     for (std::thread& t : threads) t.join();
     int code = 0;
     for (int c : codes) code = c > code ? c : code;

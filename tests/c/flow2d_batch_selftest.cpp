@@ -11,7 +11,16 @@
 // blocks, flow_%04d files, and that a rank which fails locally takes every rank out with the same exit code instead of
 // leaving them blocked in a collective).  It links neither HIP nor RCCL and nothing in the product links it.
 //
-// usage: flow2d_batch_selftest --world N [flow2d_batch's job flags] [--fail-rank R --fail-phase init|load|warmup|pass|gather-alloc]
+// The communicator comes up through StartBatchRank like the product's (side-channel agreements before and after the
+// connector's rendezvous); the side channel is a ThreadRendezvous, or -- with --file-rendezvous PREFIX -- the FileRendezvous the
+// product's separate rank processes use (here still threads, every one with an object of its own over the same files).
+//
+// usage: flow2d_batch_selftest --world N [flow2d_batch's job flags] [--file-rendezvous PREFIX [--run-id NONCE]]
+//            [--fail-rank R --fail-phase comm-prepare|comm-connect|broadcast|broadcast-absent|allreduce-absent|gather|gather-absent|
+//                                        init|load|warmup|pass|gather-alloc]
+//        "x" phases: the rank's collective fails AFTER it took part (a local failure); "x-absent": the rank never enters the
+//        collective, raises the side channel's flag and leaves -- its peers are blocked in theirs until they see the flag.
+#include <chrono>
 #include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
@@ -30,11 +39,14 @@ class LoopbackHub {
 public:
     explicit LoopbackHub(int world) : world_(world), pointers_(world, nullptr), values_(world, 0) {}
     int World() const { return world_; }
-    // every rank calls Meet with its pointer and value; the last one to arrive runs `op` over all of them, then all leave
+    // every rank calls Meet with its pointer and value; the last one to arrive runs `op` over all of them, then all leave.
+    // false: the side channel's flag went up while this rank was waiting (a peer left without entering the collective) --
+    // what ncclCommAbort does for a rank blocked in librccl.
     template <typename Op>
-    void Meet(int rank, void* pointer, int value, Op op, int* value_out)
+    bool Meet(int rank, void* pointer, int value, Op op, int* value_out, const RankRendezvous& side)
     {
         std::unique_lock<std::mutex> lock(mutex_);
+        if (side.Raised()) return false;  // (sticky: once a rank has left, no collective completes any more)
         pointers_[rank] = pointer;
         values_[rank] = value;
         const unsigned long long round = round_;
@@ -45,9 +57,16 @@ public:
             ++round_;
             cv_.notify_all();
         } else {
-            cv_.wait(lock, [&] { return round_ != round; });
+            while (round_ == round) {
+                if (side.Raised()) {
+                    --arrived_;
+                    return false;
+                }
+                cv_.wait_until(lock, std::chrono::system_clock::now() + std::chrono::milliseconds(2));  // (pthread_cond_timedwait: known to TSan)
+            }
         }
         if (value_out) *value_out = result_;
+        return true;
     }
 
 private:
@@ -61,52 +80,75 @@ private:
     int result_ = 0;
 };
 
-class LoopbackComm : public BatchComm {
-public:
-    LoopbackComm(LoopbackHub& hub, int rank) : hub_(hub), rank_(rank) {}
-    int Rank() const override { return rank_; }
-    int World() const override { return hub_.World(); }
-    bool Broadcast(void* buffer, size_t bytes, int root) override
-    {
-        hub_.Meet(rank_, buffer, 0, [&](std::vector<void*>& p, std::vector<int>&) {
-            for (size_t r = 0; r < p.size(); ++r)
-                if (static_cast<int>(r) != root) std::memcpy(p[r], p[root], bytes);
-        }, nullptr);
-        return true;
-    }
-    bool AllReduceMax(int* value) override
-    {
-        hub_.Meet(rank_, nullptr, *value, [&](std::vector<void*>&, std::vector<int>& v) {
-            int m = v[0];
-            for (int x : v) m = x > m ? x : m;
-            v[0] = m;
-        }, value);
-        return true;
-    }
-    bool GatherToRoot(const void* send, void* recv, size_t block_bytes) override
-    {
-        // rank 0 publishes its receive buffer, the others their blocks; the copies are made by whoever arrives last
-        void* mine = rank_ == 0 ? recv : const_cast<void*>(send);
-        const void* root_send = send;
-        hub_.Meet(rank_, mine, 0, [&](std::vector<void*>& p, std::vector<int>&) {
-            for (size_t r = 1; r < p.size(); ++r)
-                if (block_bytes) std::memcpy(static_cast<char*>(p[0]) + r * block_bytes, p[r], block_bytes);
-        }, nullptr);
-        if (rank_ == 0 && block_bytes) std::memcpy(recv, root_send, block_bytes);
-        return true;
-    }
-
-private:
-    LoopbackHub& hub_;
-    int rank_;
-};
-
-// ---- a rank's "device": host memory and stamps --------------------------------------------------------------------------
 struct Failure {
     int rank = -1;
     std::string phase;
 };
 
+class LoopbackComm : public BatchComm, public CommConnector {
+public:
+    LoopbackComm(LoopbackHub& hub, int rank, RankRendezvous& side, const Failure& failure) : hub_(hub), rank_(rank), side_(side), failure_(failure) {}
+    bool Fails(const char* phase) const { return rank_ == failure_.rank && failure_.phase == phase; }
+    // the connector: nothing to prepare or connect in shared memory, but both can be made to fail
+    bool Prepare() override { return !Fails("comm-prepare"); }
+    bool Connect() override
+    {
+        connected_ = !Fails("comm-connect");
+        return connected_;
+    }
+    void Abort() override { connected_ = false; }
+    BatchComm& Comm() override { return *this; }
+    int Rank() const override { return rank_; }
+    int World() const override { return hub_.World(); }
+    bool Broadcast(void* buffer, size_t bytes, int root) override
+    {
+        if (Absent("broadcast-absent")) return false;
+        const bool met = hub_.Meet(rank_, buffer, 0, [&](std::vector<void*>& p, std::vector<int>&) {
+            for (size_t r = 0; r < p.size(); ++r)
+                if (static_cast<int>(r) != root) std::memcpy(p[r], p[root], bytes);
+        }, nullptr, side_);
+        return met && !Fails("broadcast");
+    }
+    bool AllReduceMax(int* value) override
+    {
+        if (++all_reduces_ == 3 && Absent("allreduce-absent")) return false;
+        return hub_.Meet(rank_, nullptr, *value, [&](std::vector<void*>&, std::vector<int>& v) {
+            int m = v[0];
+            for (int x : v) m = x > m ? x : m;
+            v[0] = m;
+        }, value, side_);
+    }
+    bool GatherToRoot(const void* send, void* recv, size_t block_bytes) override
+    {
+        if (Absent("gather-absent")) return false;
+        // rank 0 publishes its receive buffer, the others their blocks; the copies are made by whoever arrives last
+        void* mine = rank_ == 0 ? recv : const_cast<void*>(send);
+        const void* root_send = send;
+        const bool met = hub_.Meet(rank_, mine, 0, [&](std::vector<void*>& p, std::vector<int>&) {
+            for (size_t r = 1; r < p.size(); ++r)
+                if (block_bytes) std::memcpy(static_cast<char*>(p[0]) + r * block_bytes, p[r], block_bytes);
+        }, nullptr, side_);
+        if (met && rank_ == 0 && block_bytes) std::memcpy(recv, root_send, block_bytes);
+        return met && !Fails("gather");
+    }
+
+private:
+    // the rank cannot enter the collective at all: like the product's back end it raises the flag before it returns
+    bool Absent(const char* phase)
+    {
+        if (!Fails(phase)) return false;
+        side_.Raise();
+        return true;
+    }
+    LoopbackHub& hub_;
+    int rank_;
+    RankRendezvous& side_;
+    Failure failure_;
+    bool connected_ = false;
+    int all_reduces_ = 0;
+};
+
+// ---- a rank's "device": host memory and stamps --------------------------------------------------------------------------
 class StubDevice : public BatchDevice {
 public:
     StubDevice(int rank, const Failure& failure) : rank_(rank), failure_(failure) {}
@@ -185,6 +227,7 @@ private:
 struct SelfTestFlags {
     int world = 2;
     Failure failure;
+    std::string file_prefix;  // --file-rendezvous: the product's FileRendezvous instead of the ThreadRendezvous
 };
 
 int ExtraFlag(int argc, char** argv, int i, void* user)
@@ -200,6 +243,10 @@ int ExtraFlag(int argc, char** argv, int i, void* user)
         f.failure.phase = argv[i + 1];
         return 2;
     }
+    if (a == "--file-rendezvous") {
+        f.file_prefix = argv[i + 1];
+        return 2;
+    }
     return 0;
 }
 
@@ -211,22 +258,25 @@ int main(int argc, char** argv)
     SelfTestFlags flags;
     opt.p.width = 64, opt.p.height = 48, opt.p.lanes = 2, opt.p.group = 2;
     if (!ParseBatchArgs(argc, argv, opt, ExtraFlag, &flags)) {
-        std::fprintf(stderr, "usage: flow2d_batch_selftest --world N %s       [--fail-rank R --fail-phase init|load|warmup|pass|gather-alloc]\n",
+        std::fprintf(stderr, "usage: flow2d_batch_selftest --world N %s       [--file-rendezvous PREFIX] [--fail-rank R --fail-phase PHASE]\n",
                      BatchUsage());
         return 3;
     }
     const int world = opt.world;
     if (world < 1 || world > 64) return 3;
     LoopbackHub hub(world);
+    ThreadRendezvous shared_side(world, 20.0);
     std::vector<int> codes(world, 0);
     std::vector<std::thread> threads;
     auto rank_main = [&](int rank) {
         BatchOptions mine = opt;
         // only rank 0's parameters count: give the others nonsense so that a rank that skipped the broadcast shows
         if (rank != 0) mine.p = BatchParameterBlock{1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1};
-        LoopbackComm comm(hub, rank);
+        FileRendezvous file_side(flags.file_prefix, opt.run_id, rank, world, 20.0);
+        RankRendezvous& side = flags.file_prefix.empty() ? static_cast<RankRendezvous&>(shared_side) : file_side;
+        LoopbackComm comm(hub, rank, side, flags.failure);
         StubDevice device(rank, flags.failure);
-        codes[rank] = RunBatchRank(mine, comm, device);
+        codes[rank] = StartBatchRank(mine, side, comm, device);
     };
     for (int r = 1; r < world; ++r) threads.emplace_back(rank_main, r);
     rank_main(0);

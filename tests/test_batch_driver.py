@@ -81,17 +81,66 @@ def test_digest_does_not_depend_on_the_world_size(tmp_path):
     assert len({l["flows_fnv1a"] for l in lines}) == 1
 
 
-@pytest.mark.parametrize("phase", ["init", "load", "warmup", "pass", "gather-alloc"])
+@pytest.mark.parametrize("phase", ["init", "load", "warmup", "pass", "gather-alloc", "broadcast", "gather"])
 @pytest.mark.parametrize("rank", [0, 2])
 def test_a_failing_rank_takes_every_rank_out(phase, rank):
     """flow2d_batch_selftest returns 99 when the ranks disagree on the exit code, and the timeout catches a rank left
-    blocked in a collective (round 3's driver returned from the failing rank alone)."""
+    blocked in a collective (round 3's driver returned from the failing rank alone).  "broadcast" / "gather": the
+    collective fails on the rank after it took part (round 4 returned from that rank without an agreement)."""
     p = run(["--world", 3, "--pairs", 7, "--fail-rank", rank, "--fail-phase", phase], timeout=30)
     expected = 0 if (phase == "gather-alloc" and rank != 0) else 1  # only rank 0 allocates the gathered buffer
     assert p.returncode == expected, (p.returncode, p.stderr[-1000:])
     if expected:
         assert "another rank failed" in p.stderr
         assert not [x for x in p.stdout.splitlines() if x.startswith("{")]  # no result line from a failed job
+
+
+@pytest.mark.parametrize("phase", ["comm-prepare", "comm-connect"])
+@pytest.mark.parametrize("rank", [0, 1, 7])
+@pytest.mark.parametrize("side", ["threads", "files"])
+def test_a_rank_that_cannot_bring_the_communicator_up(tmp_path, phase, rank, side):
+    """StartBatchRank: the local prerequisites and the communicator's own rendezvous sit between two agreements of the side
+    channel (memory for ranks that are threads, files for ranks that are processes -- here both over threads), so a rank
+    that fails there keeps the others out of ncclCommInitRank / makes them abort what they connected; all return 1."""
+    extra = ["--file-rendezvous", tmp_path / "id", "--run-id", "r%d" % rank] if side == "files" else []
+    p = run(["--world", 8, "--pairs", 9, "--fail-rank", rank, "--fail-phase", phase] + extra, timeout=30)
+    assert p.returncode == 1, (p.returncode, p.stderr[-1000:])
+    assert ("no rank enters it" if phase == "comm-prepare" else "did not come up") in p.stderr
+    assert not [x for x in p.stdout.splitlines() if x.startswith("{")]
+
+
+@pytest.mark.parametrize("phase", ["broadcast-absent", "allreduce-absent", "gather-absent"])
+@pytest.mark.parametrize("rank", [0, 2])
+@pytest.mark.parametrize("side", ["threads", "files"])
+def test_a_rank_that_never_enters_a_collective_frees_its_peers(tmp_path, phase, rank, side):
+    """The rank raises the side channel's flag and leaves; its peers, blocked inside the collective, see the flag (the
+    product aborts its communicator, the loopback leaves its hub) and every rank returns 1 within the timeout."""
+    extra = ["--file-rendezvous", tmp_path / "id"] if side == "files" else []
+    p = run(["--world", 3, "--pairs", 7, "--fail-rank", rank, "--fail-phase", phase] + extra, timeout=30)
+    assert p.returncode == 1, (p.returncode, p.stderr[-1000:])
+    assert not [x for x in p.stdout.splitlines() if x.startswith("{")]
+
+
+def test_file_rendezvous_ignores_another_runs_files(tmp_path):
+    """Stale side-channel files of an earlier job at the same prefix (another run id, or none) do not count as posts: the
+    job still needs -- and gets -- every rank's own post, and removes its files afterwards."""
+    prefix = tmp_path / "id"
+    for r in range(3):  # an earlier run that was killed: "all fine" posts and a raised flag
+        (tmp_path / ("id.s0.r%d" % r)).write_text("old 1")
+        (tmp_path / ("id.s1.r%d" % r)).write_text("old 0")
+    (tmp_path / "id.abort.old").write_text("old")
+    p = run(["--world", 3, "--pairs", 5, "--file-rendezvous", prefix, "--run-id", "new"], timeout=30)
+    assert p.returncode == 0, p.stderr[-1000:]
+    assert json.loads(p.stdout.splitlines()[-1])["pairs"] == 5
+    assert not [n for n in os.listdir(tmp_path) if n.startswith("id.abort.new")]
+    # the job's own posts are gone (it overwrote and then removed the stage files of its ranks)
+    assert sorted(os.listdir(tmp_path)) == ["id.abort.old"]
+
+
+def test_constancy_values_of_the_library_are_accepted():
+    for c in (0, 1, 2, 3):  # Grey, Gradient, LogDerivatives, GradientUntiled (data_structs.h)
+        assert run(["--world", 2, "--pairs", 2, "--constancy", c], timeout=30).returncode == 0
+    assert run(["--world", 2, "--pairs", 2, "--constancy", 4], timeout=30).returncode == 3
 
 
 def test_exit_codes_of_a_job(tmp_path):

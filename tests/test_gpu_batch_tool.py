@@ -65,3 +65,23 @@ def test_batch_tool_synthetic_and_exit_codes(tmp_path):
     assert p.returncode == 3
     p = subprocess.run([TOOL, "--gpus", "99"], env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=60)
     assert p.returncode == 1
+
+
+def test_run_batch8_script_with_one_rank(tmp_path):
+    """tools/run_batch8.sh, the turnkey launcher of the one-process-per-GPU form (fresh child processes, an id file and a run
+    id in a directory of the job's own), at --world 1 on the one GPU of the box: same digest as the threaded form, the
+    job's directory gone afterwards; a stale id file of another run at a fixed path does not confuse the process form."""
+    job = ["--pairs", 3, "--width", 160, "--height", 96, "--levels", 3, "--outer", 2, "--lanes", 2, "--group", 2, "--repeat", 2,
+           "--constancy", 3]
+    line = run_tool(["--gpus", 1] + job)
+    before = set(os.listdir("/tmp"))
+    p = subprocess.run([os.path.join(ROOT, "tools", "run_batch8.sh"), "--world", "1"] + [str(a) for a in job],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-1500:]
+    script = json.loads([x for x in p.stdout.splitlines() if x.startswith("{")][0])
+    assert script["world"] == 1 and script["flows_fnv1a"] == line["flows_fnv1a"]
+    assert not [n for n in set(os.listdir("/tmp")) - before if n.startswith("flow2d_batch.")]
+    stale = tmp_path / "nccl.id"
+    stale.write_bytes(b"some-older-run\n" + bytes(128))
+    other = run_tool(["--rank", 0, "--world", 1, "--id-file", stale, "--run-id", "fresh"] + job)
+    assert other["flows_fnv1a"] == line["flows_fnv1a"] and not stale.exists()

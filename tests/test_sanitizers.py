@@ -38,6 +38,10 @@ def test_host_layer_under_sanitizers(tmp_path):
         ok = run([tool, "--world", 5, "--pairs", 13, "--width", 70, "--height", 9, "--out-dir", out])
         assert ok.returncode == 0, (binary, ok.stderr[-3000:])
         assert "WARNING: ThreadSanitizer" not in ok.stderr and "AddressSanitizer" not in ok.stderr, ok.stderr[-3000:]
-        bad = run([tool, "--world", 4, "--pairs", 6, "--fail-rank", 3, "--fail-phase", "pass"])
-        assert bad.returncode == 1, (binary, bad.returncode, bad.stderr[-3000:])
-        assert "WARNING: ThreadSanitizer" not in bad.stderr and "AddressSanitizer" not in bad.stderr, bad.stderr[-3000:]
+        # a rank failing in a pass; one that cannot connect the communicator; one that never enters a collective (the
+        # side channel's flag frees its peers), over the thread and over the file side channel
+        for extra in (["--fail-phase", "pass"], ["--fail-phase", "comm-connect"], ["--fail-phase", "broadcast-absent"],
+                      ["--fail-phase", "gather-absent", "--file-rendezvous", tmp_path / ("side_" + binary)]):
+            bad = run([tool, "--world", 4, "--pairs", 6, "--fail-rank", 3] + extra)
+            assert bad.returncode == 1, (binary, extra, bad.returncode, bad.stderr[-3000:])
+            assert "WARNING: ThreadSanitizer" not in bad.stderr and "AddressSanitizer" not in bad.stderr, bad.stderr[-3000:]
