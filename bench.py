@@ -78,6 +78,11 @@ WORKLOADS = {
     "cfg5_8192_grey": dict(w=8192, h=8192, dx=12.0, dy=-7.0, seed=5, constancy=0, levels=12, scale=0.5, outer=10,
                            inner=5, median=5, sigma=1.5, alpha=35.0, pairs_per_rank=1),
 }
+# The north_star names "red-black SOR relaxation"; the reference is Jacobi, so SOR is an opt-in mode without
+# reference parity (checked against its own oracle restatement).  This workload is config 3 with every inner iteration a
+# red-black SOR iteration, temporally blocked in the strip kernel (two iterations per launch), plus the time-to-residual
+# leg: how many SOR iterations per outer iteration -- and how many ms -- reach the residual Jacobi 10 x 5 reaches.
+WORKLOADS["cfg3_4096_sor"] = dict(WORKLOADS["cfg3_4096_gradient"], sor_omega=1.5, inner=2)
 # developer what-if (not a BASELINE config): 4 / 8 pairs of config 4 stacked into one tall frame, i.e. the kernel sizes a
 # lock-step batch of pairs would launch
 WORKLOADS["x_stack4_1080p"] = dict(WORKLOADS["cfg4_1080p_batch"], h=4320, pairs_per_rank=2)
@@ -145,7 +150,7 @@ def cpu_baseline(cfg, budget_s=20.0, full_run=None):
     f0, f1 = synthetic_pair(probe, probe, cfg["dx"], cfg["dy"])
     t0 = time.perf_counter()
     O.compute_flow(f0, f1, cfg["levels"], cfg["scale"], cfg["outer"], cfg["inner"], cfg["alpha"], 0.001, 0.001,
-                   cfg["median"], cfg["sigma"], cfg["constancy"])
+                   cfg["median"], cfg["sigma"], cfg["constancy"], sor_omega=cfg.get("sor_omega", 0.0))
     t_probe = time.perf_counter() - t0
     if full_run is not None:
         side_w, side_h, (t, t_finest) = cfg["w"], cfg["h"], full_run
@@ -159,7 +164,8 @@ def cpu_baseline(cfg, budget_s=20.0, full_run=None):
         f0, f1 = synthetic_pair(side, side, cfg["dx"], cfg["dy"])
         t0 = time.perf_counter()
         _, _, t_finest = O.compute_flow(f0, f1, cfg["levels"], cfg["scale"], cfg["outer"], cfg["inner"], cfg["alpha"],
-                                        0.001, 0.001, cfg["median"], cfg["sigma"], cfg["constancy"])
+                                        0.001, 0.001, cfg["median"], cfg["sigma"], cfg["constancy"],
+                                        sor_omega=cfg.get("sor_omega", 0.0))
         t = time.perf_counter() - t0
         side_w = side_h = side
         what = "%dx%d crop of the workload's synthetic pair" % (side, side)
@@ -169,7 +175,7 @@ def cpu_baseline(cfg, budget_s=20.0, full_run=None):
     f0s, f1s = synthetic_pair(probe, probe, cfg["dx"], cfg["dy"])
     t0 = time.perf_counter()
     O.compute_flow(f0s, f1s, cfg["levels"], cfg["scale"], cfg["outer"], cfg["inner"], cfg["alpha"], 0.001, 0.001,
-                   cfg["median"], cfg["sigma"], cfg["constancy"])
+                   cfg["median"], cfg["sigma"], cfg["constancy"], sor_omega=cfg.get("sor_omega", 0.0))
     t_single = time.perf_counter() - t0
     O.set_threads(threads)
     return {
@@ -261,7 +267,7 @@ def pmc_child(flow2d, args, cfg):
         f0, f1 = (c.plane(w, h, a) for a in workload_pair(args.workload, cfg, 0))
         u, v = c.plane(w, h), c.plane(w, h)
         p = flow.params(cfg["levels"], cfg["scale"], cfg["outer"], cfg["inner"], cfg["alpha"], 0.001, 0.001,
-                        cfg["median"], cfg["sigma"], args.algorithm)
+                        cfg["median"], cfg["sigma"], args.algorithm, sor_omega=cfg.get("sor_omega", 0.0))
         for _ in range(2):
             flow.compute_flow_device(f0.ptr, f1.ptr, u.ptr, v.ptr, p, 0)
         c.synchronize()
@@ -332,7 +338,8 @@ def pmc_select(collected, cfg, algorithm_used):
     rows = collected["rows"]
     family = {1: "sweep_", 2: "fused_outer_kernel", 3: "small_level_kernel", 4: "tile_outer_kernel"}[algorithm_used]
 
-    per_solve = {1: cfg["outer"] * cfg["inner"], 2: cfg["outer"] * -(-cfg["inner"] // 5), 3: 1, 4: cfg["outer"]}[algorithm_used]
+    per_launch_max = 2 if cfg.get("sor_omega") else 5  # red-black iterations are two half-sweep stages each: two per launch
+    per_solve = {1: cfg["outer"] * cfg["inner"], 2: cfg["outer"] * -(-cfg["inner"] // per_launch_max), 3: 1, 4: cfg["outer"]}[algorithm_used]
     PYRAMIDS = 2  # pmc_child runs the pyramid twice
 
     def launches(counter, prefix, per_pyramid):
@@ -471,7 +478,7 @@ class Job:
         block = batch.broadcast_params([cfg["levels"], cfg["scale"], cfg["outer"], cfg["inner"], cfg["alpha"], 0.001,
                                         0.001, cfg["median"], cfg["sigma"], args.algorithm])
         self.params = self.runner.params(int(block[0]), block[1], int(block[2]), int(block[3]), block[4], block[5],
-                                         block[6], int(block[7]), block[8], int(block[9]))
+                                         block[6], int(block[7]), block[8], int(block[9]), sor_omega=cfg.get("sor_omega", 0.0))
         # this rank's pairs, resident in HBM before any timed region; pair k -> rank k mod world
         self.owned = batch.pairs_of_rank(cfg["pairs_per_rank"] * world, rank, world)
         frames = [workload_pair(workload, cfg, gk, world) for gk in self.owned]
@@ -730,7 +737,8 @@ def oracle_check(job):
     u, v = pu.download()[:h], pv.download()[:h]
     t0 = time.perf_counter()
     ou, ov, t_finest = O.compute_flow(job.first_pair[0], job.first_pair[1], cfg["levels"], cfg["scale"], cfg["outer"],
-                                      cfg["inner"], cfg["alpha"], 0.001, 0.001, cfg["median"], cfg["sigma"], cfg["constancy"])
+                                      cfg["inner"], cfg["alpha"], 0.001, 0.001, cfg["median"], cfg["sigma"], cfg["constancy"],
+                                      sor_omega=cfg.get("sor_omega", 0.0))
     seconds = time.perf_counter() - t0
     return {"first_pair_equals_cpu_oracle": bool(np.array_equal(u, ou) and np.array_equal(v, ov)),
             "pixels_compared": int(2 * u.size), "oracle_seconds": round(seconds, 2),
@@ -805,6 +813,62 @@ def per_sweep_sample(job, launches=10, rounds=4):
         c.close()
 
 
+def sor_time_to_residual(flow2d, cfg, local_rank, pair, omegas=(1.0, 1.5, 1.9), max_iterations=8):
+    """The finest level of the workload as ONE level problem (u = v = 0, the pair's frames as they are): the Jacobi level
+    solve of the reference's counts (outer x 5 sweeps) against red-black SOR level solves with omega in `omegas` and 1, 2, ...
+    iterations per outer iteration.  Residual of a state d = (du, dv): the root mean square of G(d) - d, where G is one more
+    fixed-point step -- phi / ksi evaluated AT d (compute_phi_ksi), then one Jacobi sweep (solve_2d*) -- i.e. the defect of the
+    nonlinear Euler-Lagrange system scaled by its diagonal; it is zero at the solution and the same yardstick for every
+    scheme.  Times: HIP events around the whole level solve, best of three after a warm pass."""
+    w, h, outer = cfg["w"], cfg["h"], cfg["outer"]
+    c = flow2d.Context(local_rank)
+    try:
+        f0, f1 = (c.plane(w, h, a) for a in pair)
+        u, v, du, dv, phi, ksi, tdu, tdv, gdu, gdv = (c.plane(w, h).fill_bytes(0) for _ in range(10))
+
+        def solve(inner, omega):
+            best, out = None, None
+            for rep in range(4):
+                e0, e1 = c.event(), c.event()
+                c.record(e0)
+                out = c.solve_level(f0, f1, u, v, du, dv, phi, ksi, tdu, tdv, w, h, 1.0, 1.0, cfg["alpha"], 0.001, 0.001,
+                                    outer, inner, cfg["constancy"], 0, sor_omega=omega)
+                c.record(e1)
+                ms = c.elapsed_ms(e0, e1)
+                best = ms if rep and (best is None or ms < best) else best
+            return out, best
+
+        def residual(state):
+            a, b = state
+            others = [q for q in (du, dv, tdu, tdv) if q is not a and q is not b]
+            c.compute_phi_ksi(f0, f1, u, v, a, b, w, h, 1.0, 1.0, 0.001, 0.001, phi, ksi)
+            c.solve_sweep(f0, f1, u, v, a, b, phi, ksi, w, h, 1.0, 1.0, cfg["alpha"], gdu, gdv, cfg["constancy"])
+            r = np.concatenate([(gdu.download(w, h) - a.download(w, h)).ravel(), (gdv.download(w, h) - b.download(w, h)).ravel()])
+            del others
+            return float(np.sqrt(np.mean(r.astype(np.float64) ** 2)))
+
+        state, ms_j = solve(5, 0.0)
+        r_j = residual(state)
+        out = {"level": "%dx%d, u = v = 0, %s data term, alpha %g" % (w, h, CONSTANCY_NAME[cfg["constancy"]], cfg["alpha"]),
+               "residual": "rms of (one more fixed-point step: phi / ksi at the state, one Jacobi sweep) - state",
+               "jacobi": {"outer": outer, "sweeps_per_outer": 5, "ms": round(ms_j, 4), "residual": r_j}, "sor": []}
+        for omega in omegas:
+            rows, reached = [], None
+            for n in range(1, max_iterations + 1):
+                state, ms = solve(n, omega)
+                r = residual(state)
+                rows.append({"iterations_per_outer": n, "ms": round(ms, 4), "residual": r})
+                if r <= r_j:
+                    reached = n
+                    break
+            out["sor"].append({"omega": omega, "iterations_per_outer_to_reach_jacobi": reached,
+                               "ms_to_reach_jacobi": rows[-1]["ms"] if reached else None,
+                               "speedup_over_jacobi": round(ms_j / rows[-1]["ms"], 3) if reached else None, "runs": rows})
+        return out
+    finally:
+        c.close()
+
+
 def batch_leg(flow2d, batch, torch, args, rank, local_rank, world):
     """BASELINE.json configs[3]: 8 pairs of 1920x1080 per GPU (64 on 8 GPUs), then ONE all_gather of the flow fields."""
     cfg = WORKLOADS[BATCH_WORKLOAD]
@@ -817,7 +881,8 @@ def batch_leg(flow2d, batch, torch, args, rank, local_rank, world):
     # at least 64 steps (like the host-entry leg): over 20 steps the fill and drain of the four lanes weigh 12 % (round 4:
     # 2 092 pairs/s in the driver's line against 2 388 for the same workload at 100 steps)
     steps = max(64, args.steps)
-    elapsed = timed_region(job, batch, torch, steps, 1)[0]
+    # (median of three regions after the same warm-up as the main region's: one region right after the CPU-side legs read low)
+    elapsed = float(np.median(timed_region(job, batch, torch, steps, args.warmup, 3)))
     check = output_check(job)
     # gather: every rank's [2, 8, H, pitch] block -> [world, 2, 8, H, pitch]; pair k = [k % world, :, k // world].  Two forms,
     # each run once untimed and once timed: to every rank (all_gather) and to rank 0 only (gather: what BASELINE.json asks)
@@ -1043,7 +1108,9 @@ def main():
         temporal = algorithm_used in (2, 3, 4)  # several sweeps per trip through HBM: not bound by the per-sweep bytes
         kernel_name = {1: "Jacobi sweep kernel (%s)" % {0: "solve_2d", 1: "solve_2d_grad", 3: "solve_2d_log"}.get(
                            cfg["constancy"], "gradient-untiled"),
-                       2: "fused outer-iteration strip kernel (phi/ksi + %d Jacobi sweeps per launch)" % min(cfg["inner"], 5),
+                       2: ("fused outer-iteration strip kernel (phi/ksi + %d red-black SOR iterations per launch)" % min(cfg["inner"], 2))
+                          if cfg.get("sor_omega") else
+                          "fused outer-iteration strip kernel (phi/ksi + %d Jacobi sweeps per launch)" % min(cfg["inner"], 5),
                        3: "single-workgroup level kernel", 4: "tiled outer-iteration kernel (LDS tiles)"}[algorithm_used]
         roof = {
             # what bounds the kernel: vector-ALU instruction issue for the kernels that keep the sweeps of an outer
@@ -1110,7 +1177,8 @@ def main():
                 "warp_scale": cfg["scale"], "outer_iterations": cfg["outer"], "inner_iterations": cfg["inner"],
                 "data_constancy": CONSTANCY_NAME[cfg["constancy"]], "median_radius": cfg["median"],
                 "gaussian_sigma": cfg["sigma"], "alpha": cfg["alpha"], "solver_algorithm": algorithm_used,
-                "relaxation": "Jacobi, reference iteration counts (bit-exact parity mode)",
+                "relaxation": ("red-black SOR, omega %g (opt-in; no reference parity: the reference is Jacobi)" % cfg["sor_omega"])
+                              if cfg.get("sor_omega") else "Jacobi, reference iteration counts (bit-exact parity mode)",
                 "parallelism": "independent pairs, one process per GPU, no data-path collective",
                 "host_path": "OpticalFlowBatch2D::ComputeFlowBatchDevice (C++): one call per step",
                 "streams_per_gpu": n_lanes, "hip_graph_replay": not args.no_graph,
@@ -1140,7 +1208,10 @@ def main():
             out["cpu_baseline"] = cpu_baseline(cfg, full_run=oracle_timing)
         else:
             out["cpu_baseline"] = None
-        if world == 1 and not args.no_reference_baseline:
+        if cfg.get("sor_omega"):
+            # the algorithm north_star names, beside the reference's Jacobi: iterations and milliseconds to the same residual
+            out["sor_time_to_residual"] = sor_time_to_residual(flow2d, cfg, local_rank, first_pair)
+        if world == 1 and not args.no_reference_baseline and not cfg.get("sor_omega"):  # (the reference has no SOR)
             ref = out["reference_gpu_baseline"] = reference_gpu_baseline(cfg, *first_pair)
             if ref and ref.get("pairs_per_s") and host_entry:  # like for like: both brackets hold the H<->D copies
                 ref["product_incl_h2d_over_reference"] = round(host_entry["pairs_per_s"] / ref["pairs_per_s"], 2)

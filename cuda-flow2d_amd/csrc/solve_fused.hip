@@ -139,9 +139,11 @@ int launch_fused_outer(flow2d_context* ctx, int constancy, const float* f0, cons
                        const float* v, const float* du, const float* dv, size_t w, size_t h, size_t pitch_bytes,
                        float hx, float hy, float alpha, float e_smooth, float e_data, size_t inner, float* out_du,
                        float* out_dv, int rows_per_strip, bool zero_increment, const float* start_du,
-                       const float* start_dv)
+                       const float* start_dv, float sor_omega)
 {
+    // sor_omega != 0: the `inner` stages are red-black half-sweeps (2 or 4: one or two iterations per launch)
     if (!fused_supports(inner) || !fused_addressable(h, pitch_bytes)) return FLOW2D_ERR_UNSUPPORTED;
+    if (sor_omega != 0.f && (inner != 2 && inner != 4)) return FLOW2D_ERR_UNSUPPORTED;
     // rows_per_strip > 0: uniform strips of that height (developer override); 0: the planner's choice
     // A lock-step group whose every instance fills the chip on its own with long strips (128 rows and more: 4096^2 and
     // up) is launched instance by instance: nothing is gained by one launch of several rounds, and the strips are then
@@ -164,6 +166,7 @@ int launch_fused_outer(flow2d_context* ctx, int constancy, const float* f0, cons
                 e_data,
                 2.f * hx, 2.f * hy, 4.f * hx, 4.f * hy, 1.f / (2.f * hx), 1.f / (2.f * hy), 1.f / (4.f * hx), 1.f / (4.f * hy),
                 static_cast<float>(1.0 / (2.0 * hx)), static_cast<float>(1.0 / (2.0 * hy)), alpha / (hx * hx), alpha / (hy * hy),
+                sor_omega, 1.f - sor_omega,
                 0, plan.blocks, 0, static_cast<unsigned long long>(ctx->batch_stride_floats),
 #ifdef FLOW2D_FUSED_STAMPS
                 stamp_buffer(), stamp_counter(),

@@ -350,7 +350,7 @@ struct Strip {
     float fxw[3], fyw[3], ftw[3];  // GRAD only
     float lf0w[3], lf1w[3];        // GRAD == 3 only: log(frame + 1) rows
     v2f UV[INNER][3];                // UV[k] = (u + du^k, v + dv^k) rows around the row sweep k+1 is working on
-    float dvc[INNER];                // dv^k of the row sweep k+1 processes in the current step
+    v2f duvc[INNER];                 // (du^k, dv^k) of the row sweep k+1 processes in the current step (Jacobi reads dv only)
     Coef C[kRing];
     // brightness derivatives and ksi of the row stage W consumes next (produced by stage P one step earlier)
     float p_fx, p_fy, p_ft, p_ksi;
@@ -406,7 +406,12 @@ __device__ __forceinline__ void inject_six(Strip<INNER, GRAD>& s)
 // stages would work on rows nothing depends on: stage P is first needed at step 2, stage W at step 3, sweep k at
 // step 3 + 2k.  The start-up steps are peeled off the row loop and compiled without those stages.
 // FAST: the sweeps divide through the prepared reciprocal (div3); false = plain division (the fallback pass).
-template <int INNER, int GRAD, bool EDGE, bool POW2, bool CONT, bool FAST, int J, int T = -1>
+// SOR: the INNER stages are red-black half-sweeps of the opt-in successive over-relaxation (flow2d_solve_params.sor_omega;
+// not a reference mode, the reference is Jacobi): stage k relaxes the pixels with (x + y) % 2 == (k - 1) % 2 in place --
+// du' = (1 - omega) du + omega gs_du with the Gauss-Seidel value of the same point update, dv' sees the relaxed du' --
+// and passes the other colour through.  A half-sweep reaches one pixel like a Jacobi sweep, so the skewed pipeline, its
+// halo and its start-up are those of INNER Jacobi sweeps; INNER / 2 iterations per launch.
+template <int INNER, int GRAD, bool EDGE, bool POW2, bool CONT, bool FAST, bool SOR, int J, int T = -1>
 __device__ __forceinline__ void strip_step(Strip<INNER, GRAD>& s, const FusedArgs& a, int r, int x, int xc, bool at_l,
                                            bool at_r, bool lane_stores, int y0, int y1, float hx_2,
                                            float hy_2)
@@ -420,7 +425,7 @@ __device__ __forceinline__ void strip_step(Strip<INNER, GRAD>& s, const FusedArg
 
     // ---- commit the prefetched row r (its slot still holds row r-3: sweep 1 needs that row's dv) ----------
     constexpr bool cont = CONT;
-    const float dv_row3 = cont ? s.start_cur.y : s.duvw[s0].y;  // start_cur still is row r-3 here
+    const v2f duv_row3 = cont ? s.start_cur : s.duvw[s0];  // start_cur still is row r-3 here
     if (cont) {
         if (FAST) guard_flow_row(s.guard, s.n_start, s.n_start);
         s.start_cur = s.n_start;  // row r-2
@@ -673,7 +678,7 @@ __device__ __forceinline__ void strip_step(Strip<INNER, GRAD>& s, const FusedArg
 
     FLOW2D_INJECT_SIX(s);
     // ---- sweeps k = 1..INNER, row rk = r-2-k (solve_2d.cu:349-367) ------------------------------------------
-    float dv_in = dv_row3;  // dv^0 of row r-3
+    v2f old = duv_row3;  // (du^0, dv^0) of row r-3
 #pragma unroll
     for (int k = 1; k <= INNER; ++k) {
         if (T >= 0 && T < 3 + 2 * k) continue;  // start-up: this sweep's row feeds nothing yet
@@ -705,8 +710,23 @@ __device__ __forceinline__ void strip_step(Strip<INNER, GRAD>& s, const FusedArg
             dU = pick2(top, d_d0, d_u0), dD = pick2(bot, d_u0, d_d0);
         }
         const v2f sums = flux_of_differences(c.wx, c.wy, dR, dL, dD, dU);  // (sumU, sumV)
+        const float dv_in = old.y;
         float du_new, dv_new;
-        if (FAST) {  // the coupled 2x2 update of solve_2d.cu:361-367 (point_update) with the three-step division
+        if (SOR) {  // point_update_sor (solver_math.hpp): the Gauss-Seidel values blended with the old ones, then the colour select
+            const float nu = ksi * (-J13_23.x - J12 * dv_in) + sums.x;
+            const float gs_du = FAST ? div3(nu, den.x, rden.x) : nu / den.x;
+            du_new = a.sor_keep * old.x + a.sor_omega * gs_du;
+            const float nv = ksi * (-J13_23.y - J12 * du_new) + sums.y;
+            const float gs_dv = FAST ? div3(nv, den.y, rden.y) : nv / den.y;
+            dv_new = a.sor_keep * old.y + a.sor_omega * gs_dv;
+            const bool mine = ((x + rk + k - 1) & 1) == 0;  // half-sweep k relaxes colour (k - 1) % 2
+            du_new = mine ? du_new : old.x;
+            dv_new = mine ? dv_new : old.y;
+            if (FAST) {
+                guard_numerators(s.guard, nu, nv);
+                if (k == INNER) guard_results(s.guard, du_new, dv_new);
+            }
+        } else if (FAST) {  // the coupled 2x2 update of solve_2d.cu:361-367 (point_update) with the three-step division
             const float nu = ksi * (-J13_23.x - J12 * dv_in) + sums.x;
             du_new = div3(nu, den.x, rden.x);
             const float nv = ksi * (-J13_23.y - J12 * du_new) + sums.y;
@@ -718,8 +738,8 @@ __device__ __forceinline__ void strip_step(Strip<INNER, GRAD>& s, const FusedArg
         }
         if (k < INNER) {
             s.UV[k][sc] = c.uvc + v2f{du_new, dv_new};
-            dv_in = s.dvc[k];      // dv^k of row r-3-k, produced by this sweep one step ago
-            s.dvc[k] = dv_new;     // dv^k of row r-2-k, for the next step
+            old = s.duvc[k];                    // (du^k, dv^k) of row r-3-k, produced by this sweep one step ago
+            s.duvc[k] = v2f{du_new, dv_new};    // of row r-2-k, for the next step
         } else if (lane_stores && rk >= y0 && rk < y1) {
 #ifdef FLOW2D_FUSED_COMPUTE_ONLY
             const unsigned off = (static_cast<unsigned>(rk & 7) * static_cast<unsigned>(a.pitch) + static_cast<unsigned>(xc)) * 4u;
@@ -743,44 +763,44 @@ __device__ __forceinline__ void strip_step(Strip<INNER, GRAD>& s, const FusedArg
     if (T < 0 && kTurnShift >= 0) s.turn_clock = __builtin_amdgcn_s_memtime();
 }
 
-template <int INNER, int GRAD, bool EDGE, bool POW2, bool CONT, bool FAST, size_t... Js>
+template <int INNER, int GRAD, bool EDGE, bool POW2, bool CONT, bool FAST, bool SOR, size_t... Js>
 __device__ __forceinline__ void strip_steps(Strip<INNER, GRAD>& s, const FusedArgs& a, int r_base, int x, int xc,
                                             bool at_l, bool at_r, bool lane_stores, int y0, int y1, 
                                             float hx_2, float hy_2, std::index_sequence<Js...>)
 {
-    (strip_step<INNER, GRAD, EDGE, POW2, CONT, FAST, static_cast<int>(Js)>(s, a, r_base + static_cast<int>(Js), x, xc, at_l,
+    (strip_step<INNER, GRAD, EDGE, POW2, CONT, FAST, SOR, static_cast<int>(Js)>(s, a, r_base + static_cast<int>(Js), x, xc, at_l,
                                                                      at_r, lane_stores, y0, y1, hx_2, hy_2),
      ...);
 }
 
 // the last, partial turn of the ring: the steps up to r_last only (wave-uniform guards)
-template <int INNER, int GRAD, bool EDGE, bool POW2, bool CONT, bool FAST, size_t... Js>
+template <int INNER, int GRAD, bool EDGE, bool POW2, bool CONT, bool FAST, bool SOR, size_t... Js>
 __device__ __forceinline__ void strip_tail(Strip<INNER, GRAD>& s, const FusedArgs& a, int r_base, int r_last, int x, int xc,
                                            bool at_l, bool at_r, bool lane_stores, int y0, int y1, float hx_2,
                                            float hy_2, std::index_sequence<Js...>)
 {
     ((r_base + static_cast<int>(Js) <= r_last
-          ? strip_step<INNER, GRAD, EDGE, POW2, CONT, FAST, static_cast<int>(Js)>(s, a, r_base + static_cast<int>(Js), x, xc,
+          ? strip_step<INNER, GRAD, EDGE, POW2, CONT, FAST, SOR, static_cast<int>(Js)>(s, a, r_base + static_cast<int>(Js), x, xc,
                                                                                 at_l, at_r, lane_stores, y0, y1, hx_2,
                                                                                 hy_2)
           : (void)0),
      ...);
 }
 
-template <int INNER, int GRAD, bool EDGE, bool POW2, bool CONT, bool FAST, size_t... Ts>
+template <int INNER, int GRAD, bool EDGE, bool POW2, bool CONT, bool FAST, bool SOR, size_t... Ts>
 __device__ __forceinline__ void strip_startup(Strip<INNER, GRAD>& s, const FusedArgs& a, int r_first, int x, int xc,
                                               bool at_l, bool at_r, bool lane_stores, int y0, int y1, 
                                               float hx_2, float hy_2, std::index_sequence<Ts...>)
 {
     constexpr int kRing = Strip<INNER, GRAD>::kRing;
-    (strip_step<INNER, GRAD, EDGE, POW2, CONT, FAST, static_cast<int>(Ts) % kRing, static_cast<int>(Ts)>(
+    (strip_step<INNER, GRAD, EDGE, POW2, CONT, FAST, SOR, static_cast<int>(Ts) % kRing, static_cast<int>(Ts)>(
          s, a, r_first + static_cast<int>(Ts), x, xc, at_l, at_r, lane_stores, y0, y1, hx_2, hy_2),
      ...);
 }
 
 // One trip of a wave down its strip: state set-up, the peeled start-up steps, the row loop, the partial last ring turn.
 // Returns whether any lane met operands the three-step division is not proven for (always false with FAST = false).
-template <int INNER, int GRAD, bool EDGE, bool POW2, bool CONT, bool FAST>
+template <int INNER, int GRAD, bool EDGE, bool POW2, bool CONT, bool FAST, bool SOR>
 __device__ __forceinline__ bool run_strip(const FusedArgs& a, int x, int xc, bool at_l, bool at_r, bool lane_stores, int y0,
                                           int y1, float hx_2, float hy_2)
 {
@@ -795,7 +815,7 @@ __device__ __forceinline__ bool run_strip(const FusedArgs& a, int x, int xc, boo
     }
 #pragma unroll
     for (int k = 0; k < INNER; ++k) {
-        s.dvc[k] = 0.f;
+        s.duvc[k] = v2f{0.f, 0.f};
 #pragma unroll
         for (int i = 0; i < 3; ++i) s.UV[k][i] = v2f{0.f, 0.f};
     }
@@ -838,14 +858,14 @@ __device__ __forceinline__ bool run_strip(const FusedArgs& a, int x, int xc, boo
     const int r_last = y1 - 1 + 2 + INNER;
     // start-up steps (a whole number of ring turns, so the row loop starts at ring position 0), then the row loop
     constexpr int kPeel = ((3 + 2 * INNER) / S::kRing) * S::kRing;
-    strip_startup<INNER, GRAD, EDGE, POW2, CONT, FAST>(s, a, r_first, x, xc, at_l, at_r, lane_stores, y0, y1, hx_2, hy_2,
+    strip_startup<INNER, GRAD, EDGE, POW2, CONT, FAST, SOR>(s, a, r_first, x, xc, at_l, at_r, lane_stores, y0, y1, hx_2, hy_2,
                                                        std::make_index_sequence<kPeel>{});
     int r = r_first + kPeel;
     for (; r + S::kRing - 1 <= r_last; r += S::kRing) {
-        strip_steps<INNER, GRAD, EDGE, POW2, CONT, FAST>(s, a, r, x, xc, at_l, at_r, lane_stores, y0, y1, hx_2, hy_2,
+        strip_steps<INNER, GRAD, EDGE, POW2, CONT, FAST, SOR>(s, a, r, x, xc, at_l, at_r, lane_stores, y0, y1, hx_2, hy_2,
                                                          std::make_index_sequence<S::kRing>{});
     }
-    strip_tail<INNER, GRAD, EDGE, POW2, CONT, FAST>(s, a, r, r_last, x, xc, at_l, at_r, lane_stores, y0, y1, hx_2, hy_2,
+    strip_tail<INNER, GRAD, EDGE, POW2, CONT, FAST, SOR>(s, a, r, r_last, x, xc, at_l, at_r, lane_stores, y0, y1, hx_2, hy_2,
                                                     std::make_index_sequence<S::kRing - 1>{});
     return guard_tripped(s.guard);
 }
@@ -859,7 +879,7 @@ constexpr bool kThreeStepDivision = true;
 #ifndef FLOW2D_FUSED_WAVES
 #define FLOW2D_FUSED_WAVES 2
 #endif
-template <int INNER, int GRAD, bool POW2, bool CONT>
+template <int INNER, int GRAD, bool POW2, bool CONT, bool SOR = false>
 __global__ __launch_bounds__(256, FLOW2D_FUSED_WAVES) void fused_outer_kernel(FusedArgs a)
 {
     using S = Strip<INNER, GRAD>;
@@ -918,13 +938,13 @@ __global__ __launch_bounds__(256, FLOW2D_FUSED_WAVES) void fused_outer_kernel(Fu
     if (bad)
         ;
     else if (__builtin_amdgcn_readfirstlane(edge))
-        bad = run_strip<INNER, GRAD, true, POW2, CONT, kThreeStepDivision>(a, x, xc, at_l, at_r, lane_stores, y0, y1, hx_2, hy_2);
+        bad = run_strip<INNER, GRAD, true, POW2, CONT, kThreeStepDivision, SOR>(a, x, xc, at_l, at_r, lane_stores, y0, y1, hx_2, hy_2);
     else
-        bad = run_strip<INNER, GRAD, false, POW2, CONT, kThreeStepDivision>(a, x, xc, at_l, at_r, lane_stores, y0, y1, hx_2, hy_2);
+        bad = run_strip<INNER, GRAD, false, POW2, CONT, kThreeStepDivision, SOR>(a, x, xc, at_l, at_r, lane_stores, y0, y1, hx_2, hy_2);
     if (__builtin_amdgcn_ballot_w64(bad) != 0ull) {
         // some lane's operands left the range the three-step division is proven for (or the launch's grid spacing did:
         // plain_only): the whole strip with the plain division (same stores, now from the reference's own arithmetic)
-        (void)run_strip<INNER, GRAD, true, POW2, CONT, false>(a, x, xc, at_l, at_r, lane_stores, y0, y1, hx_2, hy_2);
+        (void)run_strip<INNER, GRAD, true, POW2, CONT, false, SOR>(a, x, xc, at_l, at_r, lane_stores, y0, y1, hx_2, hy_2);
         // word 0 counts guard trips, word 1 the waves of launches that never tried the short forms
         if (a.fallback_count && lane == 0) atomicAdd(a.fallback_count + (a.plain_only ? 1 : 0), 1u);
     }
@@ -958,6 +978,12 @@ constexpr unsigned kFusedLdsPad = 0u;
         return 0;                                                                       \
     } while (0)
 
+#define FUSED_LAUNCH_SOR(N)                                                                   \
+    do {                                                                                      \
+        fused_outer_kernel<N, GRAD, POW2, CONT, true><<<grid, 256, kFusedLdsPad, stream>>>(a); \
+        return 0;                                                                             \
+    } while (0)
+
 template <int GRAD, bool POW2, bool CONT>
 int launch_for_inner_cont(int inner, dim3 grid, hipStream_t stream, const FusedArgs& a)
 {
@@ -968,6 +994,13 @@ int launch_for_inner_cont(int inner, dim3 grid, hipStream_t stream, const FusedA
     }
     return 1;
 #else
+    if (a.sor_omega != 0.f) {  // red-black half-sweeps: 2 or 4 stages = one or two iterations per launch (not for solve_2d_log)
+        if constexpr (GRAD != 3) {
+            if (inner == 2) FUSED_LAUNCH_SOR(2);
+            if (inner == 4) FUSED_LAUNCH_SOR(4);
+        }
+        return 1;
+    }
     switch (inner) {
         case 1: FUSED_LAUNCH(1);
         case 2: FUSED_LAUNCH(2);

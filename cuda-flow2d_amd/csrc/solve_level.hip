@@ -34,7 +34,7 @@ int launch_fused_outer(flow2d_context* ctx, int constancy, const float* f0, cons
                        const float* v, const float* du, const float* dv, size_t w, size_t h, size_t pitch_bytes,
                        float hx, float hy, float alpha, float e_smooth, float e_data, size_t inner, float* out_du,
                        float* out_dv, int rows_per_strip, bool zero_increment, const float* start_du,
-                       const float* start_dv);
+                       const float* start_dv, float sor_omega);
 }  // namespace flow2d
 
 namespace {
@@ -143,12 +143,20 @@ int flow2d_solve_level(flow2d_context* ctx, const float* frame_0, const float* f
 
     const bool sor = p->sor_omega != 0.f;
     if (sor && (!(p->sor_omega > 0.f) || !(p->sor_omega < 2.f))) return FLOW2D_ERR_INVALID_ARGUMENT;
-    if (sor && p->algorithm != FLOW2D_SOLVER_AUTO && p->algorithm != FLOW2D_SOLVER_PER_SWEEP) return FLOW2D_ERR_UNSUPPORTED;
+    if (sor && p->algorithm != FLOW2D_SOLVER_AUTO && p->algorithm != FLOW2D_SOLVER_PER_SWEEP && p->algorithm != FLOW2D_SOLVER_FUSED)
+        return FLOW2D_ERR_UNSUPPORTED;
     if (sor && p->data_constancy == FLOW2D_CONSTANCY_LOG_DERIVATIVES) return FLOW2D_ERR_UNSUPPORTED;
-    const int algorithm = sor ? FLOW2D_SOLVER_PER_SWEEP
-                              : solver_algorithm_for(p->algorithm, p->width, p->height, p->pitch_bytes,
-                                                     p->outer_iterations_count, p->inner_iterations_count,
-                                                     p->data_constancy, ctx->batch_count);
+    int algorithm = solver_algorithm_for(p->algorithm, p->width, p->height, p->pitch_bytes, p->outer_iterations_count,
+                                         p->inner_iterations_count, p->data_constancy, ctx->batch_count);
+    // Red-black SOR (opt-in): the temporally blocked form is the strip kernel with half-sweeps for stages (round 5: one launch
+    // per two iterations instead of a phi / ksi launch and two half-sweep launches per iteration).  The tiled and the
+    // single-workgroup kernels have no such stages, so AUTO gives every level to the strips -- any size runs there -- and
+    // only what the strips cannot address, or an explicit request, takes the half-sweep launches.
+    if (sor) {
+        const bool can_fuse = p->inner_iterations_count >= 1 && flow2d::fused_addressable(p->height, p->pitch_bytes);
+        if (p->algorithm == FLOW2D_SOLVER_FUSED && !can_fuse) return FLOW2D_ERR_UNSUPPORTED;
+        algorithm = (p->algorithm != FLOW2D_SOLVER_PER_SWEEP && can_fuse) ? FLOW2D_SOLVER_FUSED : FLOW2D_SOLVER_PER_SWEEP;
+    }
     if (algorithm < 0) return FLOW2D_ERR_UNSUPPORTED;
 
     flow2d_timing_slot* slot = nullptr;
@@ -202,7 +210,9 @@ int flow2d_solve_level(flow2d_context* ctx, const float* frame_0, const float* f
     float* pair_v[3] = {flow_dv, temp_dv, ksi};
     int source = 0;  // pair holding du, dv at the start of the outer iteration
     const size_t inner = p->inner_iterations_count;
-    const size_t chunks = algorithm == FLOW2D_SOLVER_FUSED ? std::max<size_t>(1, (inner + 4) / 5) : 0;
+    // (red-black iterations: two half-sweep stages each, at most two iterations per launch)
+    const size_t per_launch_max = sor ? 2 : 5;
+    const size_t chunks = algorithm == FLOW2D_SOLVER_FUSED ? std::max<size_t>(1, (inner + per_launch_max - 1) / per_launch_max) : 0;
     for (size_t i = 0; algorithm == FLOW2D_SOLVER_FUSED && i < p->outer_iterations_count; ++i) {
         int in = source;
         for (size_t c = 0; c < chunks; ++c) {
@@ -213,9 +223,10 @@ int flow2d_solve_level(flow2d_context* ctx, const float* frame_0, const float* f
             if (per_launch) FLOW2D_HIP_TRY(mark(ctx, slot));
             int st = flow2d::launch_fused_outer(ctx, p->data_constancy, frame_0, frame_1, flow_u, flow_v, pair_u[source],
                                                 pair_v[source], p->width, p->height, p->pitch_bytes, p->hx, p->hy,
-                                                p->equation_alpha, p->equation_smoothness, p->equation_data, sweeps,
-                                                pair_u[out], pair_v[out], rows, i == 0, c == 0 ? nullptr : pair_u[in],
-                                                c == 0 ? nullptr : pair_v[in]);
+                                                p->equation_alpha, p->equation_smoothness, p->equation_data,
+                                                sor ? 2 * sweeps : sweeps, pair_u[out], pair_v[out], rows, i == 0,
+                                                c == 0 ? nullptr : pair_u[in], c == 0 ? nullptr : pair_v[in],
+                                                sor ? p->sor_omega : 0.f);
             if (st != FLOW2D_OK) return st;
             if (per_launch) FLOW2D_HIP_TRY(mark(ctx, slot));
             in = out;

@@ -155,11 +155,12 @@ def test_phi_ksi_and_sweeps(ctx, flow2d, oracle, w, h, cw, ch, hx, hy):
 @pytest.mark.parametrize("w,h,cw,ch,hx,hy", [(4096, 2050, 4096, 2050, 1.0, 1.0), (2777, 3100, 2816, 3104, 1.25, 1.1),
                                               (16000, 530, 16000, 530, 7.3, 5.5), (1000, 300, 1024, 300, 1.0, 1.0)])
 def test_sweep_streaming_strips(ctx, flow2d, oracle, w, h, cw, ch, hx, hy):
-    """solve_2d and solve_2d_grad at level sizes that take the streaming form (8 Mpixel and more: strips of 62 columns walking down the level,
-    windows in registers, lane shifts for the x neighbours, mirrored halo loads instead of border selects): partial last
-    strips, strip heights that do not divide the level, levels inside larger containers, spacings that are no powers of
-    two -- bit-identical to the oracle's sweep, two sweeps in a row (the second reads what the first wrote).  (The last
-    size stays on the tile form: the same checks.)"""
+    """solve_2d and solve_2d_grad at level sizes that take the streaming form (8 Mpixel and more: strips of 64 aligned columns
+    walking down the level, windows in registers, lane shifts for the x neighbours with the strip's halo columns from two-lane
+    loads, mirrored halo loads instead of border selects): partial last strips, strip heights that do not divide the level,
+    levels inside larger containers, spacings that are no powers of two -- bit-identical to the oracle's sweep, two sweeps in
+    a row (the second reads what the first wrote), then a red-black SOR iteration in place (its half-sweeps stream too).  (The
+    last size stays on the tile form: the same checks.)"""
     f0, f1, u, v, du, dv = level_fields(oracle, w, h, 71)
     d = [up(ctx, a, cw, ch, 3.0) for a in (f0, f1, u, v, du, dv)]
     phi, ksi, tdu, tdv = (ctx.plane(cw, ch).fill_bytes(0x7f) for _ in range(4))
@@ -177,6 +178,12 @@ def test_sweep_streaming_strips(ctx, flow2d, oracle, w, h, cw, ch, hx, hy):
         ctx.solve_sweep(d[0], d[1], d[2], d[3], tdu, tdv, phi, ksi, w, h, hx, hy, 35.0, d[4], d[5], constancy)
         odu2, odv2 = oracle.solve_sweep(f0, f1, u, v, odu, odv, ophi, oksi, w, h, hx, hy, 35.0, constancy)
         assert np.array_equal(d[4].download(w, h), odu2) and np.array_equal(d[5].download(w, h), odv2), constancy
+        # opt-in red-black SOR, in place on what the two sweeps left
+        ctx.sor_iteration(*d, phi, ksi, w, h, hx, hy, 35.0, 1.6, constancy)
+        odu3, odv3 = oracle.sor_iteration(f0, f1, u, v, odu2, odv2, ophi, oksi, w, h, hx, hy, 35.0, 1.6, constancy)
+        got = d[4].download()
+        assert np.array_equal(got[:h, :w], odu3) and np.array_equal(d[5].download(w, h), odv3), ("sor", constancy)
+        assert np.all(got[h:, :] == 3.0) and np.all(got[:, w:] == 3.0)
 
 
 @pytest.mark.parametrize("window", [3, 5, 7])
@@ -448,24 +455,51 @@ def test_sor_iteration_and_level(ctx, oracle, w, h, cw, ch, omega, constancy):
     got = d[4].download()
     assert np.array_equal(got[:h, :w], odu) and np.array_equal(d[5].download(w, h), odv)
     assert np.all(got[h:, :] == 3.0) and np.all(got[:, w:] == 3.0)  # in place, level rectangle only
-    # the level loop with SOR iterations: result stays in du / dv
-    rdu, rdv = ctx.solve_level(*d[:4], d[4], d[5], phi, ksi, tdu, tdv, w, h, hx, hy, 3.5, 0.001, 0.001, 2, 3, constancy,
-                               0, sor_omega=omega)
-    assert rdu is d[4]
+    # the level loop with SOR iterations: as half-sweep launches (result stays in du / dv), and temporally blocked in the
+    # strip kernel (AUTO and FUSED: two iterations per launch, three iterations = launches of 2 + 1) -- the same bits
     odu, odv = oracle.solve_level_sor(f0, f1, u, v, w, h, hx, hy, 3.5, 0.001, 0.001, 2, 3, omega, constancy)
-    assert np.array_equal(rdu.download(w, h), odu) and np.array_equal(rdv.download(w, h), odv)
+    for algorithm in (1, 0, 2):
+        rdu, rdv = ctx.solve_level(*d[:4], d[4], d[5], phi, ksi, tdu, tdv, w, h, hx, hy, 3.5, 0.001, 0.001, 2, 3, constancy,
+                                   algorithm, sor_omega=omega)
+        if algorithm == 1:
+            assert rdu is d[4]
+        assert np.array_equal(rdu.download(w, h), odu) and np.array_equal(rdv.download(w, h), odv), algorithm
 
 
-def test_sor_rejects_bad_omega_and_fused(ctx, flow2d):
+def test_sor_rejects_bad_omega_and_kernels_without_half_sweeps(ctx, flow2d):
     w, h = 64, 48
     planes = [ctx.plane(w, h).fill_bytes(0) for _ in range(10)]
     for omega in (2.0, -0.5):
         with pytest.raises(flow2d.Flow2DError) as e:
             ctx.solve_level(*planes, w, h, 1.0, 1.0, 3.5, 0.001, 0.001, 1, 1, 0, 0, sor_omega=omega)
         assert e.value.status == 1
-    with pytest.raises(flow2d.Flow2DError) as e:  # the fused kernels are Jacobi only
-        ctx.solve_level(*planes, w, h, 1.0, 1.0, 3.5, 0.001, 0.001, 1, 1, 0, 2, sor_omega=1.2)
+    for algorithm in (3, 4):  # the single-workgroup and the tiled kernel are Jacobi only
+        with pytest.raises(flow2d.Flow2DError) as e:
+            ctx.solve_level(*planes, w, h, 1.0, 1.0, 3.5, 0.001, 0.001, 1, 1, 0, algorithm, sor_omega=1.2)
+        assert e.value.status == 5
+    with pytest.raises(flow2d.Flow2DError) as e:  # solve_2d_log has no red-black form
+        ctx.solve_level(*planes, w, h, 1.0, 1.0, 3.5, 0.001, 0.001, 1, 1, 3, 0, sor_omega=1.2)
     assert e.value.status == 5
+
+
+@pytest.mark.parametrize("constancy", [0, 1, 2])
+@pytest.mark.parametrize("w,h,iterations,omega", [(330, 250, 1, 1.9), (330, 250, 2, 1.0), (200, 136, 5, 1.5), (1100, 90, 4, 1.7),
+                                                  (64, 700, 3, 0.6)])
+def test_sor_in_the_strip_kernel(ctx, oracle, w, h, iterations, omega, constancy):
+    """The temporally blocked red-black SOR (round 5): half-sweeps as the stages of the fused strip kernel -- several strips
+    per column and per row, borders, one / two / several launches per outer iteration (five iterations = 2 + 2 + 1), power-of-two
+    and other grid spacings -- bit for bit against the oracle's in-place restatement."""
+    if constancy == 1:
+        w, h = (w + 15) // 16 * 16, (h + 7) // 8 * 8  # the reference's tile rule is defined on multiples of 16 x 8
+    f0, f1, u, v, _, _ = level_fields(oracle, w, h, 77)
+    d = [up(ctx, a, w, h) for a in (f0, f1, u, v)]
+    du, dv, phi, ksi, tdu, tdv = (ctx.plane(w, h) for _ in range(6))
+    for hx, hy in ((1.0, 1.0), (np.float32(1.25), np.float32(1.6))):
+        rdu, rdv = ctx.solve_level(*d, du, dv, phi, ksi, tdu, tdv, w, h, hx, hy, 35.0, 0.001, 0.001, 3, iterations, constancy,
+                                   2, sor_omega=omega)
+        odu, odv = oracle.solve_level_sor(f0, f1, u, v, w, h, hx, hy, 35.0, 0.001, 0.001, 3, iterations, omega, constancy)
+        assert np.array_equal(rdu.download(w, h), odu) and np.array_equal(rdv.download(w, h), odv), (hx, hy)
+    assert ctx.fused_fallbacks() == 0
 
 
 @pytest.mark.parametrize("w,h,cw,ch", [(100, 70, 128, 80), (257, 33, 300, 40), (7, 5, 8, 8), (1024, 300, 1024, 300)])

@@ -9,6 +9,9 @@ with them directly, bit for bit -- the CPU oracle is only a third party in this 
 Gradient and LogDerivatives cases use level sizes that are multiples of the reference's 16x8 thread block: off that
 grid its kernels read a shared-memory slot no thread wrote.
 """
+import json
+import os
+
 import numpy as np
 import pytest
 
@@ -16,6 +19,11 @@ from conftest import in_container, level_fields
 from test_oracle import rub_pair
 
 pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+# what FMA contraction moves rub1 / rub2 by (test_reference_kernels_with_fma_contraction_stay_near): the measured RMSE x 1.5
+# (placeholders until the figure of this round's first GPU pass is in: profiles/r05_experiments/fma_contraction_rmse.json)
+FMA_RMSE_BOUND_U = 5e-4
+FMA_RMSE_BOUND_V = 5e-4
 
 
 @pytest.fixture(scope="module")
@@ -191,7 +199,14 @@ def test_reference_kernels_with_fma_contraction_stay_near(flow2d, oracle, RK):
     with RK.RefKernels(584, 388, fma=True) as R:
         fu, fv, _, _ = R.compute_flow(f0, f1, *p)
     rmse = lambda a, b: float(np.sqrt(np.mean((a.astype(np.float64) - b) ** 2)))
-    assert rmse(u, fu) < 5e-4 and rmse(v, fv) < 5e-4
+    measured = {"rmse_u": rmse(u, fu), "rmse_v": rmse(v, fv), "max_abs_u": float(np.abs(u - fu).max()),
+                "max_abs_v": float(np.abs(v - fv).max())}
+    print("FMA contraction moves rub1 / rub2 (settings.xml values) by", measured)
+    out = os.path.join(ROOT, "gpurun_out")
+    if os.path.isdir(out):  # the figure DESIGN.md section 4 quotes (profiles/r05_experiments/fma_contraction_rmse.json)
+        with open(os.path.join(out, "fma_contraction_rmse.json"), "w") as f:
+            json.dump(measured, f)
+    assert measured["rmse_u"] < FMA_RMSE_BOUND_U and measured["rmse_v"] < FMA_RMSE_BOUND_V
 
 
 @pytest.mark.parametrize("constancy", ["log", "gradient"])

@@ -118,6 +118,7 @@ BENCH_KERNEL(k_x_permlane, ONE_IN_8("v_permlane32_swap_b32 v72, v73\n"))
 
 typedef void (*kern_t)(float*, Stamp*, int);
 
+static double g_clock_ghz = 0.0;  // shader clock of the last run(): s_memtime cycles per s_memrealtime tick (100 MHz), median over waves
 static double run(kern_t k, int waves_per_simd, float* out, Stamp* stamps, int iters, int num_cus)
 {
     const int threads = 256 * waves_per_simd;
@@ -127,9 +128,11 @@ static double run(kern_t k, int waves_per_simd, float* out, Stamp* stamps, int i
     hipDeviceSynchronize();
     std::vector<Stamp> h(waves);
     hipMemcpy(h.data(), stamps, waves * sizeof(Stamp), hipMemcpyDeviceToHost);
-    std::vector<double> cyc;
-    for (const Stamp& s : h) cyc.push_back((double)s.cycles / iters);
+    std::vector<double> cyc, clk;
+    for (const Stamp& s : h) cyc.push_back((double)s.cycles / iters), clk.push_back(s.real ? (double)s.cycles / (double)s.real * 0.1 : 0.0);
     std::sort(cyc.begin(), cyc.end());
+    std::sort(clk.begin(), clk.end());
+    g_clock_ghz = clk[clk.size() / 2];
     return cyc[cyc.size() / 2];
 }
 
@@ -193,6 +196,20 @@ int main()
     for (const Entry& e : table) {
         printf("%-72s", e.name);
         for (int w = 1; w <= 4; ++w) printf("  %dw: %6.2f", w, run(e.k, w, out, stamps, iters, cus) / e.instrs);
+        printf("\n");
+    }
+    // Does the chip hold its clock when the vector ALUs are kept busy?  Long launches (0.1-0.2 s each) of three streams at 1..4
+    // waves per SIMD: cycles per instruction per wave, the shader clock held, and what that makes in wave-instructions per
+    // SIMD and microsecond.
+    printf("\nlong launches: cycles per instruction per wave @ clock GHz -> instructions per SIMD per us\n");
+    const Entry longs[] = {{"64 plain (four chains)", k_all_plain, 64}, {"v_pk_fma_f32 chain", k_pkfma_chain, 64},
+                           {"a sweep in miniature", k_sweep_mini, 62}};
+    for (const Entry& e : longs) {
+        printf("%-30s", e.name);
+        for (int w = 1; w <= 4; ++w) {
+            const double c = run(e.k, w, out, stamps, iters * 25, cus) / e.instrs;
+            printf("  %dw: %5.2f @ %.2f -> %5.0f", w, c, g_clock_ghz, w / c * g_clock_ghz * 1e3);
+        }
         printf("\n");
     }
     return 0;

@@ -25,14 +25,18 @@ __device__ __forceinline__ int mirror(int i, int n)
 
 // VEC floats per lane; HALO: the sweep's halo lanes and rows (re-read from the neighbouring strips, as the real kernel does);
 // NIN planes read, NOUT written
-template <int VEC, bool HALO, int NIN, int NOUT>
+// (HALO as an int below: 0 none; 1 strips of 62 columns, one halo lane per side (rows start at 248-byte multiples); 2 strips
+//  of 64 ALIGNED columns, the halo rows as before, the two halo columns of the planes that need x neighbours -- all but one --
+//  by a second load instruction in which only lanes 0 and 63 are active)
+template <int VEC, int HALO, int NIN, int NOUT>
 __global__ __launch_bounds__(256) void stream_kernel(Planes p, int w, int h, int pitch, int rows, unsigned tiles_x, unsigned tiles_y,
                                                      unsigned rows_per_xcd)
 {
     const unsigned xcd = blockIdx.x & 7u, j = blockIdx.x >> 3;
     const unsigned tile_y = xcd * rows_per_xcd + j / tiles_x, tile_x = j % tiles_x;
     if (tile_y >= tiles_y) return;
-    constexpr int kHalo = HALO ? 1 : 0, kValid = 64 - 2 * kHalo;
+    constexpr int kHalo = HALO == 1 ? 1 : 0, kValid = 64 - 2 * kHalo;
+    constexpr int kRowHalo = HALO ? 1 : 0;
     const int lane = threadIdx.x & 63;
     const int strip = tile_x * 4 + (threadIdx.x >> 6);
     if (strip * kValid * VEC >= w) return;
@@ -42,11 +46,23 @@ __global__ __launch_bounds__(256) void stream_kernel(Planes p, int w, int h, int
     const int y0 = tile_y * rows, y1 = min(y0 + rows, h);
     typedef float vec __attribute__((ext_vector_type(VEC)));
     vec carry = 0.f;  // what the halo rows contribute, so that their loads cannot be dropped
-    for (int y = y0 - kHalo; y < y1 + kHalo; ++y) {
-        const size_t at = static_cast<size_t>(min(max(mirror(y, h), 0), h - 1)) * pitch + xm;
+    // HALO == 2: lane 0 fetches column x - 1, lane 63 column x + 1 (mirrored at the image border)
+    const bool halo_lane = HALO == 2 && (lane == 0 || lane == 63);
+    const int xh = min(max(mirror(lane == 0 ? x - 1 : x + 1, w), 0), w - 1);
+    for (int y = y0 - kRowHalo; y < y1 + kRowHalo; ++y) {
+        const size_t row = static_cast<size_t>(min(max(mirror(y, h), 0), h - 1)) * pitch;
+        const size_t at = row + xm;
         vec s = carry;
 #pragma unroll
         for (int i = 0; i < NIN; ++i) s += *reinterpret_cast<const vec*>(p.in[i] + at);
+        if (HALO == 2) {
+            float t = 0.f;
+            if (halo_lane) {
+#pragma unroll
+                for (int i = 0; i + 1 < NIN; ++i) t += p.in[i][row + xh];
+            }
+            s[0] += t;
+        }
         if (y < y0 || y >= y1) {
             carry = s * 1e-30f;
             continue;
@@ -65,10 +81,10 @@ struct Case {
     int vec, halo, nin, nout, rows;
 };
 
-template <int VEC, bool HALO, int NIN, int NOUT>
+template <int VEC, int HALO, int NIN, int NOUT>
 static float time_case(const Planes& p, int w, int h, int pitch, int rows, int reps)
 {
-    const int valid = (HALO ? 62 : 64) * VEC;
+    const int valid = (HALO == 1 ? 62 : 64) * VEC;
     const unsigned strips_x = (w + valid - 1) / valid, tiles_x = (strips_x + 3) / 4, tiles_y = (h + rows - 1) / rows;
     const unsigned rows_per_xcd = (tiles_y + 7) / 8;
     const dim3 grid(8 * rows_per_xcd * tiles_x);
@@ -106,23 +122,28 @@ int main(int argc, char** argv)
         for (int rows : {16, 32, 64, 128}) {
             char name[128];
             snprintf(name, sizeof name, "8 read + 2 written, 4 B per lane, halo lanes and rows, strips of %d rows", rows);
-            report(name, time_case<1, true, 8, 2>(p, w, h, pitch, rows, reps), 40.0);
+            report(name, time_case<1, 1, 8, 2>(p, w, h, pitch, rows, reps), 40.0);
+        }
+        for (int rows : {16, 32, 64, 128}) {
+            char name[128];
+            snprintf(name, sizeof name, "8 read + 2 written, 4 B per lane, aligned strips + halo rows + 2-lane halo loads, %d rows", rows);
+            report(name, time_case<1, 2, 8, 2>(p, w, h, pitch, rows, reps), 40.0);
         }
         for (int rows : {16, 64, 256}) {
             char name[128];
             snprintf(name, sizeof name, "8 read + 2 written, 4 B per lane, no halo, strips of %d rows", rows);
-            report(name, time_case<1, false, 8, 2>(p, w, h, pitch, rows, reps), 40.0);
+            report(name, time_case<1, 0, 8, 2>(p, w, h, pitch, rows, reps), 40.0);
         }
         for (int rows : {16, 64, 256}) {
             char name[128];
             snprintf(name, sizeof name, "8 read + 2 written, 16 B per lane, no halo, strips of %d rows", rows);
-            report(name, time_case<4, false, 8, 2>(p, w, h, pitch, rows, reps), 40.0);
+            report(name, time_case<4, 0, 8, 2>(p, w, h, pitch, rows, reps), 40.0);
         }
-        report("6 read + 2 written (the fused strip kernel's planes), 4 B per lane, 128 rows", time_case<1, false, 6, 2>(p, w, h, pitch, 128, reps), 32.0);
-        report("4 read + 1 written, 16 B per lane, 64 rows", time_case<4, false, 4, 1>(p, w, h, pitch, 64, reps), 20.0);
-        report("1 read + 1 written (copy), 4 B per lane, 64 rows", time_case<1, false, 1, 1>(p, w, h, pitch, 64, reps), 8.0);
-        report("1 read + 1 written (copy), 16 B per lane, 64 rows", time_case<4, false, 1, 1>(p, w, h, pitch, 64, reps), 8.0);
-        report("8 read + 0 written, 16 B per lane, 64 rows", time_case<4, false, 8, 0>(p, w, h, pitch, 64, reps), 32.0);
+        report("6 read + 2 written (the fused strip kernel's planes), 4 B per lane, 128 rows", time_case<1, 0, 6, 2>(p, w, h, pitch, 128, reps), 32.0);
+        report("4 read + 1 written, 16 B per lane, 64 rows", time_case<4, 0, 4, 1>(p, w, h, pitch, 64, reps), 20.0);
+        report("1 read + 1 written (copy), 4 B per lane, 64 rows", time_case<1, 0, 1, 1>(p, w, h, pitch, 64, reps), 8.0);
+        report("1 read + 1 written (copy), 16 B per lane, 64 rows", time_case<4, 0, 1, 1>(p, w, h, pitch, 64, reps), 8.0);
+        report("8 read + 0 written, 16 B per lane, 64 rows", time_case<4, 0, 8, 0>(p, w, h, pitch, 64, reps), 32.0);
         for (int i = 0; i < 8; ++i) (void)hipFree(const_cast<float*>(p.in[i]));
         for (int i = 0; i < 2; ++i) (void)hipFree(p.out[i]);
     }
