@@ -153,38 +153,22 @@ __global__ __launch_bounds__(256) void sweep_grey_kernel(const float* __restrict
 // Infinity Cache, where the short-lived waves of the tile form reach 5.4-5.6 TB/s; beyond it both forms are held at
 // 4.0-4.4 TB/s by HBM itself (ten separate plane streams; skewing the planes' base addresses against each other buys 3 %:
 // profiles/r04_experiments).  The streaming form takes the levels of 8 Mpixel and more.
-// Round 5: ALIGNED strips.  The round-4 strips were 62 columns wide with one halo lane per side, so every row segment of a
-// wave started at a multiple of 248 bytes and straddled three 128-byte lines instead of two; a no-arithmetic kernel in that
-// geometry (tools/ubench/stream10.hip) needs 148 us per 4096^2 pass, in strips of 64 ALIGNED columns whose two halo columns
-// come from a second load instruction with only lanes 0 and 63 active 134 us (no halo at all: 125 us; 8192^2: 590 / 549 / 514).
-// The halo value travels as the `old` operand of the lane shift (lane 0 / 63 keep it, bound_ctrl off), so the x neighbours
-// cost what they did.  The gradient term needs no wider halo any more: its tensor differentiates fx and ft inside 16-column
-// blocks (own value at the block edge, solve_2d.cu:816-841), and an aligned strip begins and ends on such an edge.
+constexpr int kSweepValid = 62;
 constexpr int kSweepAhead = 3;
-constexpr int kSweepStripRows = 64;
 constexpr size_t kSweepStreamMinPixels = size_t(8) << 20;
 
-// lane i <- lane i-1 (wave_shr:1); lane 0 keeps `halo`: the value of the column left of the strip, loaded by lane 0 itself
-__device__ __forceinline__ float sweep_from_left(float v, float halo)
+__device__ __forceinline__ float sweep_from_left(float v)  // lane i <- lane i-1
 {
-    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(halo), __float_as_int(v), 0x138, 0xf, 0xf, false));
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x138, 0xf, 0xf, true));
 }
-// lane i <- lane i+1 (wave_shl:1); lane 63 keeps `halo`: the column right of the strip
-__device__ __forceinline__ float sweep_from_right(float v, float halo)
+__device__ __forceinline__ float sweep_from_right(float v)  // lane i <- lane i+1
 {
-    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(halo), __float_as_int(v), 0x130, 0xf, 0xf, false));
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x130, 0xf, 0xf, true));
 }
 
 struct SweepRow {  // one image row of the planes a sweep reads, as loaded
     float f0, f1, u, v, du, dv, phi, ksi;
 };
-// the same row in the strip's halo column (lane 0: the column left of the strip, lane 63: right of it; other lanes: unused).
-// Only the row a step works on takes x neighbours, so the halo values are not part of the 3-row windows: they arrive through
-// a queue of their own, kSweepHaloAhead rows ahead.
-struct SweepHalo {
-    float f0, f1, u, v, du, dv, phi;
-};
-constexpr int kSweepHaloAhead = 2;
 
 struct SweepPlanes {
     const float* f0;
@@ -197,25 +181,16 @@ struct SweepPlanes {
     const float* ksi;
 };
 
-// FRAMES_AHEAD: the frames of row `row + 1` with the other planes of row `row` (the gradient term)
-// xm: the lane's (mirrored) column; xh: the halo column of lanes 0 / 63 (mirrored); halo_lane: lane 0 or 63
-template <bool FRAMES_AHEAD>
+// FRAMES_AHEAD: the frames of row `row + 1` with the other planes of row `row` (the gradient terms)
+// LOG: the frames as log(I + 1) (solve_2d_log, solve_2d.cu:519-535)
+template <bool FRAMES_AHEAD, bool LOG>
 __device__ __forceinline__ SweepRow sweep_load(const SweepPlanes& p, int row, int h, int pitch, int xm)
 {
-    const size_t rt = static_cast<size_t>(min(max(mirror_index(row, h), 0), h - 1)) * pitch;
-    const size_t rf = FRAMES_AHEAD ? static_cast<size_t>(min(max(mirror_index(row + 1, h), 0), h - 1)) * pitch : rt;
-    return SweepRow{p.f0[rf + xm], p.f1[rf + xm], p.u[rt + xm], p.v[rt + xm], p.du[rt + xm], p.dv[rt + xm], p.phi[rt + xm], p.ksi[rt + xm]};
-}
-template <bool FRAMES_AHEAD>
-__device__ __forceinline__ SweepHalo sweep_load_halo(const SweepPlanes& p, int row, int h, int pitch, int xh, bool halo_lane)
-{
-    SweepHalo r{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    if (halo_lane) {  // two active lanes: one 32-byte sector of the neighbouring strip's line per plane and side
-        const size_t rt = static_cast<size_t>(min(max(mirror_index(row, h), 0), h - 1)) * pitch;
-        const size_t rf = FRAMES_AHEAD ? static_cast<size_t>(min(max(mirror_index(row + 1, h), 0), h - 1)) * pitch : rt;
-        r = SweepHalo{p.f0[rf + xh], p.f1[rf + xh], p.u[rt + xh], p.v[rt + xh], p.du[rt + xh], p.dv[rt + xh], p.phi[rt + xh]};
-    }
-    return r;
+    const size_t at = static_cast<size_t>(min(max(mirror_index(row, h), 0), h - 1)) * pitch + xm;
+    const size_t af = FRAMES_AHEAD ? static_cast<size_t>(min(max(mirror_index(row + 1, h), 0), h - 1)) * pitch + xm : at;
+    const float a = p.f0[af], b = p.f1[af];
+    return SweepRow{LOG ? flow2d_math::log1p_frame(a) : a, LOG ? flow2d_math::log1p_frame(b) : b, p.u[at], p.v[at], p.du[at],
+                    p.dv[at], p.phi[at], p.ksi[at]};
 }
 
 // GRAD: solve_2d_grad (solve_2d.cu:683-952).  Its tensor needs fx, fy, ft of the rows y-1, y, y+1 (second derivatives inside
@@ -223,25 +198,33 @@ __device__ __forceinline__ SweepHalo sweep_load_halo(const SweepPlanes& p, int r
 // the other planes: a window slot of row q then carries the frames' row q + 1, the derivatives of row y + 1 are formed when
 // slot y + 1 arrives and kept in a 3-row window of their own.  Strips start on multiples of 16 rows, so the derivative row
 // above a strip's first row is never read (y % 8 == 0 takes the pixel's own value).
-// SOR: one red-black half-sweep of the opt-in successive over-relaxation IN PLACE (tdu == du, tdv == dv): only the pixels with
-// (x + y) % 2 == colour are relaxed and stored.  Their four neighbours have the other colour, which no wave writes in this
-// launch, so rows loaded ahead, halo rows and halo columns only ever deliver values that are still the old ones where they count.
-template <bool GRAD, bool SOR>
-__global__ __launch_bounds__(256, 4) void sweep_stream_kernel(SweepPlanes p, XcdTiles tiles, int w, int h, int pitch, int rows,
+// SOR (round 5): one red-black half-sweep of the opt-in successive over-relaxation IN PLACE (tdu == du, tdv == dv): only the
+// pixels with (x + y) % 2 == colour are relaxed and stored.  Their four neighbours have the other colour, which no wave writes
+// in this launch, so rows loaded ahead, halo rows and halo lanes only ever deliver values that are still the old ones where
+// they count.
+// MODE (round 5): 0 solve_2d; 1 solve_2d_grad; 2 the gradient term over TRUE neighbours (FLOW2D_CONSTANCY_GRADIENT_UNTILED, not
+// a reference mode): the tensor's differences of fx, fy, ft reach across block edges, reflected at the image border by selects
+// -- a derivative row computed from mirrored rows is NOT the mirrored derivative row (fy changes sign) -- and the derivative
+// row above the strip is formed in the prologue; 3 solve_2d_log (solve_2d.cu:391-669): as 1 on log(I + 1), and the first
+// derivatives, phi in the face weights and the flow neighbours of the sweep take the pixel's own value at a 16x8 block edge
+// (that kernel's halo offsets are 0: :448,462,476,490).
+template <int MODE, bool SOR>
+__global__ __launch_bounds__(256) void sweep_stream_kernel(SweepPlanes p, XcdTiles tiles, int w, int h, int pitch, int rows,
                                                            float hx, float hy, float alpha, float* tdu, float* tdv, float omega,
                                                            int colour)
 {
+    constexpr bool GRAD = MODE != 0, LOG = MODE == 3, UNTILED = MODE == 2;
     unsigned tile_x, tile_y;
     if (!xcd_tile(tiles, blockIdx.x, tile_x, tile_y)) return;
+    // halo lanes per side: one for the x neighbours of the planes; the gradient term also differentiates fx and ft in x, whose
+    // own x neighbours must be true values, so it keeps two
+    constexpr int kHalo = GRAD ? 2 : 1, kValid = 64 - 2 * kHalo;
     const int lane = threadIdx.x & 63;
     const int strip = tile_x * 4 + (threadIdx.x >> 6);
-    if (strip * 64 >= w) return;  // whole wave
-    const int x = strip * 64 + lane;
-    const int xm = min(max(mirror_index(x, w), 0), w - 1);  // lanes past the image load the reflected column: the last pixel's
-                                                            // right neighbour is then simply the next lane
-    const bool halo_lane = lane == 0 || lane == 63;
-    const int xh = min(max(mirror_index(lane == 0 ? x - 1 : x + 1, w), 0), w - 1);
-    const bool inside = x < w;
+    if (strip * kValid >= w) return;  // whole wave
+    const int x = strip * kValid - kHalo + lane;
+    const int xm = min(max(mirror_index(x, w), 0), w - 1);
+    const bool stores = lane >= kHalo && lane < 64 - kHalo && x < w;
     const int y0 = tile_y * rows, y1 = min(y0 + rows, h);
     using namespace flow2d_math;
     const float hx_2 = alpha / (hx * hx);
@@ -252,57 +235,74 @@ __global__ __launch_bounds__(256, 4) void sweep_stream_kernel(SweepPlanes p, Xcd
     // window slot = (row + 1) mod 3; rows y0 - 1 and y0 first, then the rows in flight
     SweepRow win[3];
     SweepRow ahead[kSweepAhead];
-    win[0] = sweep_load<GRAD>(p, y0 - 1, h, pitch, xm);
-    win[1] = sweep_load<GRAD>(p, y0, h, pitch, xm);
+    win[0] = sweep_load<GRAD, LOG>(p, y0 - 1, h, pitch, xm);
+    win[1] = sweep_load<GRAD, LOG>(p, y0, h, pitch, xm);
 #pragma unroll
-    for (int i = 0; i < kSweepAhead; ++i) ahead[i] = sweep_load<GRAD>(p, y0 + 1 + i, h, pitch, xm);
-    // halo queue: slot 0 = the row the next step works on
-    SweepHalo halo[kSweepHaloAhead];
-#pragma unroll
-    for (int i = 0; i < kSweepHaloAhead; ++i) halo[i] = sweep_load_halo<GRAD>(p, y0 + i, h, pitch, xh, halo_lane);
+    for (int i = 0; i < kSweepAhead; ++i) ahead[i] = sweep_load<GRAD, LOG>(p, y0 + 1 + i, h, pitch, xm);
 
-    // frame derivatives of one row from the frames' rows above / at / below it, solve_2d.cu:311-321 (:798-808)
-    // (c: the row whose derivatives are formed; hc_f0, hc_f1: the frames' halo values of that row)
-    auto derivatives = [&](float f0u, float f1u, const SweepRow& c, float hc_f0, float hc_f1, float f0d, float f1d, float& fx,
-                           float& fy, float& ft) {
-        fx = diff4(sweep_from_right(c.f0, hc_f0), sweep_from_left(c.f0, hc_f0), sweep_from_right(c.f1, hc_f1),
-                   sweep_from_left(c.f1, hc_f1), 4.f * hx);
-        fy = diff4(f0d, f0u, f1d, f1u, 4.f * hy);
-        ft = c.f1 - c.f0;
+    const bool x_lo = (x & 15) == 0, x_hi = (x & 15) == 15 || x == w - 1;
+    const bool x_hi15 = (x & 15) == 15;             // solve_2d_log's own neighbours: the block edge only (the image edge reflects)
+    const bool at_l = x == 0, at_r = x == w - 1;    // UNTILED: the reflect rule of the image border
+    // frame derivatives of row q from the frames' rows above / at / below it, solve_2d.cu:311-321 (:798-808; log: :519-535 with the
+    // block rule in x and y)
+    auto derivatives = [&](int q, float f0u, float f1u, float f0c, float f1c, float f0d, float f1d, float& fx, float& fy, float& ft) {
+        const float f0l0 = sweep_from_left(f0c), f0r0 = sweep_from_right(f0c), f1l0 = sweep_from_left(f1c), f1r0 = sweep_from_right(f1c);
+        if (LOG) {
+            const bool q_lo = (q & 7) == 0, q_hi = (q & 7) == 7;
+            fx = diff4(x_hi15 ? f0c : f0r0, x_lo ? f0c : f0l0, x_hi15 ? f1c : f1r0, x_lo ? f1c : f1l0, 4.f * hx);
+            fy = diff4(q_hi ? f0c : f0d, q_lo ? f0c : f0u, q_hi ? f1c : f1d, q_lo ? f1c : f1u, 4.f * hy);
+        } else {
+            fx = diff4(f0r0, f0l0, f1r0, f1l0, 4.f * hx);
+            fy = diff4(f0d, f0u, f1d, f1u, 4.f * hy);
+        }
+        ft = f1c - f0c;
     };
     // GRAD: (fx, fy, ft) of the rows y-1, y, y+1; slot of row q = (q + 1) mod 3 like the plane windows
     float dfx[3] = {0.f, 0.f, 0.f}, dfy[3] = {0.f, 0.f, 0.f}, dft[3] = {0.f, 0.f, 0.f};
     const float hx_1 = 1.0 / (2.0 * hx);  // evaluated in double, rounded to float (solve_2d.cu:868-869)
     const float hy_1 = 1.0 / (2.0 * hy);
-    const bool x_lo = (x & 15) == 0, x_hi = (x & 15) == 15 || x == w - 1;
     if (GRAD) {  // row y0: the frames' rows y0 - 1 (loaded here), y0 (in slot y0 - 1) and y0 + 1 (in slot y0)
-        const size_t at = static_cast<size_t>(min(max(mirror_index(y0 - 1, h), 0), h - 1)) * pitch + xm;
-        const SweepHalo h0 = sweep_load_halo<true>(p, y0 - 1, h, pitch, xh, halo_lane);  // (its frames: row y0)
-        derivatives(p.f0[at], p.f1[at], win[0], h0.f0, h0.f1, win[1].f0, win[1].f1, dfx[1], dfy[1], dft[1]);
-        dfx[0] = dfx[1], dfy[0] = dfy[1], dft[0] = dft[1];  // (row y0 - 1: never read, y0 % 8 == 0)
+        auto frame = [&](const float* plane, int row) {
+            const float value = plane[static_cast<size_t>(min(max(mirror_index(row, h), 0), h - 1)) * pitch + xm];
+            return LOG ? log1p_frame(value) : value;
+        };
+        const float a1 = frame(p.f0, y0 - 1), b1 = frame(p.f1, y0 - 1);
+        derivatives(y0, a1, b1, win[0].f0, win[0].f1, win[1].f0, win[1].f1, dfx[1], dfy[1], dft[1]);
+        dfx[0] = dfx[1], dfy[0] = dfy[1], dft[0] = dft[1];  // (row y0 - 1: never read by the block rule, y0 % 8 == 0)
+        if (UNTILED)  // true neighbours: row y0 - 1 from the frames' rows y0 - 2, y0 - 1, y0 (row 0 takes the row below instead)
+            derivatives(y0 - 1, frame(p.f0, y0 - 2), frame(p.f1, y0 - 2), a1, b1, win[0].f0, win[0].f1, dfx[0], dfy[0], dft[0]);
     }
 
-    auto step = [&](int y, int sy, const SweepRow& up, const SweepRow& c, const SweepRow& down, const SweepHalo& hc) {
+    auto step = [&](int y, int sy, const SweepRow& up, const SweepRow& c, const SweepRow& down) {
         float J11, J22, J12, J13, J23;
         if (!GRAD) {
             float fx, fy, ft;
-            derivatives(up.f0, up.f1, c, hc.f0, hc.f1, down.f0, down.f1, fx, fy, ft);
+            derivatives(y, up.f0, up.f1, c.f0, c.f1, down.f0, down.f1, fx, fy, ft);
             J11 = fx * fx, J22 = fy * fy, J12 = fx * fy, J13 = fx * ft, J23 = fy * ft;
         } else {
             // sy = slot of row y; derivatives of row y + 1 from the frames' rows y (slot y - 1), y + 1 (slot y), y + 2 (slot y + 1)
             const int su = (sy + 2) % 3, sd = (sy + 1) % 3;
-            derivatives(up.f0, up.f1, c, hc.f0, hc.f1, down.f0, down.f1, dfx[sd], dfy[sd], dft[sd]);
+            derivatives(y + 1, up.f0, up.f1, c.f0, c.f1, down.f0, down.f1, dfx[sd], dfy[sd], dft[sd]);
             const float fxc = dfx[sy], fyc = dfy[sy], ftc = dft[sy];
-            // cross-lane reads with every lane active, the block rule as selects afterwards (solve_2d.cu:816-841); lane 0 is
-            // a block's first column and lane 63 a block's last one, so what the shifts deliver there is never selected
-            const float fx_l0 = sweep_from_left(fxc, 0.f), fx_r0 = sweep_from_right(fxc, 0.f);
-            const float ft_l0 = sweep_from_left(ftc, 0.f), ft_r0 = sweep_from_right(ftc, 0.f);
-            const bool y_lo = (y & 7) == 0, y_hi = (y & 7) == 7 || y == h - 1;
-            const float fx_l = x_lo ? fxc : fx_l0, fx_r = x_hi ? fxc : fx_r0;
-            const float ft_l = x_lo ? ftc : ft_l0, ft_r = x_hi ? ftc : ft_r0;
-            const float fx_u = y_lo ? fxc : dfx[su], fx_d = y_hi ? fxc : dfx[sd];
-            const float fy_u = y_lo ? fyc : dfy[su], fy_d = y_hi ? fyc : dfy[sd];
-            const float ft_u = y_lo ? ftc : dft[su], ft_d = y_hi ? ftc : dft[sd];
+            // cross-lane reads with every lane active, the block rule as selects afterwards (solve_2d.cu:816-841)
+            const float fx_l0 = sweep_from_left(fxc), fx_r0 = sweep_from_right(fxc);
+            const float ft_l0 = sweep_from_left(ftc), ft_r0 = sweep_from_right(ftc);
+            float fx_l, fx_r, ft_l, ft_r, fx_u, fx_d, fy_u, fy_d, ft_u, ft_d;
+            if (UNTILED) {  // true neighbours, reflected at the image border
+                const bool top = y == 0, bot = y == h - 1;
+                fx_l = at_l ? fx_r0 : fx_l0, fx_r = at_r ? fx_l0 : fx_r0;
+                ft_l = at_l ? ft_r0 : ft_l0, ft_r = at_r ? ft_l0 : ft_r0;
+                fx_u = top ? dfx[sd] : dfx[su], fx_d = bot ? dfx[su] : dfx[sd];
+                fy_u = top ? dfy[sd] : dfy[su], fy_d = bot ? dfy[su] : dfy[sd];
+                ft_u = top ? dft[sd] : dft[su], ft_d = bot ? dft[su] : dft[sd];
+            } else {
+                const bool y_lo = (y & 7) == 0, y_hi = (y & 7) == 7 || y == h - 1;
+                fx_l = x_lo ? fxc : fx_l0, fx_r = x_hi ? fxc : fx_r0;
+                ft_l = x_lo ? ftc : ft_l0, ft_r = x_hi ? ftc : ft_r0;
+                fx_u = y_lo ? fxc : dfx[su], fx_d = y_hi ? fxc : dfx[sd];
+                fy_u = y_lo ? fyc : dfy[su], fy_d = y_hi ? fyc : dfy[sd];
+                ft_u = y_lo ? ftc : dft[su], ft_d = y_hi ? ftc : dft[sd];
+            }
             const float fxx = (fx_r - fx_l) * hx_1;
             const float fxy = (fx_d - fx_u) * hy_1;
             const float fyy = (fy_d - fy_u) * hy_1;
@@ -314,17 +314,20 @@ __global__ __launch_bounds__(256, 4) void sweep_stream_kernel(SweepPlanes p, Xcd
         const float yp = static_cast<float>(y < h - 1) * hy_2;
         const float ym = static_cast<float>(y > 0) * hy_2;
         const float pc = c.phi;
-        const float wxp = face_phi(sweep_from_right(pc, hc.phi), pc) * xp;
-        const float wxm = face_phi(sweep_from_left(pc, hc.phi), pc) * xm_w;
-        const float wyp = face_phi(down.phi, pc) * yp;
-        const float wym = face_phi(up.phi, pc) * ym;
+        const float su = c.u + c.du, sv = c.v + c.dv;  // the neighbours' full flow, formed once per pixel
+        const float p_r0 = sweep_from_right(pc), p_l0 = sweep_from_left(pc);
+        const float su_r0 = sweep_from_right(su), su_l0 = sweep_from_left(su), sv_r0 = sweep_from_right(sv), sv_l0 = sweep_from_left(sv);
+        // solve_2d_log: own value at the 16x8 block edge for phi and the flow as well (neighbourhood_log, :612-633)
+        const bool b_lo = LOG && (y & 7) == 0, b_hi = LOG && (y & 7) == 7, e_lo = LOG && x_lo, e_hi = LOG && x_hi15;
+        const float wxp = face_phi(e_hi ? pc : p_r0, pc) * xp;
+        const float wxm = face_phi(e_lo ? pc : p_l0, pc) * xm_w;
+        const float wyp = face_phi(b_hi ? pc : down.phi, pc) * yp;
+        const float wym = face_phi(b_lo ? pc : up.phi, pc) * ym;
         const float sumH = sum_weights(wxp, wxm, wyp, wym);
-        // the neighbours' full flow, formed once per pixel (and once per halo column)
-        const float su = c.u + c.du, sv = c.v + c.dv, hsu = hc.u + hc.du, hsv = hc.v + hc.dv;
-        const float sumU = sum_flux(wxp, wxm, wyp, wym, sweep_from_right(su, hsu), sweep_from_left(su, hsu), down.u + down.du,
-                                    up.u + up.du, c.u);
-        const float sumV = sum_flux(wxp, wxm, wyp, wym, sweep_from_right(sv, hsv), sweep_from_left(sv, hsv), down.v + down.dv,
-                                    up.v + up.dv, c.v);
+        const float sumU = sum_flux(wxp, wxm, wyp, wym, e_hi ? su : su_r0, e_lo ? su : su_l0, b_hi ? su : down.u + down.du,
+                                    b_lo ? su : up.u + up.du, c.u);
+        const float sumV = sum_flux(wxp, wxm, wyp, wym, e_hi ? sv : sv_r0, e_lo ? sv : sv_l0, b_hi ? sv : down.v + down.dv,
+                                    b_lo ? sv : up.v + up.dv, c.v);
         float r_du, r_dv;
         const float k = c.ksi;
         if (SOR)
@@ -333,7 +336,7 @@ __global__ __launch_bounds__(256, 4) void sweep_stream_kernel(SweepPlanes p, Xcd
         else
             point_update(k, update_denominator(k, J11, sumH), update_denominator(k, J22, sumH), J12, J13, J23, sumU, sumV, c.dv,
                          r_du, r_dv);
-        if (inside && (!SOR || ((x + y) & 1) == colour)) {
+        if (stores && (!SOR || ((x + y) & 1) == colour)) {
             const size_t at = static_cast<size_t>(y) * pitch + x;
             tdu[at] = r_du;
             tdv[at] = r_dv;
@@ -349,12 +352,8 @@ __global__ __launch_bounds__(256, 4) void sweep_stream_kernel(SweepPlanes p, Xcd
             win[(j + 2) % 3] = ahead[0];
 #pragma unroll
             for (int i = 0; i + 1 < kSweepAhead; ++i) ahead[i] = ahead[i + 1];
-            ahead[kSweepAhead - 1] = sweep_load<GRAD>(p, y + j + 1 + kSweepAhead, h, pitch, xm);
-            const SweepHalo hc = halo[0];
-#pragma unroll
-            for (int i = 0; i + 1 < kSweepHaloAhead; ++i) halo[i] = halo[i + 1];
-            halo[kSweepHaloAhead - 1] = sweep_load_halo<GRAD>(p, y + j + kSweepHaloAhead, h, pitch, xh, halo_lane);
-            step(y + j, (j + 1) % 3, win[j % 3], win[(j + 1) % 3], win[(j + 2) % 3], hc);
+            ahead[kSweepAhead - 1] = sweep_load<GRAD, LOG>(p, y + j + 1 + kSweepAhead, h, pitch, xm);
+            step(y + j, (j + 1) % 3, win[j % 3], win[(j + 1) % 3], win[(j + 2) % 3]);
         }
     }
 }
@@ -639,13 +638,18 @@ int launch_phi_ksi(flow2d_context* ctx, const float* f0, const float* f1, const 
 }
 
 // levels of 8 Mpixel and more (below, the ten planes sit in the Infinity Cache and the short-lived waves of the tile forms are faster)
-static bool sweep_streams(size_t w, size_t h) { return w >= 128 && h >= 8 && w * h >= kSweepStreamMinPixels; }
+static bool sweep_streams(size_t w, size_t h) { return w >= 2 * kSweepValid && h >= 8 && w * h >= kSweepStreamMinPixels; }
 static unsigned sweep_strip_rows()
 {
 #ifdef FLOW2D_DEV_BUILD  // (developer builds: strip height override, a multiple of 16)
     if (const char* e = std::getenv("FLOW2D_SWEEP_ROWS")) return std::max(16, std::atoi(e) / 16 * 16);
 #endif
-    return kSweepStripRows;
+    return 16;
+}
+static XcdTiles sweep_stream_tiles(size_t w, size_t h, int constancy)
+{
+    const unsigned valid = constancy == FLOW2D_CONSTANCY_GREY ? kSweepValid : kSweepValid - 2;  // (the gradient terms: two halo lanes per side)
+    return xcd_tiles(div_up(div_up(w, valid), 4), div_up(h, sweep_strip_rows()));
 }
 
 int launch_sweep(flow2d_context* ctx, int constancy, const float* f0, const float* f1, const float* u, const float* v,
@@ -663,19 +667,23 @@ int launch_sweep(flow2d_context* ctx, int constancy, const float* f0, const floa
         ctx->batch_count = n;
         return st;
     }
-    const bool streaming = sweep_streams(w, h);
-    if (streaming && (constancy == FLOW2D_CONSTANCY_GRADIENT || constancy == FLOW2D_CONSTANCY_GREY)) {
-        // streaming form: strips of 64 aligned columns, four to a workgroup, kSweepStripRows rows to a strip: the two halo rows
-        // of a strip are its y neighbours' rows, the two halo columns its x neighbours' -- the XCD-aware tile order keeps them
-        // in the same L2
-        const XcdTiles tiles = xcd_tiles(div_up(div_up(w, 64), 4), div_up(h, sweep_strip_rows()));
+    if (sweep_streams(w, h)) {
+        // streaming form: strips of 62 columns (60: the gradient terms), four to a workgroup, 16 rows to a strip: the two halo
+        // rows of a strip are its y neighbours' rows, which the XCD-aware tile order keeps in the same L2.  (us per 4096^2 /
+        // 8192^2 Grey sweep by strip height, one box: 8 rows 169 / 570, 16 160 / 564, 24 160 / 615, 33 167 / 610, 64 168 / 617,
+        // 128 171 / 599, 256 190 / 630.)
+        const XcdTiles tiles = sweep_stream_tiles(w, h, constancy);
         const SweepPlanes planes{f0, f1, u, v, du, dv, phi, ksi};
+        const dim3 grid(xcd_grid(tiles));
+        const int iw = (int)w, ih = (int)h, ip = (int)(pitch_bytes / 4), rows = (int)sweep_strip_rows();
         if (constancy == FLOW2D_CONSTANCY_GRADIENT)
-            sweep_stream_kernel<true, false><<<dim3(xcd_grid(tiles)), 256, 0, ctx->stream>>>(
-                planes, tiles, (int)w, (int)h, (int)(pitch_bytes / 4), (int)sweep_strip_rows(), hx, hy, alpha, tdu, tdv, 1.f, 0);
+            sweep_stream_kernel<1, false><<<grid, 256, 0, ctx->stream>>>(planes, tiles, iw, ih, ip, rows, hx, hy, alpha, tdu, tdv, 1.f, 0);
+        else if (constancy == FLOW2D_CONSTANCY_GRADIENT_UNTILED)
+            sweep_stream_kernel<2, false><<<grid, 256, 0, ctx->stream>>>(planes, tiles, iw, ih, ip, rows, hx, hy, alpha, tdu, tdv, 1.f, 0);
+        else if (constancy == FLOW2D_CONSTANCY_LOG_DERIVATIVES)
+            sweep_stream_kernel<3, false><<<grid, 256, 0, ctx->stream>>>(planes, tiles, iw, ih, ip, rows, hx, hy, alpha, tdu, tdv, 1.f, 0);
         else
-            sweep_stream_kernel<false, false><<<dim3(xcd_grid(tiles)), 256, 0, ctx->stream>>>(
-                planes, tiles, (int)w, (int)h, (int)(pitch_bytes / 4), (int)sweep_strip_rows(), hx, hy, alpha, tdu, tdv, 1.f, 0);
+            sweep_stream_kernel<0, false><<<grid, 256, 0, ctx->stream>>>(planes, tiles, iw, ih, ip, rows, hx, hy, alpha, tdu, tdv, 1.f, 0);
     } else if (constancy == FLOW2D_CONSTANCY_GRADIENT) {
         const XcdTiles tiles = xcd_tiles(div_up(w, kBlockX), div_up(h, kGradTileY));
         const dim3 grid(xcd_grid(tiles));
@@ -718,16 +726,18 @@ int launch_sor_iteration(flow2d_context* ctx, int constancy, const float* f0, co
         return st;
     }
     for (int colour = 0; colour < 2; ++colour) {
-        if (sweep_streams(w, h) && (constancy == FLOW2D_CONSTANCY_GRADIENT || constancy == FLOW2D_CONSTANCY_GREY)) {
-            // (round 5) the half-sweep as a streaming strip kernel, in place: the same rows and columns as the Jacobi form
-            const XcdTiles tiles = xcd_tiles(div_up(div_up(w, 64), 4), div_up(h, sweep_strip_rows()));
+        if (sweep_streams(w, h)) {
+            // (round 5) the half-sweep as a streaming strip kernel, in place: the same strips as the Jacobi form
+            const XcdTiles tiles = sweep_stream_tiles(w, h, constancy);
             const SweepPlanes planes{f0, f1, u, v, du, dv, phi, ksi};
+            const dim3 grid(xcd_grid(tiles));
+            const int iw = (int)w, ih = (int)h, ip = (int)(pitch_bytes / 4), rows = (int)sweep_strip_rows();
             if (constancy == FLOW2D_CONSTANCY_GRADIENT)
-                sweep_stream_kernel<true, true><<<dim3(xcd_grid(tiles)), 256, 0, ctx->stream>>>(
-                    planes, tiles, (int)w, (int)h, (int)(pitch_bytes / 4), (int)sweep_strip_rows(), hx, hy, alpha, du, dv, omega, colour);
+                sweep_stream_kernel<1, true><<<grid, 256, 0, ctx->stream>>>(planes, tiles, iw, ih, ip, rows, hx, hy, alpha, du, dv, omega, colour);
+            else if (constancy == FLOW2D_CONSTANCY_GRADIENT_UNTILED)
+                sweep_stream_kernel<2, true><<<grid, 256, 0, ctx->stream>>>(planes, tiles, iw, ih, ip, rows, hx, hy, alpha, du, dv, omega, colour);
             else
-                sweep_stream_kernel<false, true><<<dim3(xcd_grid(tiles)), 256, 0, ctx->stream>>>(
-                    planes, tiles, (int)w, (int)h, (int)(pitch_bytes / 4), (int)sweep_strip_rows(), hx, hy, alpha, du, dv, omega, colour);
+                sweep_stream_kernel<0, true><<<grid, 256, 0, ctx->stream>>>(planes, tiles, iw, ih, ip, rows, hx, hy, alpha, du, dv, omega, colour);
         } else if (constancy == FLOW2D_CONSTANCY_GRADIENT) {
             const XcdTiles tiles = xcd_tiles(div_up(w, kBlockX), div_up(h, kGradTileY));
         const dim3 grid(xcd_grid(tiles));

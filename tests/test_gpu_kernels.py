@@ -166,11 +166,16 @@ def test_sweep_streaming_strips(ctx, flow2d, oracle, w, h, cw, ch, hx, hy):
     phi, ksi, tdu, tdv = (ctx.plane(cw, ch).fill_bytes(0x7f) for _ in range(4))
     ctx.compute_phi_ksi(*d, w, h, hx, hy, 0.001, 0.001, phi, ksi)
     ophi, oksi = oracle.compute_phi_ksi(f0, f1, u, v, du, dv, w, h, hx, hy, 0.001, 0.001)
-    for constancy in (flow2d.GREY, flow2d.GRADIENT):
+    for constancy in (flow2d.GREY, flow2d.GRADIENT, flow2d.GRADIENT_UNTILED, flow2d.LOG_DERIVATIVES):
         d[4].upload(in_container(du, cw, ch, 3.0)), d[5].upload(in_container(dv, cw, ch, 3.0))
         tdu.fill_bytes(0x7f), tdv.fill_bytes(0x7f)
         ctx.solve_sweep(*d, phi, ksi, w, h, hx, hy, 35.0, tdu, tdv, constancy)
         odu, odv = oracle.solve_sweep(f0, f1, u, v, du, dv, ophi, oksi, w, h, hx, hy, 35.0, constancy)
+        if constancy == flow2d.LOG_DERIVATIVES:
+            # log(I + 1) comes from the device library here and from the CPU's libm in the oracle (last-place differences);
+            # the bit-for-bit check of the streaming log form is against the reference's own kernel (test_gpu_reference.py)
+            assert float(np.abs(tdu.download(w, h) - odu).max()) < 1e-5 and float(np.abs(tdv.download(w, h) - odv).max()) < 1e-5
+            continue
         assert np.array_equal(tdu.download(w, h), odu) and np.array_equal(tdv.download(w, h), odv), constancy
         # nothing outside the level is written
         full = tdu.download()

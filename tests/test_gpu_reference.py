@@ -119,6 +119,25 @@ def test_solver_kernels(ctx, flow2d, oracle, RK, w, h, cw, ch):
                 assert bits_equal(odu, rdu) and bits_equal(odv, rdv)
 
 
+def test_streaming_sweeps_against_the_reference_kernels(ctx, flow2d, oracle, RK):
+    """The per-sweep kernels in their streaming form (levels of 8 Mpixel and more; round 5: solve_2d_log streams too) against
+    the reference's own solve_2d / solve_2d_grad / solve_2d_log at 4096 x 2048, bit for bit."""
+    w, h = 4096, 2048
+    f0, f1, u, v, du, dv = level_fields(oracle, w, h, 58)
+    hx, hy = np.float32(1.0), np.float32(1.0)
+    with RK.RefKernels(w, h) as R:
+        d = [up(ctx, a, w, h) for a in (f0, f1, u, v, du, dv)]
+        phi, ksi, tdu, tdv = (ctx.plane(w, h) for _ in range(4))
+        ctx.compute_phi_ksi(*d, w, h, hx, hy, 0.001, 0.001, phi, ksi)
+        rphi, rksi = R.phi_ksi(f0, f1, u, v, du, dv, hx, hy, 0.001, 0.001)
+        assert bits_equal(phi.download(w, h), rphi) and bits_equal(ksi.download(w, h), rksi)
+        for c in (flow2d.GREY, flow2d.GRADIENT, flow2d.LOG_DERIVATIVES):
+            alpha = 35.0 if c != flow2d.LOG_DERIVATIVES else 0.01
+            ctx.solve_sweep(*d, phi, ksi, w, h, hx, hy, alpha, tdu, tdv, c)
+            rdu, rdv = R.sweep(ref_constancy(flow2d, RK, c), f0, f1, u, v, du, dv, rphi, rksi, hx, hy, alpha)
+            assert bits_equal(tdu.download(w, h), rdu) and bits_equal(tdv.download(w, h), rdv), c
+
+
 @pytest.mark.parametrize("algorithm", [1, 2, 3, 4, 0])
 @pytest.mark.parametrize("constancy", [0, 1, 3])
 @pytest.mark.parametrize("outer,inner", [(2, 3), (3, 5), (1, 7)])
