@@ -4,6 +4,7 @@
 #include <array>
 #include <cmath>
 #include <cstdlib>
+#include <cstring>
 #include <map>
 
 #include "common.hpp"
@@ -117,7 +118,18 @@ static FusedPlan fused_plan_search(const flow2d_context* ctx, size_t w, size_t h
         const double cost = rounds(blocks_x * ny * batch, kEdgeCost * ((double)rows + halo));
         if (cost < best - 1e-9) best = cost, plan = FusedPlan{(int)rows, (int)rows, (int)ny, (int)blocks_x, (int)(blocks_x * ny)};
     }
+#ifdef FLOW2D_DEV_BUILD  // developer override: exactly this many strips per interior column (border-aware plan), whatever it costs
+    // (FLOW2D_FUSED_NY=ny[,height]: only for levels of that height, default 4096)
+    static const long env_ny = std::getenv("FLOW2D_FUSED_NY") ? std::atol(std::getenv("FLOW2D_FUSED_NY")) : 0;
+    static const long env_ny_h = (std::getenv("FLOW2D_FUSED_NY") && std::strchr(std::getenv("FLOW2D_FUSED_NY"), ','))
+                                     ? std::atol(std::strchr(std::getenv("FLOW2D_FUSED_NY"), ',') + 1) : 4096;
+    const long forced_ny = (long)h == env_ny_h ? env_ny : 0;
+    if (forced_ny >= 3) best = 1e300;
+#else
+    const long forced_ny = 0;
+#endif
     for (long ny = 3; blocks_x >= 3 && ny <= (long)h / 2; ++ny) {  // border-aware: ny strips per interior column
+        if (forced_ny >= 3 && ny != forced_ny) continue;
         // rows_edge = (rows_interior + halo) / kEdgeCost - halo and 2 rows_edge + (ny - 2) rows_interior = h
         const double ri_real = ((double)h + 2.0 * halo - 2.0 * halo / kEdgeCost) / ((double)(ny - 2) + 2.0 / kEdgeCost);
         long re = (long)std::floor((ri_real + halo) / kEdgeCost - halo);

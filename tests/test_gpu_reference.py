@@ -20,10 +20,10 @@ from test_oracle import rub_pair
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-# what FMA contraction moves rub1 / rub2 by (test_reference_kernels_with_fma_contraction_stay_near): the measured RMSE x 1.5
-# (placeholders until the figure of this round's first GPU pass is in: profiles/r05_experiments/fma_contraction_rmse.json)
-FMA_RMSE_BOUND_U = 5e-4
-FMA_RMSE_BOUND_V = 5e-4
+# what FMA contraction moves rub1 / rub2 by (test_reference_kernels_with_fma_contraction_stay_near): measured on the MI355X
+# (profiles/r05_experiments/fma_contraction_rmse.json: RMSE 1.131e-4 in u, 9.01e-5 in v, largest single difference 0.018 px) x 1.5
+FMA_RMSE_BOUND_U = 1.7e-4
+FMA_RMSE_BOUND_V = 1.36e-4
 
 
 @pytest.fixture(scope="module")
@@ -206,9 +206,10 @@ def test_compute_flow(flow2d, oracle, RK, pair, p, constancy):
 
 def test_reference_kernels_with_fma_contraction_stay_near(flow2d, oracle, RK):
     """For information and as a guard on the no-contraction choice: the same reference sources compiled with the
-    compiler's default FMA contraction (what nvcc's -fmad=true resembles) move rub1/rub2's flow by about 1e-4 RMSE
-    (SURVEY 8c measured 1.1e-4 with a CPU build), i.e. the 1e-4 gate of BASELINE.json is the contraction noise
-    floor; the product follows the non-contracted build exactly (test_compute_flow)."""
+    compiler's default FMA contraction (what nvcc's -fmad=true, the reference Makefile's default, resembles) move rub1 / rub2's
+    flow by 1.13e-4 (u) and 9.0e-5 (v) RMSE (SURVEY 8c measured 1.1e-4 with a CPU build): the 1e-4 gate of BASELINE.json lies
+    INSIDE the reference's own contraction noise and can be neither affirmed nor denied against a binary this image cannot
+    build; the product follows the non-contracted build exactly (test_compute_flow)."""
     if not RK.available(fma=True):
         pytest.skip("no FMA-contracted reference build")
     f0, f1 = rub_pair()
