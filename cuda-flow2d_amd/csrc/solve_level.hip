@@ -234,7 +234,11 @@ int flow2d_solve_level(flow2d_context* ctx, const float* frame_0, const float* f
         }
         source = in;
     }
-    // Tiled path: one launch per outer iteration, ping-pong between the caller's two pairs
+    // Tiled path: one launch per outer iteration, ping-pong between the caller's two pairs.  (Round 5 tried TWO outer
+    // iterations per launch of the 8 x 8 and 16 x 16 tiles over a halo of 2 (inner + 1) pixels -- half the launches of the
+    // launch-bound levels: the regions of 32 x 32 / 40 x 40 pixels recompute 16x / 6x the tile and a lone 1024^2 pair took 0.76
+    // instead of 0.71 ms, a lone 4096^2 pair 4.24 instead of 4.08-4.17, the pipelined rates 1 % less:
+    // profiles/r05_experiments/tile_two_outer_ab.txt.  Not kept.)
     for (size_t i = 0; algorithm == FLOW2D_SOLVER_TILED && i < p->outer_iterations_count; ++i) {
         const int out = source == 0 ? 1 : 0;
         if (per_launch) FLOW2D_HIP_TRY(mark(ctx, slot));

@@ -42,3 +42,18 @@ bench.timed_region(job, batch, torch, 20, 3, 1)
 job.close()
 rate("C  plain planes after a closed config-3 job")
 rate("C' torch tensor after a closed config-3 job", local)
+
+# ---- which of the sampling legs leaves the process slower? (round 5: the batch leg read 8-9 % low after them) --------------------
+import types  # noqa: E402
+
+first_pair = bench.workload_pair("cfg3_4096_gradient", cfg3, 0)
+params = flow2d.OpticalFlow.params(cfg3["levels"], cfg3["scale"], cfg3["outer"], cfg3["inner"], cfg3["alpha"], 0.001, 0.001,
+                                   cfg3["median"], cfg3["sigma"], 0)
+sample = types.SimpleNamespace(flow2d=flow2d, cfg=cfg3, local_rank=0, first_pair=first_pair, params=params, sync=lambda: None)
+bench.measured_copy_peak(flow2d, 0)
+rate("D  after measured_copy_peak (512 MiB device-to-device copy)")
+bench.per_sweep_sample(sample)
+rate("E  after per_sweep_sample (per-sweep launches, a context of its own)")
+bench.roofline_sample(sample)
+rate("F  after roofline_sample (eager passes with per-launch events, then a replayed lone pair)")
+rate("F' again")
