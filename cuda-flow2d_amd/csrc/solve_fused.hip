@@ -40,6 +40,16 @@ static unsigned int* stamp_counter() { return reinterpret_cast<unsigned int*>(st
 
 bool fused_supports(size_t inner) { return inner >= 1 && inner <= 5; }
 
+// Stage W multiplies the sum of two robustifiers by HALF the neighbour weight alpha / h^2 instead of halving the sum first: the
+// same bits as long as halving the weight is exact, i.e. the weight is zero or a normal number with room below it
+// (solve_fused_kernel.hpp, stage W).  A weight below 2^-100 (alpha of 1e-30 and less) sends the level to the other kernels.
+bool fused_weights_ok(float hx, float hy, float alpha)
+{
+    const float wx = alpha / (hx * hx), wy = alpha / (hy * hy);
+    auto ok = [](float w) { return w == 0.f || (std::fabs(w) >= 0x1p-100f && std::isfinite(w)) || std::isnan(w); };
+    return ok(wx) && ok(wy);
+}
+
 // The fused kernel addresses a plane through a buffer descriptor with 32-bit byte offsets (row offset as the scalar
 // offset, column as a 32-bit vector offset): the plane, height x pitch bytes, must stay below 4 GiB.
 bool fused_addressable(size_t h, size_t pitch_bytes) { return h != 0 && pitch_bytes <= 0xffffffffull / h; }
@@ -156,6 +166,7 @@ int launch_fused_outer(flow2d_context* ctx, int constancy, const float* f0, cons
     // sor_omega != 0: the `inner` stages are red-black half-sweeps (2 or 4: one or two iterations per launch)
     if (!fused_supports(inner) || !fused_addressable(h, pitch_bytes)) return FLOW2D_ERR_UNSUPPORTED;
     if (sor_omega != 0.f && (inner != 2 && inner != 4)) return FLOW2D_ERR_UNSUPPORTED;
+    if (!fused_weights_ok(hx, hy, alpha)) return FLOW2D_ERR_UNSUPPORTED;
     // rows_per_strip > 0: uniform strips of that height (developer override); 0: the planner's choice
     // A lock-step group whose every instance fills the chip on its own with long strips (128 rows and more: 4096^2 and
     // up) is launched instance by instance: nothing is gained by one launch of several rounds, and the strips are then
@@ -178,6 +189,7 @@ int launch_fused_outer(flow2d_context* ctx, int constancy, const float* f0, cons
                 e_data,
                 2.f * hx, 2.f * hy, 4.f * hx, 4.f * hy, 1.f / (2.f * hx), 1.f / (2.f * hy), 1.f / (4.f * hx), 1.f / (4.f * hy),
                 static_cast<float>(1.0 / (2.0 * hx)), static_cast<float>(1.0 / (2.0 * hy)), alpha / (hx * hx), alpha / (hy * hy),
+                0.5f * (alpha / (hx * hx)), 0.5f * (alpha / (hy * hy)),
                 sor_omega, 1.f - sor_omega,
                 0, plan.blocks, 0, static_cast<unsigned long long>(ctx->batch_stride_floats),
 #ifdef FLOW2D_FUSED_STAMPS

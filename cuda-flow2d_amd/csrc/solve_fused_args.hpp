@@ -43,6 +43,7 @@ struct FusedArgs {
     float inv_two_hx, inv_two_hy, inv_four_hx, inv_four_hy;  // their reciprocals (exact when h is a power of two)
     float hx_1, hy_1;                                // float(1.0 / (2.0 * h)), solve_2d.cu:868-869
     float hx_2, hy_2;                                // alpha / (h * h), solve_2d.cu:337-340
+    float half_hx_2, half_hy_2;                      // ... halved (exactly: the launcher checks), what stage W multiplies with
     // opt-in red-black SOR (not a reference mode): omega in (0, 2) makes the launch's `inner` stages half-sweeps; 0 = Jacobi.
     // sor_keep = 1.f - omega, evaluated on the host in float like the per-sweep kernel and the oracle do
     float sor_omega, sor_keep;

@@ -63,7 +63,7 @@
 #if (defined(FLOW2D_FUSED_STAMPS) || defined(FLOW2D_FUSED_SHORT_RING) || defined(FLOW2D_FUSED_WAVES) || defined(FLOW2D_FUSED_COMPUTE_ONLY) || defined(FLOW2D_FUSED_MEMORY_ONLY) ||          \
      defined(FLOW2D_FUSED_TURN_SHIFT) || defined(FLOW2D_FUSED_PLAIN_DIVISION) || defined(FLOW2D_FUSED_NO_PINS) ||          \
      defined(FLOW2D_FUSED_DEV) || defined(FLOW2D_FUSED_EDGE_COST) || defined(FLOW2D_FUSED_NO_SPLIT) ||                    \
-     defined(FLOW2D_FUSED_PLAIN_ORDER) || defined(FLOW2D_FUSED_NO_PACKED) || defined(FLOW2D_FUSED_INJECT)) &&                                                                               \
+     defined(FLOW2D_FUSED_PLAIN_ORDER) || defined(FLOW2D_FUSED_NO_PACKED) || defined(FLOW2D_FUSED_INJECT) || defined(FLOW2D_FUSED_FULL_WEIGHTS)) &&                                                                               \
     !defined(FLOW2D_DEV_BUILD)
 #error "the fused kernel's timing probes need -DFLOW2D_DEV_BUILD: they are not part of the product library"
 #endif
@@ -592,16 +592,32 @@ __device__ __forceinline__ void strip_step(Strip<INNER, GRAD>& s, const FusedArg
             pU = top ? s.phiw[s1] : s.phiw[s0];
             pD = bot ? s.phiw[s0] : s.phiw[s1];
         }
+        // hx_2, hy_2 hold HALF the neighbour weight alpha / h^2 here (FusedArgs::half_hx_2): face_phi (a + b) / 2.f times the weight
+        // is the one rounding of (a + b) w / 2 either way -- dividing a sum of two robustifiers by two is exact (they are 0 or at
+        // least 2.7e-20: 1 / (2 sqrt(FLT_MAX))), and so is halving the weight (the launcher refuses weights below 2^-100) -- so
+        // (a + b) * (w / 2) has the same bits in one instruction less per face pair (round 5)
         const float yp = EDGE ? static_cast<float>(rw < h - 1) * hy_2 : hy_2;
         const float ym = EDGE ? static_cast<float>(rw > 0) * hy_2 : hy_2;
         // face_phi * (xp, xm), solve_2d.cu:337-346: xp = [x < w-1] * alpha / hx^2, xm = [x > 0] * alpha / hx^2; an interior
         // strip has no image border, so both are the uniform alpha / hx^2 there
         if (!EDGE && GRAD != 3) {  // the neighbours as DPP operands of the two additions
+#ifdef FLOW2D_FUSED_FULL_WEIGHTS  // (developer A/B: the literal (a + b) / 2.f * w of rounds 1-4; hx_2, hy_2 are the full weights then)
             c.wx = v2f{scalar_only(from_right(pc) + pc), scalar_only(from_left(pc) + pc)} / 2.f * v2f{hx_2, hx_2};
+#else
+            c.wx = v2f{scalar_only(from_right(pc) + pc), scalar_only(from_left(pc) + pc)} * v2f{hx_2, hx_2};
+#endif
         } else {
+#ifdef FLOW2D_FUSED_FULL_WEIGHTS
             c.wx = (p_rl + pc) / 2.f * (EDGE ? v2f{at_r ? 0.f : hx_2, at_l ? 0.f : hx_2} : v2f{hx_2, hx_2});
+#else
+            c.wx = (p_rl + pc) * (EDGE ? v2f{at_r ? 0.f : hx_2, at_l ? 0.f : hx_2} : v2f{hx_2, hx_2});
+#endif
         }
+#ifdef FLOW2D_FUSED_FULL_WEIGHTS
         c.wy = v2f{face_phi(pD, pc) * yp, face_phi(pU, pc) * ym};
+#else
+        c.wy = (v2f{pD, pU} + pc) * v2f{yp, ym};
+#endif
         const float sumH = sum_weights(c.wx.x, c.wx.y, c.wy.x, c.wy.y);
         const float c_ksi = s.p_ksi;
         c.uvc = s.uvw[s2];
@@ -929,7 +945,11 @@ __global__ __launch_bounds__(256, FLOW2D_FUSED_WAVES) void fused_outer_kernel(Fu
     if (y0 >= y1) return;  // (a middle strip the rounding of rows_interior left empty)
     const bool at_l = (x == 0), at_r = (x == a.w - 1);
     const bool lane_stores = lane >= S::kHalo && lane < 64 - S::kHalo && x < a.w;
+#ifdef FLOW2D_FUSED_FULL_WEIGHTS
     const float hx_2 = a.hx_2, hy_2 = a.hy_2;
+#else
+    const float hx_2 = a.half_hx_2, hy_2 = a.half_hy_2;  // HALF the neighbour weights: see stage W
+#endif
 
     // does any row or column this wave touches sit on an image border?  (a superset test is fine)
     const int x_first = strip_x * S::kValid - S::kHalo;

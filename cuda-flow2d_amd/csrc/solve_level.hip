@@ -24,11 +24,12 @@ int launch_small_level(flow2d_context* ctx, int constancy, const float* f0, cons
                        float e_smooth, float e_data, size_t outer, size_t inner, float* out_du, float* out_dv);
 bool fused_supports(size_t inner);
 bool fused_addressable(size_t h, size_t pitch_bytes);
+bool fused_weights_ok(float hx, float hy, float alpha);
 bool tiled_supports(int constancy, size_t inner);
 int launch_tiled_outer(flow2d_context* ctx, int constancy, const float* f0, const float* f1, const float* u,
                        const float* v, const float* du, const float* dv, size_t w, size_t h, size_t pitch_bytes, float hx,
                        float hy, float alpha, float e_smooth, float e_data, size_t inner, float* out_du, float* out_dv,
-                       bool zero_increment);
+                       bool zero_increment, float sor_omega);
 
 int launch_fused_outer(flow2d_context* ctx, int constancy, const float* f0, const float* f1, const float* u,
                        const float* v, const float* du, const float* dv, size_t w, size_t h, size_t pitch_bytes,
@@ -143,21 +144,35 @@ int flow2d_solve_level(flow2d_context* ctx, const float* frame_0, const float* f
 
     const bool sor = p->sor_omega != 0.f;
     if (sor && (!(p->sor_omega > 0.f) || !(p->sor_omega < 2.f))) return FLOW2D_ERR_INVALID_ARGUMENT;
-    if (sor && p->algorithm != FLOW2D_SOLVER_AUTO && p->algorithm != FLOW2D_SOLVER_PER_SWEEP && p->algorithm != FLOW2D_SOLVER_FUSED)
-        return FLOW2D_ERR_UNSUPPORTED;
     if (sor && p->data_constancy == FLOW2D_CONSTANCY_LOG_DERIVATIVES) return FLOW2D_ERR_UNSUPPORTED;
     int algorithm = solver_algorithm_for(p->algorithm, p->width, p->height, p->pitch_bytes, p->outer_iterations_count,
                                          p->inner_iterations_count, p->data_constancy, ctx->batch_count);
-    // Red-black SOR (opt-in): the temporally blocked form is the strip kernel with half-sweeps for stages (round 5: one launch
-    // per two iterations instead of a phi / ksi launch and two half-sweep launches per iteration).  The tiled and the
-    // single-workgroup kernels have no such stages, so AUTO gives every level to the strips -- any size runs there -- and
-    // only what the strips cannot address, or an explicit request, takes the half-sweep launches.
+    // Red-black SOR (opt-in): temporally blocked in the strip kernel and in the LDS tiles with half-sweeps for stages (round 5: one
+    // launch per two iterations instead of a phi / ksi launch and two half-sweep launches per iteration).  AUTO picks tiles or
+    // strips by the level's size like for Jacobi (the tiles up to two iterations per outer iteration; the single-workgroup kernel
+    // has no such stages); only what the strips cannot address, or an explicit request, takes the half-sweep launches.
     if (sor) {
+        // stages of a launch = half-sweeps: the tiles hold up to four (two iterations), the strips chain launches of four
+        const size_t stages = 2 * p->inner_iterations_count;
         const bool can_fuse = p->inner_iterations_count >= 1 && flow2d::fused_addressable(p->height, p->pitch_bytes);
+        const bool can_tile = p->inner_iterations_count >= 1 && stages <= 4 && flow2d::tiled_supports(p->data_constancy, stages);
+        const bool auto_tiles = can_tile && solver_algorithm_for(FLOW2D_SOLVER_AUTO, p->width, p->height, p->pitch_bytes,
+                                                                 p->outer_iterations_count, stages, p->data_constancy,
+                                                                 ctx->batch_count) == FLOW2D_SOLVER_TILED;
         if (p->algorithm == FLOW2D_SOLVER_FUSED && !can_fuse) return FLOW2D_ERR_UNSUPPORTED;
-        algorithm = (p->algorithm != FLOW2D_SOLVER_PER_SWEEP && can_fuse) ? FLOW2D_SOLVER_FUSED : FLOW2D_SOLVER_PER_SWEEP;
+        if (p->algorithm == FLOW2D_SOLVER_TILED && !can_tile) return FLOW2D_ERR_UNSUPPORTED;
+        if (p->algorithm == FLOW2D_SOLVER_SINGLE_WORKGROUP) return FLOW2D_ERR_UNSUPPORTED;
+        if (p->algorithm == FLOW2D_SOLVER_AUTO)
+            algorithm = auto_tiles ? FLOW2D_SOLVER_TILED : (can_fuse ? FLOW2D_SOLVER_FUSED : FLOW2D_SOLVER_PER_SWEEP);
+        else
+            algorithm = p->algorithm;
     }
     if (algorithm < 0) return FLOW2D_ERR_UNSUPPORTED;
+    // the strips multiply with half the neighbour weight alpha / h^2, which must be exactly representable (solve_fused.hip)
+    if (algorithm == FLOW2D_SOLVER_FUSED && !flow2d::fused_weights_ok(p->hx, p->hy, p->equation_alpha)) {
+        if (p->algorithm == FLOW2D_SOLVER_FUSED) return FLOW2D_ERR_UNSUPPORTED;
+        algorithm = FLOW2D_SOLVER_PER_SWEEP;
+    }
 
     flow2d_timing_slot* slot = nullptr;
     if (ctx->timing) {
@@ -244,8 +259,8 @@ int flow2d_solve_level(flow2d_context* ctx, const float* frame_0, const float* f
         if (per_launch) FLOW2D_HIP_TRY(mark(ctx, slot));
         int st = flow2d::launch_tiled_outer(ctx, p->data_constancy, frame_0, frame_1, flow_u, flow_v, pair_u[source],
                                             pair_v[source], p->width, p->height, p->pitch_bytes, p->hx, p->hy,
-                                            p->equation_alpha, p->equation_smoothness, p->equation_data, inner,
-                                            pair_u[out], pair_v[out], i == 0);
+                                            p->equation_alpha, p->equation_smoothness, p->equation_data,
+                                            sor ? 2 * inner : inner, pair_u[out], pair_v[out], i == 0, sor ? p->sor_omega : 0.f);
         if (st != FLOW2D_OK) return st;
         if (per_launch) FLOW2D_HIP_TRY(mark(ctx, slot));
         source = out;

@@ -38,6 +38,7 @@ struct TileArgs {
     int inner;
     int zero_increment;  // first outer iteration of a level: du = dv = 0, the planes are not read
     float hx, hy, alpha, e_smooth, e_data;
+    float sor_omega;  // SOR instantiations only: the `inner` stages are red-black half-sweeps (round 5)
     unsigned long long batch_stride;  // floats between the instances of a batched launch (blockIdx.z)
 };
 
@@ -47,7 +48,10 @@ struct TileArgs {
 // hide behind the other's arithmetic)
 // POW2: 2h and 4h are powers of two (every level of a 0.5 pyramid), so the six divisions by them in compute_phi_ksi
 // are exact multiplies by the reciprocal (solver_math.hpp, div_spacing).
-template <int TX, int TY, int GRAD, int kThreads, bool POW2>
+// SOR (round 5): the stages are half-sweeps of the opt-in red-black successive over-relaxation -- stage k relaxes the pixels
+// with (x + y) % 2 == (k - 1) % 2 (point_update_sor) and passes the other colour through; a half-sweep reaches one pixel like a
+// Jacobi sweep, so rings, halo and barriers are those of `inner` Jacobi sweeps: two iterations per launch at most.
+template <int TX, int TY, int GRAD, int kThreads, bool POW2, bool SOR>
 __global__ __launch_bounds__(kThreads, 8) void tile_outer_kernel(TileArgs a)
 {
     constexpr int kHalo = kMaxInner + 1;
@@ -216,7 +220,7 @@ __global__ __launch_bounds__(kThreads, 8) void tile_outer_kernel(TileArgs a)
     float* pong_v = P_dv;
     float du_new[PPT];
 #pragma unroll
-    for (int j = 0; j < PPT; ++j) du_new[j] = 0.f;
+    for (int j = 0; j < PPT; ++j) du_new[j] = SOR ? du0[j] : 0.f;  // (SOR: the increment a half-sweep blends with)
     for (int k = 1; k <= a.inner; ++k) {
 #pragma unroll
         for (int j = 0; j < PPT; ++j) {
@@ -227,7 +231,16 @@ __global__ __launch_bounds__(kThreads, 8) void tile_outer_kernel(TileArgs a)
                 const float sumV = sum_flux(wxp[j], wxm[j], wyp[j], wym[j], ping_v[nr], ping_v[nl], ping_v[nd],
                                             ping_v[nu], vc[j]);
                 float ndv;
-                point_update(ksi[j], den_u[j], den_v[j], J12[j], J13[j], J23[j], sumU, sumV, dv_cur[j], du_new[j], ndv);
+                if (SOR) {
+                    float ndu;
+                    point_update_sor(ksi[j], den_u[j], den_v[j], J12[j], J13[j], J23[j], sumU, sumV, du_new[j], dv_cur[j],
+                                     a.sor_omega, ndu, ndv);
+                    const bool mine = ((global_x(j) + global_y(j) + k - 1) & 1) == 0;  // half-sweep k relaxes colour (k - 1) % 2
+                    du_new[j] = mine ? ndu : du_new[j];
+                    ndv = mine ? ndv : dv_cur[j];
+                } else {
+                    point_update(ksi[j], den_u[j], den_v[j], J12[j], J13[j], J23[j], sumU, sumV, dv_cur[j], du_new[j], ndv);
+                }
                 dv_cur[j] = ndv;
                 pong_u[slot(j)] = uc[j] + du_new[j];
                 pong_v[slot(j)] = vc[j] + ndv;
@@ -252,15 +265,23 @@ __global__ __launch_bounds__(kThreads, 8) void tile_outer_kernel(TileArgs a)
     }
 }
 
+template <int TX, int TY, int kThreads, bool POW2, bool SOR>
+void launch_tiles_sor(int grad, dim3 grid, hipStream_t stream, const TileArgs& a)
+{
+    if (grad == 1)
+        tile_outer_kernel<TX, TY, 1, kThreads, POW2, SOR><<<grid, kThreads, 0, stream>>>(a);
+    else if (grad == 2)
+        tile_outer_kernel<TX, TY, 2, kThreads, POW2, SOR><<<grid, kThreads, 0, stream>>>(a);
+    else
+        tile_outer_kernel<TX, TY, 0, kThreads, POW2, SOR><<<grid, kThreads, 0, stream>>>(a);
+}
 template <int TX, int TY, int kThreads, bool POW2>
 void launch_tiles_pow2(int grad, dim3 grid, hipStream_t stream, const TileArgs& a)
 {
-    if (grad == 1)
-        tile_outer_kernel<TX, TY, 1, kThreads, POW2><<<grid, kThreads, 0, stream>>>(a);
-    else if (grad == 2)
-        tile_outer_kernel<TX, TY, 2, kThreads, POW2><<<grid, kThreads, 0, stream>>>(a);
+    if (a.sor_omega != 0.f)
+        launch_tiles_sor<TX, TY, kThreads, POW2, true>(grad, grid, stream, a);
     else
-        tile_outer_kernel<TX, TY, 0, kThreads, POW2><<<grid, kThreads, 0, stream>>>(a);
+        launch_tiles_sor<TX, TY, kThreads, POW2, false>(grad, grid, stream, a);
 }
 
 // true when x is a normal power of two whose reciprocal (and 1/(2x), 1/(4x)) is exactly representable
@@ -291,14 +312,15 @@ bool tiled_supports(int constancy, size_t inner)
 }
 
 // One outer iteration: reads du/dv (previous outer iteration, unless zero_increment), writes out_du/out_dv.
+// sor_omega != 0: the `inner` stages are red-black half-sweeps (an even number: inner / 2 iterations).
 int launch_tiled_outer(flow2d_context* ctx, int constancy, const float* f0, const float* f1, const float* u,
                        const float* v, const float* du, const float* dv, size_t w, size_t h, size_t pitch_bytes, float hx,
                        float hy, float alpha, float e_smooth, float e_data, size_t inner, float* out_du, float* out_dv,
-                       bool zero_increment)
+                       bool zero_increment, float sor_omega)
 {
-    if (!tiled_supports(constancy, inner)) return FLOW2D_ERR_UNSUPPORTED;
+    if (!tiled_supports(constancy, inner) || (sor_omega != 0.f && (inner & 1))) return FLOW2D_ERR_UNSUPPORTED;
     TileArgs a{f0, f1, u, v, du, dv, out_du, out_dv, (int)w, (int)h, (int)(pitch_bytes / 4), (int)inner,
-               zero_increment ? 1 : 0, hx, hy, alpha, e_smooth, e_data,
+               zero_increment ? 1 : 0, hx, hy, alpha, e_smooth, e_data, sor_omega,
                static_cast<unsigned long long>(ctx->batch_stride_floats)};
     const int grad = constancy == FLOW2D_CONSTANCY_GRADIENT ? 1 : (constancy == FLOW2D_CONSTANCY_GRADIENT_UNTILED ? 2 : 0);
     // Tile size by level size (measured on MI355X, level solve of 10 x 5, Grey / Gradient, ms; fused strips for comparison):

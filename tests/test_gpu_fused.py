@@ -89,6 +89,26 @@ def test_denominators_outside_the_proven_range_fall_back(ctx, oracle):
     assert ctx.fused_fallbacks() > before
 
 
+@pytest.mark.parametrize("alpha,fuses", [(1e-29, True), (1e-31, False), (0.0, True), (3e-36, False)])
+def test_neighbour_weights_the_strips_cannot_halve_exactly(ctx, flow2d, oracle, alpha, fuses):
+    """Stage W multiplies (phi_n + phi_c) by HALF the neighbour weight alpha / h^2 (round 5) -- the same bits as (phi_n + phi_c) / 2
+    times the weight while halving the weight is exact.  Weights below 2^-100 are not the strips' business: AUTO gives the level to
+    the per-sweep kernels, an explicit request is refused; every path agrees with the oracle."""
+    w, h = 1300, 300  # (above AUTO's tile threshold: the strips' level)
+    f0, f1, u, v, _, _ = level_fields(oracle, w, h, 27)
+    hx = hy = np.float32(1.0)
+    same = lambda x, y: np.array_equal(x, y, equal_nan=True)  # (alpha = 0 leaves 0 / 0 where the image is flat: NaN on both sides)
+    a, b, odu, odv = fused_vs_oracle(ctx, oracle, f0, f1, u, v, w, h, w, h, hx, hy, alpha, 2, 5, 0, algorithm=0)
+    assert same(a, odu) and same(b, odv)
+    if fuses:
+        a, b, odu, odv = fused_vs_oracle(ctx, oracle, f0, f1, u, v, w, h, w, h, hx, hy, alpha, 2, 5, 0, algorithm=2)
+        assert same(a, odu) and same(b, odv)
+    else:
+        with pytest.raises(flow2d.Flow2DError) as e:
+            fused_vs_oracle(ctx, oracle, f0, f1, u, v, w, h, w, h, hx, hy, alpha, 2, 5, 0, algorithm=2)
+        assert e.value.status == 5
+
+
 def test_overflowing_results_match_the_per_sweep_kernels(ctx, flow2d, oracle):
     """An infinite patch in the flow: the sweeps around it produce infinities and NaNs.  Non-finite results trip the
     output guard, and the repeat with the plain division delivers what the per-sweep kernels (one launch per reference

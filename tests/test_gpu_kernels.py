@@ -478,10 +478,12 @@ def test_sor_rejects_bad_omega_and_kernels_without_half_sweeps(ctx, flow2d):
         with pytest.raises(flow2d.Flow2DError) as e:
             ctx.solve_level(*planes, w, h, 1.0, 1.0, 3.5, 0.001, 0.001, 1, 1, 0, 0, sor_omega=omega)
         assert e.value.status == 1
-    for algorithm in (3, 4):  # the single-workgroup and the tiled kernel are Jacobi only
-        with pytest.raises(flow2d.Flow2DError) as e:
-            ctx.solve_level(*planes, w, h, 1.0, 1.0, 3.5, 0.001, 0.001, 1, 1, 0, algorithm, sor_omega=1.2)
-        assert e.value.status == 5
+    with pytest.raises(flow2d.Flow2DError) as e:  # the single-workgroup kernel is Jacobi only
+        ctx.solve_level(*planes, w, h, 1.0, 1.0, 3.5, 0.001, 0.001, 1, 1, 0, 3, sor_omega=1.2)
+    assert e.value.status == 5
+    with pytest.raises(flow2d.Flow2DError) as e:  # the tiles hold two iterations (four half-sweep stages) at most
+        ctx.solve_level(*planes, w, h, 1.0, 1.0, 3.5, 0.001, 0.001, 1, 3, 0, 4, sor_omega=1.2)
+    assert e.value.status == 5
     with pytest.raises(flow2d.Flow2DError) as e:  # solve_2d_log has no red-black form
         ctx.solve_level(*planes, w, h, 1.0, 1.0, 3.5, 0.001, 0.001, 1, 1, 3, 0, sor_omega=1.2)
     assert e.value.status == 5
@@ -505,6 +507,24 @@ def test_sor_in_the_strip_kernel(ctx, oracle, w, h, iterations, omega, constancy
         odu, odv = oracle.solve_level_sor(f0, f1, u, v, w, h, hx, hy, 35.0, 0.001, 0.001, 3, iterations, omega, constancy)
         assert np.array_equal(rdu.download(w, h), odu) and np.array_equal(rdv.download(w, h), odv), (hx, hy)
     assert ctx.fused_fallbacks() == 0
+
+
+@pytest.mark.parametrize("constancy", [0, 1, 2])
+@pytest.mark.parametrize("w,h,iterations,omega", [(96, 64, 1, 1.9), (150, 90, 2, 1.2), (330, 250, 2, 1.7), (512, 384, 1, 0.8), (40, 33, 2, 1.5)])
+def test_sor_in_the_lds_tiles(ctx, oracle, w, h, iterations, omega, constancy):
+    """Red-black SOR in the tiled kernel (round 5: half-sweeps as its stages, one or two iterations per launch; 8 x 8, 16 x 16 and
+    32 x 32 tiles), explicitly and as AUTO's choice for these level sizes: the oracle's bits."""
+    if constancy == 1:
+        w, h = (w + 15) // 16 * 16, (h + 7) // 8 * 8
+    f0, f1, u, v, _, _ = level_fields(oracle, w, h, 79)
+    d = [up(ctx, a, w, h) for a in (f0, f1, u, v)]
+    du, dv, phi, ksi, tdu, tdv = (ctx.plane(w, h) for _ in range(6))
+    hx, hy = np.float32(1.25), np.float32(1.6)
+    odu, odv = oracle.solve_level_sor(f0, f1, u, v, w, h, hx, hy, 35.0, 0.001, 0.001, 3, iterations, omega, constancy)
+    for algorithm in (4, 0):
+        rdu, rdv = ctx.solve_level(*d, du, dv, phi, ksi, tdu, tdv, w, h, hx, hy, 35.0, 0.001, 0.001, 3, iterations, constancy,
+                                   algorithm, sor_omega=omega)
+        assert np.array_equal(rdu.download(w, h), odu) and np.array_equal(rdv.download(w, h), odv), algorithm
 
 
 @pytest.mark.parametrize("w,h,cw,ch", [(100, 70, 128, 80), (257, 33, 300, 40), (7, 5, 8, 8), (1024, 300, 1024, 300)])

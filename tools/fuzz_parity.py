@@ -1,6 +1,6 @@
 """Developer tool: random whole-pipeline configurations, product (single pairs and lock-step groups) against the CPU
 oracle, bit for bit.  usage (GPU box): python tools/fuzz_parity.py [cases] [seed] [solver algorithm: 0 auto, 2 fused strips
-on every level, ...]"""
+on every level, ...] [share of cases in the opt-in red-black SOR mode, default 0.2: omega drawn from (0.3, 1.95)]"""
 import importlib
 import os
 import sys
@@ -17,6 +17,7 @@ def main():
     cases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
     rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
     algorithm = int(sys.argv[3]) if len(sys.argv) > 3 else 0
+    sor_share = float(sys.argv[4]) if len(sys.argv) > 4 else 0.2
     ctx = F.Context(0)
     bad = 0
     t0 = time.time()
@@ -27,6 +28,7 @@ def main():
              int(rng.integers(1, 9)), float(np.float32(10.0 ** rng.uniform(-1.0, 2.0))), 0.001, 0.001,
              int(rng.choice([1, 3, 5, 7])), float(rng.choice([0.0, 0.45, 1.0, 1.5, 2.9])))
         G = int(rng.choice([1, 1, 2, 3, 5]))
+        omega = float(np.float32(rng.uniform(0.3, 1.95))) if rng.uniform() < sor_share else 0.0
         pairs = [O.synthetic_pair(w, h, float(rng.uniform(-3, 3)), float(rng.uniform(-3, 3)), seed=int(rng.integers(1 << 30)),
                                   noise=bool(rng.integers(2))) for _ in range(G)]
         batch = F.OpticalFlowBatch(w, h, constancy, lanes=1, group_size=G)
@@ -35,18 +37,18 @@ def main():
                       ctx.plane(w, h * G).fill_bytes(0x7f), ctx.plane(w, h * G).fill_bytes(0x7f)]
             batch.use_graph(bool(rng.integers(2)))
             try:
-                batch.compute_flow_batch_device(*[[q.ptr] for q in planes], batch.params(*p, algorithm))
+                batch.compute_flow_batch_device(*[[q.ptr] for q in planes], batch.params(*p, algorithm, sor_omega=omega))
             except F.Flow2DError as e:
-                print("case %d refused (%s): %s" % (n, e, (w, h, constancy, p, G)))
+                print("case %d refused (%s): %s" % (n, e, (w, h, constancy, p, G, omega)))
                 continue
             batch.synchronize()
             u, v = planes[2].download(), planes[3].download()
             for k, (f0, f1) in enumerate(pairs):
-                ou, ov, _ = O.compute_flow(f0, f1, *p, constancy)
+                ou, ov, _ = O.compute_flow(f0, f1, *p, constancy, sor_omega=omega)
                 if not (np.array_equal(u[k * h:(k + 1) * h], ou, equal_nan=True) and
                         np.array_equal(v[k * h:(k + 1) * h], ov, equal_nan=True)):
                     bad += 1
-                    print("MISMATCH case %d pair %d: %s" % (n, k, (w, h, constancy, p, G)))
+                    print("MISMATCH case %d pair %d: %s" % (n, k, (w, h, constancy, p, G, omega)))
             for q in planes:
                 q.free()
         finally:
