@@ -132,7 +132,11 @@ __device__ __forceinline__ unsigned turn_parity()
 __device__ __forceinline__ void take_turns(unsigned long long clock, unsigned parity)
 {
     if (kTurnShift < 0) return;
+#if FLOW2D_FUSED_WAVES == 3  // (three waves per SIMD: the favoured role goes round the three wave slots)
+    if ((static_cast<unsigned>(clock >> (kTurnShift < 0 ? 0 : kTurnShift)) % 3u) == parity % 3u)
+#else
     if (((static_cast<unsigned>(clock >> (kTurnShift < 0 ? 0 : kTurnShift)) ^ parity) & 1u) != 0u)
+#endif
         __builtin_amdgcn_s_setprio(1);
     else
         __builtin_amdgcn_s_setprio(0);
