@@ -58,6 +58,7 @@
 //                                two, so that the five-sweep kernel fits FLOW2D_FUSED_WAVES=3 waves per SIMD (168 registers): what
 //                                would a third wave buy the full kernel's instruction stream?  (tools/occupancy5_exp.sh)
 //   FLOW2D_FUSED_WAVES=n         __launch_bounds__(256, n)
+//   FLOW2D_FUSED_FULL_WEIGHTS    stage W's face weights as (a + b) / 2.f * w (rounds 1-4) instead of (a + b) * (w / 2), for A/B
 //   FLOW2D_FUSED_ORDER=1 / 2     stage W (2: and stage P) of a row step after its sweeps instead of before them: the step as two
 //                                chains that do not depend on each other (round 5's A/B for "independent stages")
 #if (defined(FLOW2D_FUSED_STAMPS) || defined(FLOW2D_FUSED_SHORT_RING) || defined(FLOW2D_FUSED_WAVES) || defined(FLOW2D_FUSED_COMPUTE_ONLY) || defined(FLOW2D_FUSED_MEMORY_ONLY) ||          \

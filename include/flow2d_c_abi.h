@@ -321,9 +321,11 @@ typedef struct flow2d_solve_params {
     int data_constancy;          /* flow2d_constancy */
     int algorithm;               /* flow2d_solver_algorithm */
     float sor_omega;             /* 0 (default): Jacobi sweeps as in the reference.  In (0, 2): every inner iteration
-                                    is one red-black SOR iteration instead (opt-in, no reference parity).  AUTO and
-                                    FUSED run it temporally blocked in the strip kernel (two iterations per launch);
-                                    PER_SWEEP as two half-sweep launches per iteration, in place. */
+                                    is one red-black SOR iteration instead (opt-in, no reference parity).  AUTO runs it
+                                    temporally blocked -- LDS tiles or strips by level size, two iterations per launch --,
+                                    FUSED / TILED (at most two iterations per outer iteration) ask for one of the two,
+                                    PER_SWEEP for two half-sweep launches per iteration, in place; SINGLE_WORKGROUP and
+                                    the LogDerivatives term have no red-black form (FLOW2D_ERR_UNSUPPORTED). */
 } flow2d_solve_params;
 
 /* Which algorithm flow2d_solve_level runs for a request: `requested` resolved (AUTO -> one of the four), or -1 when the
