@@ -939,7 +939,7 @@ def spawn_ranks(args):
     import socket
     import subprocess
 
-    if not args.plumbing_check:
+    if not (args.plumbing_check or args.rehearse_on_one_gpu):
         import torch  # device_count() alone does not initialise the GPU on this image
         visible = torch.cuda.device_count()
         if visible < args.gpus:
@@ -1021,6 +1021,9 @@ def main():
                     help="skip the rocprofv3 --pmc child passes that measure the dominant kernel's HBM bytes and VALU "
                          "instructions for this run (N = 1 only); the line then quotes profiles/traffic.json")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--rehearse-on-one-gpu", action="store_true",
+                    help="developer: the N ranks of --gpus N all use GPU 0 and talk over gloo (keep N <= 6), to walk the "
+                         "multi-rank branches of this file on a one-GPU box; the line says so and is NOT a measurement")
     ap.add_argument("--plumbing-check", action="store_true",
                     help="rank plumbing only (launcher, process group on gloo, broadcast, barriers, gathers) without the "
                          "flow computation; needs no GPU and prints no metric")
@@ -1046,6 +1049,10 @@ def main():
             time.sleep(1.0)
     rank, local_rank, world = batch.world_info()
     args.gpus = world  # launched by torch.distributed.run: the launcher's world size is the number of GPUs
+    if args.rehearse_on_one_gpu:
+        if world > 6:
+            sys.exit("bench.py --rehearse-on-one-gpu: at most 6 ranks may share a GPU")
+        local_rank = 0
     # counters of THIS workload, collected by child processes before this one initialises the GPU
     pmc_run = pmc_passes(args, cfg) if (world == 1 and not args.no_pmc) else {}
 
@@ -1054,7 +1061,8 @@ def main():
     if not torch.cuda.is_available():
         sys.exit("bench.py needs an MI355X: the flow2d path has no CPU fallback")
     torch.cuda.set_device(local_rank)
-    batch.init(backend="nccl", device=torch.device("cuda", local_rank))  # RCCL; no-op for one process
+    # RCCL; no-op for one process (the rehearsal's ranks share a GPU, which RCCL refuses: gloo)
+    batch.init(backend="gloo" if args.rehearse_on_one_gpu else "nccl", device=torch.device("cuda", local_rank))
 
     w, h = cfg["w"], cfg["h"]
     job = Job(flow2d, batch, args.workload, cfg, args, rank, local_rank, world)
@@ -1180,6 +1188,8 @@ def main():
             "value": round(px_iters * pairs_total / elapsed / 1e6, 1),
             "unit": "Mpixel*iters/s",
             "n_gpus": world,
+            **({"rehearsal": "%d ranks sharing ONE GPU over gloo (--rehearse-on-one-gpu): a walk through the multi-rank "
+                             "branches, not a measurement" % world} if args.rehearse_on_one_gpu else {}),
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4),

@@ -44,6 +44,13 @@ def _collective_device(device):
     return torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else "cpu"
 
 
+def _staged_through_host(local):
+    """gloo gathers host tensors only: a device block handed to it (bench.py --rehearse-on-one-gpu, N ranks sharing one
+    GPU) goes through host memory.  RCCL takes device blocks as they are."""
+    import torch.distributed as dist
+    return local.is_cuda and dist.get_backend() == "gloo"
+
+
 def broadcast_params(values, device=None):
     """Rank 0's parameter block (a flat sequence of numbers, e.g. levels, scale, outer, inner, alpha, ...) on every
     rank: all ranks of a batch solve with the same parameters whatever their own command line said."""
@@ -69,6 +76,8 @@ def all_gather_fields(local, out=None):
     world = dist.get_world_size()
     if out is None:
         out = torch.empty((world,) + tuple(local.shape), dtype=local.dtype, device=local.device)
+    if _staged_through_host(local):
+        return out.copy_(all_gather_fields(local.cpu()))
     # the collective's own layout is the concatenation along dim 0: [world * pairs_per_rank, ...]
     dist.all_gather_into_tensor(out.view((-1,) + tuple(local.shape[1:])), local.contiguous())
     return out
@@ -84,6 +93,11 @@ def gather_fields_to_root(local, out=None, root=0):
     if not (dist.is_available() and dist.is_initialized()):
         return local.unsqueeze(0) if out is None else out.copy_(local.unsqueeze(0))
     world, rank = dist.get_world_size(), dist.get_rank()
+    if _staged_through_host(local):
+        at_root = gather_fields_to_root(local.cpu(), root=root)
+        if rank != root:
+            return None
+        return at_root.to(local.device) if out is None else out.copy_(at_root)
     if rank != root:
         dist.gather(local.contiguous(), dst=root)
         return None

@@ -85,3 +85,24 @@ def test_run_batch8_script_with_one_rank(tmp_path):
     stale.write_bytes(b"some-older-run\n" + bytes(128))
     other = run_tool(["--rank", 0, "--world", 1, "--id-file", stale, "--run-id", "fresh"] + job)
     assert other["flows_fnv1a"] == line["flows_fnv1a"] and not stale.exists()
+
+
+def test_bench_multi_rank_branches_with_two_ranks_on_this_gpu():
+    """`bench.py --gpus 2` end to end on the one-GPU box: both ranks use GPU 0 and talk over gloo
+    (--rehearse-on-one-gpu), so the world > 1 branches -- shard rule, distinct pairs per rank, parameter broadcast,
+    barriers, max over ranks, the batch leg's two gathers -- run against real flow fields.  Not a measurement."""
+    import sys
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--rehearse-on-one-gpu", "--workload",
+                        "cfg2_1024_grey", "--steps", "8", "--warmup", "2", "--repeats", "2", "--no-host-entry-leg"],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=420, cwd=ROOT)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [json.loads(x) for x in p.stdout.splitlines() if x.startswith("{")]
+    assert len(lines) == 1  # rank 0 alone prints
+    line = lines[0]
+    assert line["n_gpus"] == 2 and "rehearsal" in line and line["value"] > 0 and line["scaling"] == "weak"
+    check = line["output_check"]
+    assert check["ok"] and check["graph_replay_equals_eager"] and check["oracle"]["first_pair_equals_cpu_oracle"]
+    gather = line["batch"]["gather"]
+    assert line["batch"]["pairs_total_per_step"] == 16 and line["batch"]["output_check"]["ok"]
+    assert gather["own_block_intact"] and gather["every_pair_present"] and gather["root_equals_all_gather"]
