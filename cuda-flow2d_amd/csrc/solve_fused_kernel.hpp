@@ -52,19 +52,22 @@
 //   FLOW2D_FUSED_PLAIN_ORDER     blocks in plain order instead of one contiguous run per XCD
 //   FLOW2D_FUSED_INJECT=k        24 extra instructions of one class per steady-state row step (1 plain, 2 packed, 3 DPP, 4 transcendental, 5 s_nop):
 //                                what an instruction of that class costs in this kernel's own stream (tools/fused_price_list.sh)
-//   FLOW2D_FUSED_NO_PACKED       the face products as plain multiplies (with -Xclang -target-feature -Xclang -packed-fp32-ops: no packed arithmetic at all)
 //   FLOW2D_FUSED_COMPUTE_ONLY, FLOW2D_FUSED_MEMORY_ONLY   timing probes that compute WRONG results
 //   FLOW2D_FUSED_SHORT_RING=n    timing probe, WRONG results: a coefficient ring of n (3) entries and one input row in flight instead of
 //                                two, so that the five-sweep kernel fits FLOW2D_FUSED_WAVES=3 waves per SIMD (168 registers): what
 //                                would a third wave buy the full kernel's instruction stream?  (tools/occupancy5_exp.sh)
+//   FLOW2D_FUSED_NO_LANE_SHIFT   timing probe, WRONG results: x neighbours = the lane's own value, no DPP instruction (with the
+//                                packed-fp32-ops feature off: a row step of plain instructions only -- what would that stream cost?)
 //   FLOW2D_FUSED_WAVES=n         __launch_bounds__(256, n)
 //   FLOW2D_FUSED_FULL_WEIGHTS    stage W's face weights as (a + b) / 2.f * w (rounds 1-4) instead of (a + b) * (w / 2), for A/B
 //   FLOW2D_FUSED_ORDER=1 / 2     stage W (2: and stage P) of a row step after its sweeps instead of before them: the step as two
 //                                chains that do not depend on each other (round 5's A/B for "independent stages")
+// A build option, not a probe (csrc/Makefile sets it for the instances it compiles WITH packed fp32 arithmetic):
+//   FLOW2D_FUSED_PACKED          the face products as v_pk_mul_f32 ... op_sel instead of two plain multiplies
 #if (defined(FLOW2D_FUSED_STAMPS) || defined(FLOW2D_FUSED_SHORT_RING) || defined(FLOW2D_FUSED_WAVES) || defined(FLOW2D_FUSED_COMPUTE_ONLY) || defined(FLOW2D_FUSED_MEMORY_ONLY) ||          \
      defined(FLOW2D_FUSED_TURN_SHIFT) || defined(FLOW2D_FUSED_PLAIN_DIVISION) || defined(FLOW2D_FUSED_NO_PINS) ||          \
      defined(FLOW2D_FUSED_DEV) || defined(FLOW2D_FUSED_EDGE_COST) || defined(FLOW2D_FUSED_NO_SPLIT) ||                    \
-     defined(FLOW2D_FUSED_PLAIN_ORDER) || defined(FLOW2D_FUSED_NO_PACKED) || defined(FLOW2D_FUSED_INJECT) || defined(FLOW2D_FUSED_FULL_WEIGHTS)) &&                                                                               \
+     defined(FLOW2D_FUSED_PLAIN_ORDER) || defined(FLOW2D_FUSED_INJECT) || defined(FLOW2D_FUSED_FULL_WEIGHTS) || defined(FLOW2D_FUSED_NO_LANE_SHIFT)) &&                                                                               \
     !defined(FLOW2D_DEV_BUILD)
 #error "the fused kernel's timing probes need -DFLOW2D_DEV_BUILD: they are not part of the product library"
 #endif
@@ -96,6 +99,18 @@ __device__ __forceinline__ void plane_store(float* plane, unsigned byte_offset, 
 // lane i receives lane i-1 (wave_shr:1) / lane i+1 (wave_shl:1); the end lanes of the wave receive 0
 // (bound_ctrl), which only ever reaches halo columns.  No "old" operand, so the move can fold into the
 // consuming VALU instruction.
+#ifdef FLOW2D_FUSED_NO_LANE_SHIFT  // timing probe, WRONG results: the lane's own value, no instruction at all
+__device__ __forceinline__ float from_left(float v)
+{
+    asm volatile("" : "+v"(v));
+    return v;
+}
+__device__ __forceinline__ float from_right(float v)
+{
+    asm volatile("" : "+v"(v));
+    return v;
+}
+#else
 __device__ __forceinline__ float from_left(float v)
 {
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x138, 0xf, 0xf, true));
@@ -104,6 +119,7 @@ __device__ __forceinline__ float from_right(float v)
 {
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x130, 0xf, 0xf, true));
 }
+#endif
 
 // Developer experiment (round 4, -DFLOW2D_FUSED_TURN_SHIFT=15; not in the product build): the two waves of a SIMD take
 // turns at being the one the issue arbiter favours.  Vector issue on a SIMD goes to the wave of higher priority and, among
@@ -286,21 +302,23 @@ __device__ __forceinline__ bool guard_tripped(const DivGuard& g)
 // transcendental instruction, which on gfx950 needs a wait state before an ordinary VALU instruction may read it.)
 __device__ __forceinline__ v2f mul_by_x(v2f w, v2f d)
 {
-#ifdef FLOW2D_FUSED_NO_PACKED
+#ifndef FLOW2D_FUSED_PACKED
     return v2f{w.x * d.x, w.x * d.y};
-#endif
+#else
     v2f r;
     asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]" : "=v"(r) : "v"(w), "v"(d));
     return r;
+#endif
 }
 __device__ __forceinline__ v2f mul_by_y(v2f w, v2f d)
 {
-#ifdef FLOW2D_FUSED_NO_PACKED
+#ifndef FLOW2D_FUSED_PACKED
     return v2f{w.y * d.x, w.y * d.y};
-#endif
+#else
     v2f r;
     asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,0]" : "=v"(r) : "v"(w), "v"(d));
     return r;
+#endif
 }
 // keeps the vectoriser from pairing two scalar operations into a packed one (an empty statement: no instruction)
 __device__ __forceinline__ float scalar_only(float v)
