@@ -58,6 +58,7 @@
 //                                would a third wave buy the full kernel's instruction stream?  (tools/occupancy5_exp.sh)
 //   FLOW2D_FUSED_NO_LANE_SHIFT   timing probe, WRONG results: x neighbours = the lane's own value, no DPP instruction (with the
 //                                packed-fp32-ops feature off: a row step of plain instructions only -- what would that stream cost?)
+//   FLOW2D_FUSED_THREE_AHEAD     three input rows in flight instead of two (six more registers)
 //   FLOW2D_FUSED_WAVES=n         __launch_bounds__(256, n)
 //   FLOW2D_FUSED_FULL_WEIGHTS    stage W's face weights as (a + b) / 2.f * w (rounds 1-4) instead of (a + b) * (w / 2), for A/B
 //   FLOW2D_FUSED_ORDER=1 / 2     stage W (2: and stage P) of a row step after its sweeps instead of before them: the step as two
@@ -67,7 +68,7 @@
 #if (defined(FLOW2D_FUSED_STAMPS) || defined(FLOW2D_FUSED_SHORT_RING) || defined(FLOW2D_FUSED_WAVES) || defined(FLOW2D_FUSED_COMPUTE_ONLY) || defined(FLOW2D_FUSED_MEMORY_ONLY) ||          \
      defined(FLOW2D_FUSED_TURN_SHIFT) || defined(FLOW2D_FUSED_PLAIN_DIVISION) || defined(FLOW2D_FUSED_NO_PINS) ||          \
      defined(FLOW2D_FUSED_DEV) || defined(FLOW2D_FUSED_EDGE_COST) || defined(FLOW2D_FUSED_NO_SPLIT) ||                    \
-     defined(FLOW2D_FUSED_PLAIN_ORDER) || defined(FLOW2D_FUSED_INJECT) || defined(FLOW2D_FUSED_FULL_WEIGHTS) || defined(FLOW2D_FUSED_NO_LANE_SHIFT)) &&                                                                               \
+     defined(FLOW2D_FUSED_PLAIN_ORDER) || defined(FLOW2D_FUSED_INJECT) || defined(FLOW2D_FUSED_FULL_WEIGHTS) || defined(FLOW2D_FUSED_NO_LANE_SHIFT) || defined(FLOW2D_FUSED_THREE_AHEAD)) &&                                                                               \
     !defined(FLOW2D_DEV_BUILD)
 #error "the fused kernel's timing probes need -DFLOW2D_DEV_BUILD: they are not part of the product library"
 #endif
@@ -382,6 +383,10 @@ struct Strip {
     v2f n_uv, n_duv;
     float m_f0, m_f1;
     v2f m_uv, m_duv;
+#ifdef FLOW2D_FUSED_THREE_AHEAD  // developer A/B: a third input row in flight (row r+3)
+    float l_f0, l_f1;
+    v2f l_uv, l_duv;
+#endif
     // continue_sweeps only: the sweeps' starting increment of row r-2 (start_cur) and the row fetched for the
     // next step (n_start)
     v2f start_cur, n_start;
@@ -469,10 +474,15 @@ __device__ __forceinline__ void strip_step(Strip<INNER, GRAD>& s, const FusedArg
 #ifndef FLOW2D_FUSED_SHORT_RING
         s.n_f0 = s.m_f0, s.n_f1 = s.m_f1, s.n_uv = s.m_uv, s.n_duv = s.m_duv;
 #endif
-#ifdef FLOW2D_FUSED_COMPUTE_ONLY  // developer probe (timing only, wrong results): every row folded onto eight cache-resident rows
-        const int rn = (r + 2) & 7;
+#ifdef FLOW2D_FUSED_THREE_AHEAD
+        constexpr int kAhead = 3;
 #else
-        const int rn = min(max(r + 2, 0), h - 1);
+        constexpr int kAhead = 2;
+#endif
+#ifdef FLOW2D_FUSED_COMPUTE_ONLY  // developer probe (timing only, wrong results): every row folded onto eight cache-resident rows
+        const int rn = (r + kAhead) & 7;
+#else
+        const int rn = min(max(r + kAhead, 0), h - 1);
 #endif
         const unsigned off = (static_cast<unsigned>(rn) * static_cast<unsigned>(a.pitch) + static_cast<unsigned>(xc)) * 4u;
 #ifdef FLOW2D_FUSED_SHORT_RING  // (probe: one row in flight)
@@ -480,6 +490,12 @@ __device__ __forceinline__ void strip_step(Strip<INNER, GRAD>& s, const FusedArg
         s.n_f1 = plane_load(a.f1, off);
         s.n_uv = v2f{plane_load(a.u, off), plane_load(a.v, off)};
         s.n_duv = a.zero_increment ? v2f{0.f, 0.f} : v2f{plane_load(a.du, off), plane_load(a.dv, off)};
+#elif defined(FLOW2D_FUSED_THREE_AHEAD)
+        s.m_f0 = s.l_f0, s.m_f1 = s.l_f1, s.m_uv = s.l_uv, s.m_duv = s.l_duv;
+        s.l_f0 = plane_load(a.f0, off);
+        s.l_f1 = plane_load(a.f1, off);
+        s.l_uv = v2f{plane_load(a.u, off), plane_load(a.v, off)};
+        s.l_duv = a.zero_increment ? v2f{0.f, 0.f} : v2f{plane_load(a.du, off), plane_load(a.dv, off)};
 #else
         s.m_f0 = plane_load(a.f0, off);
         s.m_f1 = plane_load(a.f1, off);
@@ -887,6 +903,15 @@ __device__ __forceinline__ bool run_strip(const FusedArgs& a, int x, int xc, boo
             s.m_uv = v2f{a.u[o2], a.v[o2]};
             s.m_duv = a.zero_increment ? v2f{0.f, 0.f} : v2f{a.du[o2], a.dv[o2]};
         }
+#ifdef FLOW2D_FUSED_THREE_AHEAD
+        {
+            const size_t o3 = static_cast<size_t>(min(max(r_first + 2, 0), a.h - 1)) * a.pitch + xc;
+            s.l_f0 = a.f0[o3];
+            s.l_f1 = a.f1[o3];
+            s.l_uv = v2f{a.u[o3], a.v[o3]};
+            s.l_duv = a.zero_increment ? v2f{0.f, 0.f} : v2f{a.du[o3], a.dv[o3]};
+        }
+#endif
         s.start_cur = s.n_start = v2f{0.f, 0.f};
         if (CONT) {  // the first step commits row r_first - 2 of the starting increment
             const size_t os = static_cast<size_t>(min(max(r_first - 2, 0), a.h - 1)) * a.pitch + xc;
