@@ -59,6 +59,7 @@
 //   FLOW2D_FUSED_NO_LANE_SHIFT   timing probe, WRONG results: x neighbours = the lane's own value, no DPP instruction (with the
 //                                packed-fp32-ops feature off: a row step of plain instructions only -- what would that stream cost?)
 //   FLOW2D_FUSED_THREE_AHEAD     three input rows in flight instead of two (six more registers)
+//   FLOW2D_FUSED_VGPR_BUDGET=n   a register budget below the 256 that two waves per SIMD allow (room for other lanes' kernels beside a launch)
 //   FLOW2D_FUSED_WAVES=n         __launch_bounds__(256, n)
 //   FLOW2D_FUSED_FULL_WEIGHTS    stage W's face weights as (a + b) / 2.f * w (rounds 1-4) instead of (a + b) * (w / 2), for A/B
 //   FLOW2D_FUSED_ORDER=1 / 2     stage W (2: and stage P) of a row step after its sweeps instead of before them: the step as two
@@ -68,7 +69,7 @@
 #if (defined(FLOW2D_FUSED_STAMPS) || defined(FLOW2D_FUSED_SHORT_RING) || defined(FLOW2D_FUSED_WAVES) || defined(FLOW2D_FUSED_COMPUTE_ONLY) || defined(FLOW2D_FUSED_MEMORY_ONLY) ||          \
      defined(FLOW2D_FUSED_TURN_SHIFT) || defined(FLOW2D_FUSED_PLAIN_DIVISION) || defined(FLOW2D_FUSED_NO_PINS) ||          \
      defined(FLOW2D_FUSED_DEV) || defined(FLOW2D_FUSED_EDGE_COST) || defined(FLOW2D_FUSED_NO_SPLIT) ||                    \
-     defined(FLOW2D_FUSED_PLAIN_ORDER) || defined(FLOW2D_FUSED_INJECT) || defined(FLOW2D_FUSED_FULL_WEIGHTS) || defined(FLOW2D_FUSED_NO_LANE_SHIFT) || defined(FLOW2D_FUSED_THREE_AHEAD)) &&                                                                               \
+     defined(FLOW2D_FUSED_PLAIN_ORDER) || defined(FLOW2D_FUSED_INJECT) || defined(FLOW2D_FUSED_FULL_WEIGHTS) || defined(FLOW2D_FUSED_NO_LANE_SHIFT) || defined(FLOW2D_FUSED_THREE_AHEAD) || defined(FLOW2D_FUSED_VGPR_BUDGET)) &&                                                                               \
     !defined(FLOW2D_DEV_BUILD)
 #error "the fused kernel's timing probes need -DFLOW2D_DEV_BUILD: they are not part of the product library"
 #endif
@@ -943,8 +944,15 @@ constexpr bool kThreeStepDivision = true;
 #ifndef FLOW2D_FUSED_WAVES
 #define FLOW2D_FUSED_WAVES 2
 #endif
+// FLOW2D_FUSED_VGPR_BUDGET=n (developer A/B): at most n vector registers (gfx950's register file is unified, the compiler doubles
+// the attribute's value: n / 2 is what it wants to be told)
+#ifdef FLOW2D_FUSED_VGPR_BUDGET
+#define FLOW2D_FUSED_VGPR_ATTR __attribute__((amdgpu_num_vgpr(FLOW2D_FUSED_VGPR_BUDGET / 2)))
+#else
+#define FLOW2D_FUSED_VGPR_ATTR
+#endif
 template <int INNER, int GRAD, bool POW2, bool CONT, bool SOR = false>
-__global__ __launch_bounds__(256, FLOW2D_FUSED_WAVES) void fused_outer_kernel(FusedArgs a)
+__global__ __launch_bounds__(256, FLOW2D_FUSED_WAVES) FLOW2D_FUSED_VGPR_ATTR void fused_outer_kernel(FusedArgs a)
 {
     using S = Strip<INNER, GRAD>;
     const int lane = threadIdx.x & 63;
