@@ -98,7 +98,7 @@ static FusedPlan fused_plan_search(const flow2d_context* ctx, size_t w, size_t h
     const long cus = ctx->num_cus > 0 ? ctx->num_cus : 256;
     const long cap = cus * 2;
     const int ring = (((int)inner + 1 + 2) / 3) * 3;
-    const int peel = ((3 + 2 * (int)inner) / ring) * ring;
+    const int peel = 3 + 2 * (int)inner;  // run_strip's start-up steps
     double saved = 2 * 102.0 + 3 * 20.0;
     for (int k = 1; k <= (int)inner; ++k) saved += 46.0 * std::min(3 + 2 * k, peel);
     const double halo = (double)(2 * (long)inner + 3) - saved / (138.0 + 46.0 * (double)inner);  // the last ring turn is partial

@@ -465,8 +465,12 @@ __device__ __forceinline__ void strip_step(Strip<INNER, GRAD>& s, const FusedArg
     s.f0w[s0] = s.n_f0;
     s.f1w[s0] = s.n_f1;
     s.uvw[s0] = s.n_uv;
+#if defined(FLOW2D_FUSED_SHORT_RING) || defined(FLOW2D_FUSED_THREE_AHEAD)
     s.duvw[s0] = s.n_duv;
-    if (FAST) guard_flow_row(s.guard, s.n_uv, s.n_duv);
+#else
+    s.duvw[s0] = v2f{a.zero_increment ? 0.f : s.n_duv.x, a.zero_increment ? 0.f : s.n_duv.y};
+#endif
+    if (FAST) guard_flow_row(s.guard, s.n_uv, s.duvw[s0]);
     if (GRAD == 3) {
         s.lf0w[s0] = log1p_frame(s.n_f0);
         s.lf1w[s0] = log1p_frame(s.n_f1);
@@ -483,7 +487,9 @@ __device__ __forceinline__ void strip_step(Strip<INNER, GRAD>& s, const FusedArg
 #ifdef FLOW2D_FUSED_COMPUTE_ONLY  // developer probe (timing only, wrong results): every row folded onto eight cache-resident rows
         const int rn = (r + kAhead) & 7;
 #else
-        const int rn = min(max(r + kAhead, 0), h - 1);
+        // (a strip without EDGE keeps kHalo + 1 + kAhead rows away from the top and bottom border -- the kernel's edge test -- so
+        //  its prefetch row needs no clamp: two scalar instructions less per step, each of which costs the wave an issue turn)
+        const int rn = EDGE ? min(max(r + kAhead, 0), h - 1) : r + kAhead;
 #endif
         const unsigned off = (static_cast<unsigned>(rn) * static_cast<unsigned>(a.pitch) + static_cast<unsigned>(xc)) * 4u;
 #ifdef FLOW2D_FUSED_SHORT_RING  // (probe: one row in flight)
@@ -501,7 +507,9 @@ __device__ __forceinline__ void strip_step(Strip<INNER, GRAD>& s, const FusedArg
         s.m_f0 = plane_load(a.f0, off);
         s.m_f1 = plane_load(a.f1, off);
         s.m_uv = v2f{plane_load(a.u, off), plane_load(a.v, off)};
-        s.m_duv = a.zero_increment ? v2f{0.f, 0.f} : v2f{plane_load(a.du, off), plane_load(a.dv, off)};
+        // the increment planes are read whether or not the launch treats them as zero (first outer iteration: they are valid planes
+        // with stale contents) and the zero is selected when the row is committed: no branch around two loads in every step
+        s.m_duv = v2f{plane_load(a.du, off), plane_load(a.dv, off)};
 #endif
     }
 
@@ -679,8 +687,9 @@ __device__ __forceinline__ void strip_step(Strip<INNER, GRAD>& s, const FusedArg
             float fx_l, fx_r, ft_l, ft_r, fx_u, fx_d, fy_u, fy_d, ft_u, ft_d;
             if (GRAD == 1 || GRAD == 3) {  // the reference's tile rule: own value at the 16x8 block edge and at the image edge
                 const int tx = x & 15, ty = rw & 7;
-                const bool x_lo = (tx == 0), x_hi = (tx == 15) || (x == w - 1);
-                const bool y_lo = (ty == 0), y_hi = (ty == 7) || (rw == h - 1);
+                // (a strip without EDGE holds no pixel of the last column or row: its tile rule is the block rule alone)
+                const bool x_lo = (tx == 0), x_hi = (tx == 15) || (EDGE && x == w - 1);
+                const bool y_lo = (ty == 0), y_hi = (ty == 7) || (EDGE && rw == h - 1);
                 fx_l = x_lo ? fxc : fx_l0, fx_r = x_hi ? fxc : fx_r0;
                 ft_l = x_lo ? ftc : ft_l0, ft_r = x_hi ? ftc : ft_r0;
                 fx_u = y_lo ? fxc : s.fxw[s0], fx_d = y_hi ? fxc : s.fxw[s1];
@@ -796,7 +805,7 @@ __device__ __forceinline__ void strip_step(Strip<INNER, GRAD>& s, const FusedArg
             s.UV[k][sc] = c.uvc + v2f{du_new, dv_new};
             old = s.duvc[k];                    // (du^k, dv^k) of row r-3-k, produced by this sweep one step ago
             s.duvc[k] = v2f{du_new, dv_new};    // of row r-2-k, for the next step
-        } else if (lane_stores && rk >= y0 && rk < y1) {
+        } else if (lane_stores) {  // (rk is in [y0, y1) in every step that gets here: run_strip's start-up and r_last)
 #ifdef FLOW2D_FUSED_COMPUTE_ONLY
             const unsigned off = (static_cast<unsigned>(rk & 7) * static_cast<unsigned>(a.pitch) + static_cast<unsigned>(xc)) * 4u;
 #else
@@ -819,26 +828,29 @@ __device__ __forceinline__ void strip_step(Strip<INNER, GRAD>& s, const FusedArg
     if (T < 0 && kTurnShift >= 0) s.turn_clock = __builtin_amdgcn_s_memtime();
 }
 
-template <int INNER, int GRAD, bool EDGE, bool POW2, bool CONT, bool FAST, bool SOR, size_t... Js>
+// one turn of the ring starting at ring position J0 (the start-up ends there)
+template <int INNER, int GRAD, bool EDGE, bool POW2, bool CONT, bool FAST, bool SOR, int J0, size_t... Is>
 __device__ __forceinline__ void strip_steps(Strip<INNER, GRAD>& s, const FusedArgs& a, int r_base, int x, int xc,
                                             bool at_l, bool at_r, bool lane_stores, int y0, int y1, 
-                                            float hx_2, float hy_2, std::index_sequence<Js...>)
+                                            float hx_2, float hy_2, std::index_sequence<Is...>)
 {
-    (strip_step<INNER, GRAD, EDGE, POW2, CONT, FAST, SOR, static_cast<int>(Js)>(s, a, r_base + static_cast<int>(Js), x, xc, at_l,
-                                                                     at_r, lane_stores, y0, y1, hx_2, hy_2),
+    constexpr int kRing = Strip<INNER, GRAD>::kRing;
+    (strip_step<INNER, GRAD, EDGE, POW2, CONT, FAST, SOR, (J0 + static_cast<int>(Is)) % kRing>(s, a, r_base + static_cast<int>(Is), x, xc, at_l,
+                                                                                    at_r, lane_stores, y0, y1, hx_2, hy_2),
      ...);
 }
 
 // the last, partial turn of the ring: the steps up to r_last only (wave-uniform guards)
-template <int INNER, int GRAD, bool EDGE, bool POW2, bool CONT, bool FAST, bool SOR, size_t... Js>
+template <int INNER, int GRAD, bool EDGE, bool POW2, bool CONT, bool FAST, bool SOR, int J0, size_t... Is>
 __device__ __forceinline__ void strip_tail(Strip<INNER, GRAD>& s, const FusedArgs& a, int r_base, int r_last, int x, int xc,
                                            bool at_l, bool at_r, bool lane_stores, int y0, int y1, float hx_2,
-                                           float hy_2, std::index_sequence<Js...>)
+                                           float hy_2, std::index_sequence<Is...>)
 {
-    ((r_base + static_cast<int>(Js) <= r_last
-          ? strip_step<INNER, GRAD, EDGE, POW2, CONT, FAST, SOR, static_cast<int>(Js)>(s, a, r_base + static_cast<int>(Js), x, xc,
-                                                                                at_l, at_r, lane_stores, y0, y1, hx_2,
-                                                                                hy_2)
+    constexpr int kRing = Strip<INNER, GRAD>::kRing;
+    ((r_base + static_cast<int>(Is) <= r_last
+          ? strip_step<INNER, GRAD, EDGE, POW2, CONT, FAST, SOR, (J0 + static_cast<int>(Is)) % kRing>(s, a, r_base + static_cast<int>(Is), x, xc,
+                                                                                               at_l, at_r, lane_stores, y0, y1, hx_2,
+                                                                                               hy_2)
           : (void)0),
      ...);
 }
@@ -896,13 +908,21 @@ __device__ __forceinline__ bool run_strip(const FusedArgs& a, int x, int xc, boo
         s.n_f0 = a.f0[o];
         s.n_f1 = a.f1[o];
         s.n_uv = v2f{a.u[o], a.v[o]};
+#if defined(FLOW2D_FUSED_SHORT_RING) || defined(FLOW2D_FUSED_THREE_AHEAD)
         s.n_duv = a.zero_increment ? v2f{0.f, 0.f} : v2f{a.du[o], a.dv[o]};
+#else
+        s.n_duv = v2f{a.du[o], a.dv[o]};
+#endif
         {
             const size_t o2 = static_cast<size_t>(min(max(r_first + 1, 0), a.h - 1)) * a.pitch + xc;
             s.m_f0 = a.f0[o2];
             s.m_f1 = a.f1[o2];
             s.m_uv = v2f{a.u[o2], a.v[o2]};
+#if defined(FLOW2D_FUSED_SHORT_RING) || defined(FLOW2D_FUSED_THREE_AHEAD)
             s.m_duv = a.zero_increment ? v2f{0.f, 0.f} : v2f{a.du[o2], a.dv[o2]};
+#else
+            s.m_duv = v2f{a.du[o2], a.dv[o2]};
+#endif
         }
 #ifdef FLOW2D_FUSED_THREE_AHEAD
         {
@@ -921,17 +941,20 @@ __device__ __forceinline__ bool run_strip(const FusedArgs& a, int x, int xc, boo
     }
     // the last stored row y1-1 leaves the last sweep at input row (y1-1) + 2 + INNER
     const int r_last = y1 - 1 + 2 + INNER;
-    // start-up steps (a whole number of ring turns, so the row loop starts at ring position 0), then the row loop
-    constexpr int kPeel = ((3 + 2 * INNER) / S::kRing) * S::kRing;
+    // start-up steps, then the row loop.  The start-up is exactly the 2 INNER + 3 steps before the last sweep first produces a row
+    // anybody stores (row y0 leaves it at input row y0 + 2 + INNER = r_first + 2 INNER + 3), so EVERY later step stores a row of
+    // [y0, y1): the steady-state steps carry no row test (five scalar instructions per step, each an issue turn of the wave).  The
+    // row loop therefore starts at ring position kPeel % kRing, not 0.
+    constexpr int kPeel = 2 * INNER + 3, kJ0 = kPeel % S::kRing;
     strip_startup<INNER, GRAD, EDGE, POW2, CONT, FAST, SOR>(s, a, r_first, x, xc, at_l, at_r, lane_stores, y0, y1, hx_2, hy_2,
                                                        std::make_index_sequence<kPeel>{});
     int r = r_first + kPeel;
     for (; r + S::kRing - 1 <= r_last; r += S::kRing) {
-        strip_steps<INNER, GRAD, EDGE, POW2, CONT, FAST, SOR>(s, a, r, x, xc, at_l, at_r, lane_stores, y0, y1, hx_2, hy_2,
-                                                         std::make_index_sequence<S::kRing>{});
+        strip_steps<INNER, GRAD, EDGE, POW2, CONT, FAST, SOR, kJ0>(s, a, r, x, xc, at_l, at_r, lane_stores, y0, y1, hx_2, hy_2,
+                                                              std::make_index_sequence<S::kRing>{});
     }
-    strip_tail<INNER, GRAD, EDGE, POW2, CONT, FAST, SOR>(s, a, r, r_last, x, xc, at_l, at_r, lane_stores, y0, y1, hx_2, hy_2,
-                                                    std::make_index_sequence<S::kRing - 1>{});
+    strip_tail<INNER, GRAD, EDGE, POW2, CONT, FAST, SOR, kJ0>(s, a, r, r_last, x, xc, at_l, at_r, lane_stores, y0, y1, hx_2, hy_2,
+                                                         std::make_index_sequence<S::kRing - 1>{});
     return guard_tripped(s.guard);
 }
 
@@ -1009,7 +1032,8 @@ __global__ __launch_bounds__(256, FLOW2D_FUSED_WAVES) FLOW2D_FUSED_VGPR_ATTR voi
 
     // does any row or column this wave touches sit on an image border?  (a superset test is fine)
     const int x_first = strip_x * S::kValid - S::kHalo;
-    const bool edge = x_first <= 0 || x_first + 63 >= a.w - 1 || y0 <= S::kHalo + 1 || y1 + S::kHalo + 1 >= a.h;
+    // (rows: the strip reads y0 - kHalo .. y1 + kHalo + 1 + rows in flight; the interior body fetches them unclamped)
+    const bool edge = x_first <= 0 || x_first + 63 >= a.w - 1 || y0 <= S::kHalo + 1 || y1 + S::kHalo + 4 >= a.h;
     bool bad = a.plain_only != 0;
     if (bad)
         ;
