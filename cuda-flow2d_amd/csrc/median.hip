@@ -101,6 +101,18 @@ struct Source {
     }
 };
 
+// The streaming kernels address a plane as base pointer (wave-uniform: a scalar register pair) + one 32-bit per-lane BYTE offset
+// (global_load / global_store ... saddr), like the strip kernel of the solver: a 64-bit address per access was two to three
+// vector instructions each, a quarter of the kernel.  Planes of 4 GiB and more take the generic kernel (launch_median).
+__device__ __forceinline__ float plane_load(const float* plane, unsigned byte_offset)
+{
+    return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(plane) + static_cast<size_t>(byte_offset));
+}
+__device__ __forceinline__ void plane_store(float* plane, unsigned byte_offset, float value)
+{
+    *reinterpret_cast<float*>(reinterpret_cast<char*>(plane) + static_cast<size_t>(byte_offset)) = value;
+}
+
 // v_cmp_class mask: signalling NaN, quiet NaN, negative zero
 constexpr int kSpecialClass = 0x1 | 0x2 | 0x20;
 __device__ __forceinline__ bool is_special(float v) { return __builtin_amdgcn_classf(v, kSpecialClass); }
@@ -236,14 +248,14 @@ template <bool EDGE, bool ADD>
 __device__ __forceinline__ RowLoad<EDGE, ADD> load_row(const Source<ADD> in, int row, int h, int pitch, int xc,
                                                        const int (&xm)[5])
 {
-    const size_t line = static_cast<size_t>(min(max(mirror_index(row, h), 0), h - 1)) * pitch;
+    const unsigned line = static_cast<unsigned>(min(max(mirror_index(row, h), 0), h - 1)) * static_cast<unsigned>(pitch);
     RowLoad<EDGE, ADD> r;
     r.a[0] = 0.f;
 #pragma unroll
     for (int i = 0; i < (EDGE ? 5 : 1); ++i) {
-        const size_t at = line + (EDGE ? xm[i] : xc);
-        r.v[i] = in.in[at];
-        if (ADD) r.a[i] = in.add[at];
+        const unsigned at = (line + static_cast<unsigned>(EDGE ? xm[i] : xc)) * 4u;
+        r.v[i] = plane_load(in.in, at);
+        if (ADD) r.a[i] = plane_load(in.add, at);
     }
     return r;
 }
@@ -296,8 +308,9 @@ __device__ __forceinline__ void median5_step(float (&ring)[6][5], RowLoad<EDGE, 
     for (int i = 30; i < kMedianPairWires; ++i) v[i] = 0.f;
     run_pair_program(v, std::make_index_sequence<kMedianPairOps>{});
     if (lane_stores) {
-        out[static_cast<size_t>(ya) * pitch + x] = v[kMedianPairOutA];
-        if (ya + 1 < y1) out[static_cast<size_t>(ya + 1) * pitch + x] = v[kMedianPairOutB];
+        const unsigned at = (static_cast<unsigned>(ya) * static_cast<unsigned>(pitch) + static_cast<unsigned>(x)) * 4u;
+        plane_store(out, at, v[kMedianPairOutA]);
+        if (ya + 1 < y1) plane_store(out, at + static_cast<unsigned>(pitch) * 4u, v[kMedianPairOutB]);
     }
 }
 
@@ -422,14 +435,14 @@ template <bool EDGE, bool ADD>
 __device__ __forceinline__ Row7Load<EDGE, ADD> load_row7(const Source<ADD> in, int row, int h, int pitch, int xc,
                                                          const int (&xm)[7])
 {
-    const size_t line = static_cast<size_t>(min(max(mirror_index(row, h), 0), h - 1)) * pitch;
+    const unsigned line = static_cast<unsigned>(min(max(mirror_index(row, h), 0), h - 1)) * static_cast<unsigned>(pitch);
     Row7Load<EDGE, ADD> r;
     r.a[0] = 0.f;
 #pragma unroll
     for (int i = 0; i < (EDGE ? 7 : 1); ++i) {
-        const size_t at = line + (EDGE ? xm[i] : xc);
-        r.v[i] = in.in[at];
-        if (ADD) r.a[i] = in.add[at];
+        const unsigned at = (line + static_cast<unsigned>(EDGE ? xm[i] : xc)) * 4u;
+        r.v[i] = plane_load(in.in, at);
+        if (ADD) r.a[i] = plane_load(in.add, at);
     }
     return r;
 }
@@ -481,8 +494,9 @@ __device__ __forceinline__ void median7_step(float (&ring)[8][7], Row7Load<EDGE,
     for (int i = 56; i < kMedian7PairWires; ++i) v[i] = 0.f;
     run_pair7_program(v, std::make_index_sequence<kMedian7PairOps>{});
     if (lane_stores) {
-        out[static_cast<size_t>(ya) * pitch + x] = v[kMedian7PairOutA];
-        if (ya + 1 < y1) out[static_cast<size_t>(ya + 1) * pitch + x] = v[kMedian7PairOutB];
+        const unsigned at = (static_cast<unsigned>(ya) * static_cast<unsigned>(pitch) + static_cast<unsigned>(x)) * 4u;
+        plane_store(out, at, v[kMedian7PairOutA]);
+        if (ya + 1 < y1) plane_store(out, at + static_cast<unsigned>(pitch) * 4u, v[kMedian7PairOutB]);
     }
 }
 
@@ -595,7 +609,8 @@ static int launch_median(flow2d_context* ctx, const float* input, const float* i
     const dim3 grid(flow2d::div_up(width, kBlockX), flow2d::div_up(height, kBlockY), z);
     const dim3 block(kBlockX, kBlockY);
     const int w = (int)width, h = (int)height, pitch = (int)(pitch_bytes / 4);
-    if (window == 5 && width >= 8 && height >= 8) {  // mirrored rows/columns up to 3 beyond the border stay inside
+    const bool offsets_fit = static_cast<unsigned long long>(pitch_bytes) * height < (1ull << 32);  // the streaming kernels' 32-bit byte offsets
+    if (window == 5 && width >= 8 && height >= 8 && offsets_fit) {  // mirrored rows/columns up to 3 beyond the border stay inside
         const int rows = median5_rows_per_strip(ctx, width, height);
         const dim3 sgrid(flow2d::div_up(flow2d::div_up(width, kStreamValid), 4), flow2d::div_up(height, rows), z);
         median5_stream_kernel<ADD><<<sgrid, 256, 0, ctx->stream>>>(input, input_b, addend, addend_b, w, h, pitch, rows, output,
@@ -603,7 +618,7 @@ static int launch_median(flow2d_context* ctx, const float* input, const float* i
         FLOW2D_CHECK_LAUNCH();
         return FLOW2D_OK;
     }
-    if (window == 7 && width >= 12 && height >= 12) {  // mirrored rows/columns up to 5 beyond the border stay inside
+    if (window == 7 && width >= 12 && height >= 12 && offsets_fit) {  // mirrored rows/columns up to 5 beyond the border stay inside
         const int rows = median5_rows_per_strip(ctx, width, height);
         const dim3 sgrid(flow2d::div_up(flow2d::div_up(width, kStream7Valid), 4), flow2d::div_up(height, rows), z);
         median7_stream_kernel<ADD><<<sgrid, 256, 0, ctx->stream>>>(input, input_b, addend, addend_b, w, h, pitch, rows, output,
