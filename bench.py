@@ -469,7 +469,11 @@ class Job:
         # A step is still one pair's whole pyramid; K steps are K pairs.
         self.step_group = 1
         if self.single:
-            self.step_group = args.step_group if args.step_group > 0 else (8 if w * h <= 1024 * 1024 else 4 if w * h <= 2048 * 2048 else 2 if w * h <= 4096 * 4096 else 1)
+            # (round 5, profiles/r05_experiments/step_group_sweeps.txt: 584 x 388 8 / 16 / 32 / 64 -> 1 707 / 1 973 / 2 340 / 2 007 pairs/s,
+            #  1024^2 4 391 / 4 711 / 4 890 / 4 512, 4096^2 2 / 4 / 8 -> 332 / 338 / 345 at the driver's 20 steps and 340 / 345 / 348 at 100,
+            #  8192^2 1 / 2 -> 96.4 / 94.3: the small kernels and coarse levels of a group share launches, and every launch of a
+            #  graph costs its stream 4-5 us)
+            self.step_group = args.step_group if args.step_group > 0 else (32 if w * h <= 1024 * 1024 else 16 if w * h <= 2048 * 2048 else 8 if w * h <= 4096 * 4096 else 1)
         self.pending = []
         self.rotate = self.single or self.grouped  # a step is one entry; steps rotate over the lanes
         self.n_lanes = max(1, min(args.max_lanes, args.pipeline if self.rotate else cfg["pairs_per_rank"] * args.pipeline))
@@ -674,14 +678,20 @@ def host_entry_leg(job, batch, torch, steps):
     frames = [workload_pair(job.workload, cfg, gk, job.world) for gk in job.owned]
     f0s = [flow2d.HostImage(w, h, True, f[0]) for f in frames]
     f1s = [flow2d.HostImage(w, h, True, f[1]) for f in frames]
-    N = job.step_group  # steps handed over together (config 2: the batch object forms a lock-step group of them)
+    # steps handed over together (the batch object forms a lock-step group of them).  With host copies inside the bracket a large
+    # group delays its first kernel behind all of its uploads and its downloads behind its last kernel: smaller groups than the
+    # device-resident region's above 512^2 (4096^2, groups of 8 / 2: 273 / 322 pairs/s; 1024^2, 32 / 8: 2 966 / 3 724; 584 x 388
+    # is launch-bound either way: 32 / 8: 2 122 / 1 769)
+    N = job.step_group if w * h <= 512 * 512 else min(job.step_group, 8 if w * h <= 1024 * 1024 else 4 if w * h <= 2048 * 2048 else 2)
     n_sets = 2 * job.n_lanes * N
     steps = max(N, steps // N * N)
     outs = [([flow2d.HostImage(w, h, True) for _ in range(G)], [flow2d.HostImage(w, h, True) for _ in range(G)])
             for _ in range(n_sets)]
     images = f0s + f1s + [q for us, vs in outs for q in us + vs]
     pinned = all(q.pinned for q in images)
-    runner = job.runner
+    # (the host-image entry takes whole lock-step groups only: a smaller group needs a batch object of its own)
+    own_runner = job.step_group > 1 and N != job.step_group
+    runner = flow2d.OpticalFlowBatch(w, h, cfg["constancy"], lanes=job.n_lanes, device=job.local_rank, group_size=N) if own_runner else job.runner
     runner.use_graph(not job.args.no_graph)
 
     def call(c):
@@ -725,6 +735,8 @@ def host_entry_leg(job, batch, torch, steps):
     finally:
         for q in images:
             q.close()
+        if own_runner:
+            runner.close()
 
 
 def oracle_check(job):
@@ -1002,6 +1014,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-reference-baseline", action="store_true")
     ap.add_argument("--no-batch-leg", action="store_true")
+    ap.add_argument("--batch-leg-last", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--no-oracle-check", action="store_true",
                     help="skip comparing the first pair's flow with the CPU oracle (output_check.oracle)")
     ap.add_argument("--no-host-entry-leg", action="store_true", help="skip the H<->D-inclusive leg (pairs_per_s_incl_h2d)")
@@ -1012,7 +1025,7 @@ def main():
     ap.add_argument("--max-lanes", type=int, default=4, help="upper bound on the lanes (streams) per GPU")
     ap.add_argument("--step-group", type=int, default=0,
                     help="single-pair workloads: consecutive steps handed to the batch entry this many at a time, which "
-                         "forms a lock-step group of them (0 = automatic: 8 up to 1024^2, 4 up to 2048^2, 2 up to 4096^2, else 1; the "
+                         "forms a lock-step group of them (0 = automatic: 32 up to 1024^2, 16 up to 2048^2, 8 up to 4096^2, else 1; the "
                          "finest level of a 4096^2 group still runs one launch per pair)")
     ap.add_argument("--batch-mode", choices=["groups", "lanes"], default="groups",
                     help="batched workloads: all pairs of a step as one lock-step group (every kernel launched once for "
@@ -1065,6 +1078,13 @@ def main():
     batch.init(backend="gloo" if args.rehearse_on_one_gpu else "nccl", device=torch.device("cuda", local_rank))
 
     w, h = cfg["w"], cfg["h"]
+    # The batch leg (BASELINE.json configs[3]) runs FIRST, on a GPU nothing else has touched yet, and is gone before the main job
+    # allocates: behind the main job's legs it read low by amounts that changed with what ran before it (after the sampling legs
+    # 8-9 % in rounds 4 and 5; behind a main job of eight-pair groups and its host-entry leg 2 281 against 2 530-2 630 pairs/s:
+    # profiles/r05_experiments/batch_leg_bisect.txt, batch_leg_first_ab.txt).  The line's `value` is the main job's region below.
+    batch_result = None
+    if not args.no_batch_leg and args.workload != BATCH_WORKLOAD and not args.batch_leg_last:
+        batch_result = batch_leg(flow2d, batch, torch, args, rank, local_rank, world)
     job = Job(flow2d, batch, args.workload, cfg, args, rank, local_rank, world)
     free_b, total_b = job.ctx.mem_info()
     plane_b = job.runner.pitch * h * (job.group if job.step_group == 1 else job.step_group)  # a (group-tall) container
@@ -1098,11 +1118,7 @@ def main():
                                    sync=lambda: None)
     job.close()
 
-    # the batch leg comes right after the main job, before the sampling legs (eager instrumented passes, per-sweep launches, a
-    # 512 MiB copy): after them it read 8-9 % low in rounds 4 and 5 (2 160-2 200 pairs/s against 2 380-2 400 for the same
-    # workload on its own, whatever else was switched off: profiles/r05_experiments/batch_leg_bisect.txt)
-    batch_result = None
-    if not args.no_batch_leg and args.workload != BATCH_WORKLOAD:
+    if not args.no_batch_leg and args.workload != BATCH_WORKLOAD and args.batch_leg_last:  # (developer A/B: where rounds 4-5 had it)
         batch_result = batch_leg(flow2d, batch, torch, args, rank, local_rank, world)
 
     finest, pair_latency_ms = roofline_sample(sample)
