@@ -10,7 +10,11 @@ N > 1: one process per GPU (torch.distributed, backend nccl = RCCL), every rank 
 no data-path collective (independent pairs: SURVEY 8e) -> weak scaling.  Rank 0 prints ONE JSON line.
 
 Order of a run
-  1. warm-up (records the HIP graphs), barrier
+  0. batch leg (BASELINE.json configs[3]), a side figure of the line (`batch`): 8 pairs of 1920x1080 per GPU as one lock-step group
+     per step on 4 streams, >= 64 steps, median of three regions; then the flow fields of all ranks are gathered to rank 0 over RCCL
+     (timed separately: gather.ms).  It runs first, on an untouched GPU, and is closed before the main job allocates (behind the
+     main job it read low by amounts that depended on what had run before it)
+  1. warm-up of the main job (records the HIP graphs), barrier
   2. TIMED REGIONS: `--repeats` (5) regions of exactly K steps each, replayed from the recorded graphs, nothing else; barrier
      around each; max over ranks; the line reports the MEDIAN region (ms_per_step, value, pairs_per_s) and the fastest / slowest
   3. output check: the flow fields the timed steps left in HBM are hashed; an eager (un-graphed) recomputation
@@ -18,11 +22,9 @@ Order of a run
      every plane set in flight holds a DIFFERENT synthetic pair (distinct_pairs_in_flight)
   4. host-entry leg: the same pairs from HOST images to HOST flows (uploads and downloads inside the bracket, pipelined
      against the pyramids by OpticalFlowBatch2D::ComputeFlowBatch): pairs_per_s_incl_h2d, SURVEY 8(d) metric 2 as defined
-  5. batch leg (BASELINE.json configs[3]): 8 pairs of 1920x1080 per GPU as one lock-step group per step on 4 streams, >= 64 steps,
-     median of three regions; then the flow fields of all ranks are gathered to rank 0 over RCCL (timed separately: gather.ms)
-  6. roofline sample: eager passes with HIP events on the launch stream around every finest-level solver launch; the per-sweep
+  5. roofline sample: eager passes with HIP events on the launch stream around every finest-level solver launch; the per-sweep
      kernel alone; a device-to-device copy for scale
-  7. baselines on rank 0 at N = 1: the CPU oracle on the workload's pair; the reference's own kernels (oracle/_ref,
+  6. baselines on rank 0 at N = 1: the CPU oracle on the workload's pair; the reference's own kernels (oracle/_ref,
      compiled from its sources for gfx950) with the reference's launch schedule on this GPU
   (--workload cfg3_4096_sor: the opt-in red-black SOR mode and its leg against Jacobi on the whole pyramid)
 
