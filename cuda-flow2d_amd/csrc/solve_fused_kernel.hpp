@@ -62,6 +62,7 @@
 //   FLOW2D_FUSED_NO_LANE_SHIFT   timing probe, WRONG results: x neighbours = the lane's own value, no DPP instruction (with the
 //                                packed-fp32-ops feature off: a row step of plain instructions only -- what would that stream cost?)
 //   FLOW2D_FUSED_THREE_AHEAD     three input rows in flight instead of two (six more registers)
+//   FLOW2D_FUSED_NT_STORE, FLOW2D_FUSED_NT_LOAD   non-temporal stores of the result rows / loads of the input rows
 //   FLOW2D_FUSED_VGPR_BUDGET=n   a register budget below the 256 that two waves per SIMD allow (room for other lanes' kernels beside a launch)
 //   FLOW2D_FUSED_WAVES=n         __launch_bounds__(256, n)
 //   FLOW2D_FUSED_FULL_WEIGHTS    stage W's face weights as (a + b) / 2.f * w (rounds 1-4) instead of (a + b) * (w / 2), for A/B
@@ -72,7 +73,7 @@
 #if (defined(FLOW2D_FUSED_STAMPS) || defined(FLOW2D_FUSED_SHORT_RING) || defined(FLOW2D_FUSED_WAVES) || defined(FLOW2D_FUSED_COMPUTE_ONLY) || defined(FLOW2D_FUSED_MEMORY_ONLY) ||          \
      defined(FLOW2D_FUSED_TURN_SHIFT) || defined(FLOW2D_FUSED_PLAIN_DIVISION) || defined(FLOW2D_FUSED_NO_PINS) ||          \
      defined(FLOW2D_FUSED_DEV) || defined(FLOW2D_FUSED_EDGE_COST) || defined(FLOW2D_FUSED_NO_SPLIT) ||                    \
-     defined(FLOW2D_FUSED_PLAIN_ORDER) || defined(FLOW2D_FUSED_INJECT) || defined(FLOW2D_FUSED_FULL_WEIGHTS) || defined(FLOW2D_FUSED_NO_LANE_SHIFT) || defined(FLOW2D_FUSED_THREE_AHEAD) || defined(FLOW2D_FUSED_VGPR_BUDGET)) &&                                                                               \
+     defined(FLOW2D_FUSED_PLAIN_ORDER) || defined(FLOW2D_FUSED_INJECT) || defined(FLOW2D_FUSED_FULL_WEIGHTS) || defined(FLOW2D_FUSED_NO_LANE_SHIFT) || defined(FLOW2D_FUSED_THREE_AHEAD) || defined(FLOW2D_FUSED_VGPR_BUDGET) || defined(FLOW2D_FUSED_NT_STORE) || defined(FLOW2D_FUSED_NT_LOAD)) &&                                                                               \
     !defined(FLOW2D_DEV_BUILD)
 #error "the fused kernel's timing probes need -DFLOW2D_DEV_BUILD: they are not part of the product library"
 #endif
@@ -94,11 +95,19 @@ constexpr int kStampWords = 8, kStampWaves = 1 << 16;
 // lanes and read back, 24 v_readlane per row step.)  Planes stay below 4 GiB (fused_addressable).
 __device__ __forceinline__ float plane_load(const float* plane, unsigned byte_offset)
 {
+#ifdef FLOW2D_FUSED_NT_LOAD  // developer A/B: non-temporal loads of the input rows
+    return __builtin_nontemporal_load(reinterpret_cast<const float*>(reinterpret_cast<const char*>(plane) + static_cast<size_t>(byte_offset)));
+#else
     return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(plane) + static_cast<size_t>(byte_offset));
+#endif
 }
 __device__ __forceinline__ void plane_store(float* plane, unsigned byte_offset, float value)
 {
+#ifdef FLOW2D_FUSED_NT_STORE  // developer A/B: streaming (non-temporal) stores of the result rows
+    __builtin_nontemporal_store(value, reinterpret_cast<float*>(reinterpret_cast<char*>(plane) + static_cast<size_t>(byte_offset)));
+#else
     *reinterpret_cast<float*>(reinterpret_cast<char*>(plane) + static_cast<size_t>(byte_offset)) = value;
+#endif
 }
 
 // lane i receives lane i-1 (wave_shr:1) / lane i+1 (wave_shl:1); the end lanes of the wave receive 0
