@@ -64,6 +64,7 @@
 //   FLOW2D_FUSED_THREE_AHEAD     three input rows in flight instead of two (six more registers)
 //   FLOW2D_FUSED_NT_STORE, FLOW2D_FUSED_NT_LOAD   non-temporal stores of the result rows / loads of the input rows
 //   FLOW2D_FUSED_VGPR_BUDGET=n   a register budget below the 256 that two waves per SIMD allow (room for other lanes' kernels beside a launch)
+//   FLOW2D_FUSED_STAGGER=n       the waves start in four phases n x 64 cycles apart
 //   FLOW2D_FUSED_WAVES=n         __launch_bounds__(256, n)
 //   FLOW2D_FUSED_FULL_WEIGHTS    stage W's face weights as (a + b) / 2.f * w (rounds 1-4) instead of (a + b) * (w / 2), for A/B
 //   FLOW2D_FUSED_ORDER=1 / 2     stage W (2: and stage P) of a row step after its sweeps instead of before them: the step as two
@@ -73,7 +74,7 @@
 #if (defined(FLOW2D_FUSED_STAMPS) || defined(FLOW2D_FUSED_SHORT_RING) || defined(FLOW2D_FUSED_WAVES) || defined(FLOW2D_FUSED_COMPUTE_ONLY) || defined(FLOW2D_FUSED_MEMORY_ONLY) ||          \
      defined(FLOW2D_FUSED_TURN_SHIFT) || defined(FLOW2D_FUSED_PLAIN_DIVISION) || defined(FLOW2D_FUSED_NO_PINS) ||          \
      defined(FLOW2D_FUSED_DEV) || defined(FLOW2D_FUSED_EDGE_COST) || defined(FLOW2D_FUSED_NO_SPLIT) ||                    \
-     defined(FLOW2D_FUSED_PLAIN_ORDER) || defined(FLOW2D_FUSED_INJECT) || defined(FLOW2D_FUSED_FULL_WEIGHTS) || defined(FLOW2D_FUSED_NO_LANE_SHIFT) || defined(FLOW2D_FUSED_THREE_AHEAD) || defined(FLOW2D_FUSED_VGPR_BUDGET) || defined(FLOW2D_FUSED_NT_STORE) || defined(FLOW2D_FUSED_NT_LOAD)) &&                                                                               \
+     defined(FLOW2D_FUSED_PLAIN_ORDER) || defined(FLOW2D_FUSED_INJECT) || defined(FLOW2D_FUSED_FULL_WEIGHTS) || defined(FLOW2D_FUSED_NO_LANE_SHIFT) || defined(FLOW2D_FUSED_THREE_AHEAD) || defined(FLOW2D_FUSED_VGPR_BUDGET) || defined(FLOW2D_FUSED_NT_STORE) || defined(FLOW2D_FUSED_NT_LOAD) || defined(FLOW2D_FUSED_STAGGER)) &&                                                                               \
     !defined(FLOW2D_DEV_BUILD)
 #error "the fused kernel's timing probes need -DFLOW2D_DEV_BUILD: they are not part of the product library"
 #endif
@@ -990,6 +991,12 @@ template <int INNER, int GRAD, bool POW2, bool CONT, bool SOR = false>
 __global__ __launch_bounds__(256, FLOW2D_FUSED_WAVES) FLOW2D_FUSED_VGPR_ATTR void fused_outer_kernel(FusedArgs a)
 {
     using S = Strip<INNER, GRAD>;
+#ifdef FLOW2D_FUSED_STAGGER  // developer A/B: the waves of a launch start in four phases, n x 64 cycles apart (do their memory bursts collide?)
+    {
+        const unsigned phase = (blockIdx.x + (threadIdx.x >> 6)) & 3u;
+        for (unsigned i = 0; i < phase; ++i) __builtin_amdgcn_s_sleep(FLOW2D_FUSED_STAGGER);
+    }
+#endif
     const int lane = threadIdx.x & 63;
 #ifdef FLOW2D_FUSED_STAMPS
     const unsigned long long stamp_r0 = __builtin_amdgcn_s_memrealtime(), stamp_c0 = __builtin_amdgcn_s_memtime();
