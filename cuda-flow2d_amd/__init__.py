@@ -79,6 +79,10 @@ def hip_lib():
         L.flow2d_last_error.restype = C.c_char_p
         L.flow2d_device_count.argtypes = [C.POINTER(i)]
         L.flow2d_hw_queues.restype = i
+        L.flow2d_request_hw_queues.argtypes = [i]
+        # the lanes of the batched path want a hardware queue each; a refusal (HIP already running, e.g. under torch: bench.py
+        # exports the variable itself) is reported by flow2d_last_error() and OpticalFlowBatch2D's warning, not here
+        L.flow2d_request_hw_queues(8)
         L.flow2d_context_create.argtypes = [i, C.POINTER(vp)]
         L.flow2d_context_create_on_stream.argtypes = [i, vp, C.POINTER(vp)]
         L.flow2d_context_destroy.argtypes = [vp]

@@ -6,19 +6,25 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <unistd.h>
 
 #include "common.hpp"
 
 namespace {
 thread_local std::string g_last_error;
 
-// The HIP runtime deals a process's streams onto GPU_MAX_HW_QUEUES hardware queues (default 4) and reads the variable
-// once, when it initialises (the first HIP call of the process).  The batched host path keeps four lanes (streams) busy
-// next to whatever other stream the process owns (RCCL's, the caller's): with the default, two lanes share a queue and
-// wait behind each other (4096^2, four lanes: 205 instead of 224 pairs/s).  So the library asks for eight queues when
-// it is loaded, unless the caller has set the variable; a process that initialised HIP before loading the library keeps
-// what it had (flow2d_hw_queues() tells, OpticalFlowBatch2D warns).
-__attribute__((constructor)) void ask_for_hardware_queues() { setenv("GPU_MAX_HW_QUEUES", "8", 0); }
+// Has this process started the HIP runtime?  The runtime opens the kernel driver's device node when it initialises and keeps it
+// open: a descriptor of /dev/kfd among the process's own is the sign (no HIP call can answer the question without starting it).
+bool hip_runtime_started()
+{
+    char link[64], target[64];
+    for (int fd = 0; fd < 1024; ++fd) {
+        std::snprintf(link, sizeof(link), "/proc/self/fd/%d", fd);
+        const ssize_t n = readlink(link, target, sizeof(target) - 1);
+        if (n > 0 && std::string(target, static_cast<size_t>(n)) == "/dev/kfd") return true;
+    }
+    return false;
+}
 }
 
 namespace flow2d {
@@ -68,6 +74,30 @@ int flow2d_hw_queues(void)
     const char* v = std::getenv("GPU_MAX_HW_QUEUES");
     const int n = v ? std::atoi(v) : 0;
     return n > 0 ? n : 4;
+}
+
+// The HIP runtime deals a process's streams onto GPU_MAX_HW_QUEUES hardware queues (default 4) and reads the variable once, when
+// it initialises (the first HIP call of the process).  The batched host path keeps four lanes (streams) busy next to whatever
+// other stream the process owns (RCCL's, the caller's): with the default, two lanes share a queue and wait behind each other
+// (4096^2, four lanes: 205 instead of 224 pairs/s).  The host layer therefore asks for eight queues before its first HIP call.
+// (Rounds 2-5 did it from a library constructor -- a side effect of dlopen on the host process that silently did nothing when
+// HIP was already running; now it is a call, and it says when it came too late.)
+int flow2d_request_hw_queues(int queues)
+{
+    if (queues < 1) return FLOW2D_ERR_INVALID_ARGUMENT;
+    const bool set_by_caller = std::getenv("GPU_MAX_HW_QUEUES") != nullptr;
+    if (flow2d_hw_queues() >= queues && (set_by_caller || queues <= 4)) return FLOW2D_OK;  // (unset: the runtime's default of 4)
+    if (set_by_caller) {
+        flow2d::set_last_error_text("GPU_MAX_HW_QUEUES is set to fewer queues than requested; the caller's value stands");
+        return FLOW2D_ERR_UNSUPPORTED;
+    }
+    if (hip_runtime_started()) {
+        flow2d::set_last_error_text("the HIP runtime of this process was started before flow2d_request_hw_queues: it keeps its default of 4 "
+                                    "hardware queues (export GPU_MAX_HW_QUEUES, or call this before the first HIP call)");
+        return FLOW2D_ERR_UNSUPPORTED;
+    }
+    setenv("GPU_MAX_HW_QUEUES", std::to_string(queues).c_str(), 1);
+    return FLOW2D_OK;
 }
 
 int flow2d_device_count(int* count)

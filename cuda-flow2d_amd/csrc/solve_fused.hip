@@ -9,6 +9,7 @@
 
 #include "common.hpp"
 #include "solve_fused_args.hpp"
+#include "solve_fused_probes.hpp"
 
 namespace {
 
@@ -23,19 +24,64 @@ bool is_power_of_two(float x)
 
 namespace flow2d {
 
-#ifdef FLOW2D_FUSED_STAMPS
-// developer builds: one device buffer for the wave stamps of all instance objects (allocated at the first launch)
+namespace probe = flow2d_probe;
+
+#ifdef FLOW2D_DEV_BUILD
+// developer builds: one device buffer for the wave stamps of all instance objects, their counter behind them, and one for the
+// waves' stall histograms (allocated at the first launch)
 static unsigned long long* stamp_buffer()
 {
     static unsigned long long* p = [] {
         void* q = nullptr;
-        (void)hipMalloc(&q, (size_t(1) << 16) * 8 * sizeof(unsigned long long) + sizeof(unsigned long long));
-        (void)hipMemset(q, 0, (size_t(1) << 16) * 8 * sizeof(unsigned long long) + sizeof(unsigned long long));
+        const size_t bytes = size_t(probe::kStampWaves) * probe::kStampWords * sizeof(unsigned long long) + sizeof(unsigned long long);
+        (void)hipMalloc(&q, bytes);
+        (void)hipMemset(q, 0, bytes);
         return static_cast<unsigned long long*>(q);
     }();
     return p;
 }
-static unsigned int* stamp_counter() { return reinterpret_cast<unsigned int*>(stamp_buffer() + (size_t(1) << 16) * 8); }
+static unsigned int* stamp_counter() { return reinterpret_cast<unsigned int*>(stamp_buffer() + size_t(probe::kStampWaves) * probe::kStampWords); }
+static unsigned int* stall_buffer()
+{
+    static unsigned int* p = [] {
+        void* q = nullptr;
+        const size_t bytes = size_t(probe::kStallWaves) * probe::kStallRows * 64 * sizeof(unsigned int);
+        (void)hipMalloc(&q, bytes);
+        (void)hipMemset(q, 0, bytes);
+        return static_cast<unsigned int*>(q);
+    }();
+    return p;
+}
+
+// packed-planes probe: (f0, f1, u, v) of a pixel side by side in one float4 plane, (du, dv) in a float2 plane; the launcher packs
+// before and unpacks after every launch (the kernel alone is what the probe times: stamps or a kernel trace)
+struct PackedPlanes {
+    float *in = nullptr, *duv = nullptr, *out = nullptr;
+    size_t floats = 0;
+};
+static PackedPlanes& packed_planes(size_t plane_floats)
+{
+    static PackedPlanes p;
+    if (p.floats < plane_floats) {
+        (void)hipFree(p.in), (void)hipFree(p.duv), (void)hipFree(p.out);
+        (void)hipMalloc(reinterpret_cast<void**>(&p.in), plane_floats * 16);
+        (void)hipMalloc(reinterpret_cast<void**>(&p.duv), plane_floats * 8);
+        (void)hipMalloc(reinterpret_cast<void**>(&p.out), plane_floats * 8);
+        p.floats = plane_floats;
+    }
+    return p;
+}
+__global__ void pack_planes_kernel(const float* f0, const float* f1, const float* u, const float* v, const float* du, const float* dv,
+                                   float4* in, float2* duv, size_t n)
+{
+    const size_t i = blockIdx.x * size_t(blockDim.x) + threadIdx.x;
+    if (i < n) in[i] = make_float4(f0[i], f1[i], u[i], v[i]), duv[i] = make_float2(du[i], dv[i]);
+}
+__global__ void unpack_planes_kernel(const float2* out, float* du, float* dv, size_t n)
+{
+    const size_t i = blockIdx.x * size_t(blockDim.x) + threadIdx.x;
+    if (i < n) du[i] = out[i].x, dv[i] = out[i].y;
+}
 #endif
 
 bool fused_supports(size_t inner) { return inner >= 1 && inner <= 5; }
@@ -68,12 +114,8 @@ bool fused_addressable(size_t h, size_t pitch_bytes) { return h != 0 && pitch_by
 struct FusedPlan {
     int rows_interior, rows_edge, strips_interior, blocks_x, blocks;  // blocks: the launch's grid (per batch instance)
 };
-// EDGE body / interior body: 1.2-1.26 in VALU instructions per row step (swept 1.0 ... 1.38 in round 3: 1.22)
-#ifdef FLOW2D_FUSED_EDGE_COST
-static const double kEdgeCost = FLOW2D_FUSED_EDGE_COST;
-#else
+// EDGE body / interior body: 1.2-1.26 in VALU instructions per row step (swept 1.0 ... 1.38 in rounds 3 and 5: 1.22)
 static const double kEdgeCost = 1.22;
-#endif
 
 static FusedPlan fused_plan_search(const flow2d_context* ctx, size_t w, size_t h, size_t inner, long instances);
 
@@ -93,11 +135,10 @@ FusedPlan fused_plan(const flow2d_context* ctx, size_t w, size_t h, size_t inner
 
 static FusedPlan fused_plan_search(const flow2d_context* ctx, size_t w, size_t h, size_t inner, long instances)
 {
-    const int valid = 64 - 2 * ((int)inner + 1);
+    const int valid = probe::kNoHalo ? 64 : 64 - 2 * ((int)inner + 1);
     const long blocks_x = (div_up(w, valid) + 3) / 4;
     const long cus = ctx->num_cus > 0 ? ctx->num_cus : 256;
     const long cap = cus * 2;
-    const int ring = (((int)inner + 1 + 2) / 3) * 3;
     const int peel = 3 + 2 * (int)inner;  // run_strip's start-up steps
     double saved = 2 * 102.0 + 3 * 20.0;
     for (int k = 1; k <= (int)inner; ++k) saved += 46.0 * std::min(3 + 2 * k, peel);
@@ -110,11 +151,7 @@ static FusedPlan fused_plan_search(const flow2d_context* ctx, size_t w, size_t h
     // 0 / 1 / 2 / 3 on one box (profiles/r04_experiments/plan_work_weight_ab.txt): config 2 3 993-4 103 / 4 107-4 120 / 4 199-4 211 /
     // 4 220-4 266 pairs/s, rub1-rub2 1 535-1 540 / 1 586-1 591 / 1 622-1 630 / 1 622-1 625, configs 3, 4, 5 unchanged; a lone 1080p
     // pair 1.10 / 1.09 / 1.11 / 1.14 ms, a lone 1024^2 pair 0.67 / 0.65 / 0.65 / 0.67 ms: two.
-#ifdef FLOW2D_DEV_BUILD
-    static const double bias = std::getenv("FLOW2D_FUSED_PLAN_BIAS") ? std::atof(std::getenv("FLOW2D_FUSED_PLAN_BIAS")) : 2.0;
-#else
     const double bias = 2.0;
-#endif
     auto rounds = [&](long blocks, double slowest) {
         const long full = blocks / cap, rem = blocks % cap;
         return full * 2.0 * slowest + (rem == 0 ? 0.0 : (rem <= cus ? 1.3 * slowest : 2.0 * slowest)) +
@@ -128,18 +165,7 @@ static FusedPlan fused_plan_search(const flow2d_context* ctx, size_t w, size_t h
         const double cost = rounds(blocks_x * ny * batch, kEdgeCost * ((double)rows + halo));
         if (cost < best - 1e-9) best = cost, plan = FusedPlan{(int)rows, (int)rows, (int)ny, (int)blocks_x, (int)(blocks_x * ny)};
     }
-#ifdef FLOW2D_DEV_BUILD  // developer override: exactly this many strips per interior column (border-aware plan), whatever it costs
-    // (FLOW2D_FUSED_NY=ny[,height]: only for levels of that height, default 4096)
-    static const long env_ny = std::getenv("FLOW2D_FUSED_NY") ? std::atol(std::getenv("FLOW2D_FUSED_NY")) : 0;
-    static const long env_ny_h = (std::getenv("FLOW2D_FUSED_NY") && std::strchr(std::getenv("FLOW2D_FUSED_NY"), ','))
-                                     ? std::atol(std::strchr(std::getenv("FLOW2D_FUSED_NY"), ',') + 1) : 4096;
-    const long forced_ny = (long)h == env_ny_h ? env_ny : 0;
-    if (forced_ny >= 3) best = 1e300;
-#else
-    const long forced_ny = 0;
-#endif
     for (long ny = 3; blocks_x >= 3 && ny <= (long)h / 2; ++ny) {  // border-aware: ny strips per interior column
-        if (forced_ny >= 3 && ny != forced_ny) continue;
         // rows_edge = (rows_interior + halo) / kEdgeCost - halo and 2 rows_edge + (ny - 2) rows_interior = h
         const double ri_real = ((double)h + 2.0 * halo - 2.0 * halo / kEdgeCost) / ((double)(ny - 2) + 2.0 / kEdgeCost);
         long re = (long)std::floor((ri_real + halo) / kEdgeCost - halo);
@@ -172,12 +198,7 @@ int launch_fused_outer(flow2d_context* ctx, int constancy, const float* f0, cons
     // up) is launched instance by instance: nothing is gained by one launch of several rounds, and the strips are then
     // planned -- and show in a kernel trace -- exactly as for a single pair.  Smaller levels share a launch (grid.z),
     // which lets the planner give them longer strips.
-#ifdef FLOW2D_FUSED_NO_SPLIT
-    const bool never_split = true;
-#else
-    const bool never_split = false;
-#endif
-    const bool split = !never_split && ctx->batch_count > 1 && fused_plan(ctx, w, h, inner, 1).rows_interior >= 128;
+    const bool split = ctx->batch_count > 1 && fused_plan(ctx, w, h, inner, 1).rows_interior >= 128;
     const unsigned instances_per_launch = split ? 1u : ctx->batch_count;
     FusedPlan plan = fused_plan(ctx, w, h, inner, (long)instances_per_launch);
     if (rows_per_strip > 0)
@@ -192,10 +213,19 @@ int launch_fused_outer(flow2d_context* ctx, int constancy, const float* f0, cons
                 0.5f * (alpha / (hx * hx)), 0.5f * (alpha / (hy * hy)),
                 sor_omega, 1.f - sor_omega,
                 0, plan.blocks, 0, static_cast<unsigned long long>(ctx->batch_stride_floats),
-#ifdef FLOW2D_FUSED_STAMPS
-                stamp_buffer(), stamp_counter(),
-#endif
+                nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
                 ctx->fused_fallbacks};
+#ifdef FLOW2D_DEV_BUILD
+    if (probe::kStamps) a.stamps = stamp_buffer(), a.stamp_count = stamp_counter(), a.stalls = stall_buffer();
+    const size_t plane_floats = h * (pitch_bytes / 4);
+    if (probe::kPackedPlanes) {
+        if (ctx->batch_count > 1 || a.continue_sweeps || plane_floats * 16 > 0xffffffffull) return FLOW2D_ERR_UNSUPPORTED;
+        PackedPlanes& pp = packed_planes(plane_floats);
+        a.pack_in = pp.in, a.pack_duv = pp.duv, a.pack_out = pp.out;
+        pack_planes_kernel<<<(unsigned)div_up(plane_floats, 256), 256, 0, ctx->stream>>>(f0, f1, u, v, du, dv, reinterpret_cast<float4*>(pp.in),
+                                                                                    reinterpret_cast<float2*>(pp.duv), plane_floats);
+    }
+#endif
     {  // 2h and 4h as three-step divisors (non-power-of-two spacings): within [2^-30, 2^40] like every guarded denominator
         const float lo = std::min(a.two_hx, a.two_hy), hi = std::max(a.four_hx, a.four_hy);
         if (!(lo >= 0x1p-30f && hi <= 0x1p40f)) a.plain_only = 1;
@@ -203,9 +233,7 @@ int launch_fused_outer(flow2d_context* ctx, int constancy, const float* f0, cons
     // XCD-aware block order: x-adjacent blocks share their halo columns, y-adjacent strips their halo rows; in one XCD
     // they meet in its L2 (reads of a 4096^2 launch 541 -> 455 MB; worth 1-3 % of the launch since the round-3 kernel
     // is within reach of the memory system).
-#ifndef FLOW2D_FUSED_PLAIN_ORDER
     a.blocks_per_xcd = (plan.blocks + 7) / 8;
-#endif
     const dim3 grid(a.blocks_per_xcd ? a.blocks_per_xcd * 8 : plan.blocks, 1, instances_per_launch);
     const bool pow2 = is_power_of_two(hx) && is_power_of_two(hy);
     int rc = 0;
@@ -226,20 +254,32 @@ int launch_fused_outer(flow2d_context* ctx, int constancy, const float* f0, cons
         rc = pow2 ? fused_launch_g0_p1(in, grid, ctx->stream, a) : fused_launch_g0_p0(in, grid, ctx->stream, a);
     }
     if (rc) return FLOW2D_ERR_UNSUPPORTED;
+#ifdef FLOW2D_DEV_BUILD
+    if (probe::kPackedPlanes)
+        unpack_planes_kernel<<<(unsigned)div_up(plane_floats, 256), 256, 0, ctx->stream>>>(reinterpret_cast<const float2*>(a.pack_out), out_du, out_dv,
+                                                                                      plane_floats);
+#endif
     FLOW2D_CHECK_LAUNCH();
     return FLOW2D_OK;
 }
 
 }  // namespace flow2d
 
-#ifdef FLOW2D_FUSED_STAMPS
-// developer builds only: the wave stamps recorded since the last call (8 words per wave), newest launches last
-extern "C" FLOW2D_API int flow2d_dev_fused_stamps(unsigned long long* out, size_t max_waves, size_t* waves)
+#ifdef FLOW2D_DEV_BUILD
+// developer builds only: the wave stamps recorded since the last call (kStampWords words per wave), newest launches last, and -- when
+// stalls is not null -- the stall histograms of the first min(waves, kStallWaves) of them (kStallRows x 64 words per wave)
+extern "C" FLOW2D_API int flow2d_dev_fused_stamps(unsigned long long* out, size_t max_waves, size_t* waves, unsigned int* stalls)
 {
+    namespace probe = flow2d_probe;
+    if (!probe::kStamps) return FLOW2D_ERR_UNSUPPORTED;
     unsigned int n = 0;
     if (hipMemcpy(&n, flow2d::stamp_counter(), sizeof(n), hipMemcpyDeviceToHost) != hipSuccess) return FLOW2D_ERR_DEVICE;
-    const size_t take = std::min<size_t>(std::min<size_t>(n, 1u << 16), max_waves);
-    if (take && hipMemcpy(out, flow2d::stamp_buffer(), take * 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost) != hipSuccess)
+    const size_t take = std::min<size_t>(std::min<size_t>(n, probe::kStampWaves), max_waves);
+    if (take && hipMemcpy(out, flow2d::stamp_buffer(), take * probe::kStampWords * sizeof(unsigned long long), hipMemcpyDeviceToHost) != hipSuccess)
+        return FLOW2D_ERR_DEVICE;
+    const size_t hist = std::min<size_t>(take, probe::kStallWaves);
+    if (stalls && hist &&
+        hipMemcpy(stalls, flow2d::stall_buffer(), hist * probe::kStallRows * 64 * sizeof(unsigned int), hipMemcpyDeviceToHost) != hipSuccess)
         return FLOW2D_ERR_DEVICE;
     (void)hipMemset(flow2d::stamp_counter(), 0, sizeof(unsigned int));
     *waves = take;

@@ -51,10 +51,14 @@ struct FusedArgs {
                                       // takes the fallback pass (plain divisions) at once
     int blocks, blocks_per_xcd;       // working blocks of the plan; ceil(blocks / 8), or 0 for the plain block order
     unsigned long long batch_stride;  // floats between the instances of a batched launch (blockIdx.z)
-#ifdef FLOW2D_FUSED_STAMPS  // developer builds: per-wave time stamps (8 words per wave) and their counter
+    // developer probes (solve_fused_probes.hpp; null in the product library, whose kernels never read them): per-wave time stamps
+    // with their counter and stall histograms; the frames and the flow of a pixel as one float4 plane, the increment as float2 planes
     unsigned long long* stamps;
     unsigned int* stamp_count;
-#endif
+    unsigned int* stalls;
+    const float* pack_in;
+    const float* pack_duv;
+    float* pack_out;
     unsigned int* fallback_count;     // [0] waves that repeated their strip with the plain division, [1] waves of plain_only
                                       // launches (diagnostics; may be null)
 };

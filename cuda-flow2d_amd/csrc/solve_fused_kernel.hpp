@@ -43,52 +43,17 @@
 #include "solve_fused_args.hpp"
 #include "solver_math.hpp"
 
-// Developer switches (timing builds under ab/, loaded through FLOW2D_HIP_LIB; tools/ab_time.sh, tools/ab_bench.sh) exist in
-// developer builds only (-DFLOW2D_DEV_BUILD); the product library has none of them and reads no environment variable:
-//   FLOW2D_FUSED_DEV             only the instantiations of the 4096^2 benchmark (compiles in half a minute)
-//   FLOW2D_FUSED_STAMPS          per-wave time stamps (tools/fused_wave_stamps.py)
-//   FLOW2D_FUSED_TURN_SHIFT=n    the two waves of a SIMD swap issue priority every 2^n cycles (take_turns)
-//   FLOW2D_FUSED_PLAIN_DIVISION  the compiler's division in the sweeps instead of the three-step one
-//   FLOW2D_FUSED_NO_PINS         let the scheduler place the guard updates
-//   FLOW2D_FUSED_EDGE_COST=x     border / interior body cost ratio of the strip planner (default 1.22)
-//   FLOW2D_FUSED_NO_SPLIT        a lock-step group's finest level as one launch of several rounds
-//   FLOW2D_FUSED_PLAIN_ORDER     blocks in plain order instead of one contiguous run per XCD
-//   FLOW2D_FUSED_INJECT=k        24 extra instructions of one class per steady-state row step (1 plain, 2 packed, 3 DPP, 4 transcendental, 5 s_nop):
-//                                what an instruction of that class costs in this kernel's own stream (tools/fused_price_list.sh)
-//   FLOW2D_FUSED_COMPUTE_ONLY, FLOW2D_FUSED_MEMORY_ONLY   timing probes that compute WRONG results
-//   FLOW2D_FUSED_SHORT_RING=n    timing probe, WRONG results: a coefficient ring of n (3) entries and one input row in flight instead of
-//                                two, so that the five-sweep kernel fits FLOW2D_FUSED_WAVES=3 waves per SIMD (168 registers): what
-//                                would a third wave buy the full kernel's instruction stream?  (tools/occupancy5_exp.sh)
-//   FLOW2D_FUSED_NO_LANE_SHIFT   timing probe, WRONG results: x neighbours = the lane's own value, no DPP instruction (with the
-//                                packed-fp32-ops feature off: a row step of plain instructions only -- what would that stream cost?)
-//   FLOW2D_FUSED_THREE_AHEAD     three input rows in flight instead of two (six more registers)
-//   FLOW2D_FUSED_NT_STORE, FLOW2D_FUSED_NT_LOAD   non-temporal stores of the result rows / loads of the input rows
-//   FLOW2D_FUSED_VGPR_BUDGET=n   a register budget below the 256 that two waves per SIMD allow (room for other lanes' kernels beside a launch)
-//   FLOW2D_FUSED_STAGGER=n       the waves start in four phases n x 64 cycles apart
-//   FLOW2D_FUSED_WAVES=n         __launch_bounds__(256, n)
-//   FLOW2D_FUSED_FULL_WEIGHTS    stage W's face weights as (a + b) / 2.f * w (rounds 1-4) instead of (a + b) * (w / 2), for A/B
-//   FLOW2D_FUSED_ORDER=1 / 2     stage W (2: and stage P) of a row step after its sweeps instead of before them: the step as two
-//                                chains that do not depend on each other (round 5's A/B for "independent stages")
-// A build option, not a probe (csrc/Makefile sets it for the instances it compiles WITH packed fp32 arithmetic):
-//   FLOW2D_FUSED_PACKED          the face products as v_pk_mul_f32 ... op_sel instead of two plain multiplies
-#if (defined(FLOW2D_FUSED_STAMPS) || defined(FLOW2D_FUSED_SHORT_RING) || defined(FLOW2D_FUSED_WAVES) || defined(FLOW2D_FUSED_COMPUTE_ONLY) || defined(FLOW2D_FUSED_MEMORY_ONLY) ||          \
-     defined(FLOW2D_FUSED_TURN_SHIFT) || defined(FLOW2D_FUSED_PLAIN_DIVISION) || defined(FLOW2D_FUSED_NO_PINS) ||          \
-     defined(FLOW2D_FUSED_DEV) || defined(FLOW2D_FUSED_EDGE_COST) || defined(FLOW2D_FUSED_NO_SPLIT) ||                    \
-     defined(FLOW2D_FUSED_PLAIN_ORDER) || defined(FLOW2D_FUSED_INJECT) || defined(FLOW2D_FUSED_FULL_WEIGHTS) || defined(FLOW2D_FUSED_NO_LANE_SHIFT) || defined(FLOW2D_FUSED_THREE_AHEAD) || defined(FLOW2D_FUSED_VGPR_BUDGET) || defined(FLOW2D_FUSED_NT_STORE) || defined(FLOW2D_FUSED_NT_LOAD) || defined(FLOW2D_FUSED_STAGGER)) &&                                                                               \
-    !defined(FLOW2D_DEV_BUILD)
-#error "the fused kernel's timing probes need -DFLOW2D_DEV_BUILD: they are not part of the product library"
-#endif
+// Developer probes (stamps and stall histogram, compute-only / memory-only / no-halo / packed-plane timing builds) are compile-time
+// constants of solve_fused_probes.hpp, all false in the product library.  One build option is not a probe (csrc/Makefile sets it
+// for the instances it compiles WITH packed fp32 arithmetic): FLOW2D_FUSED_PACKED, the face products as v_pk_mul_f32 ... op_sel.
+#include "solve_fused_probes.hpp"
 
 namespace {
 
 using namespace flow2d_math;
 using flow2d::FusedArgs;
 
-#ifdef FLOW2D_FUSED_STAMPS
-// per wave: start / end on the 100 MHz clock, shader cycles, HW_ID, XCC_ID, block id, wave in block | edge << 8, y0 | y1 << 32
-constexpr int kStampWords = 8, kStampWaves = 1 << 16;
-#endif
-
+namespace probe = flow2d_probe;
 
 // A plane row is addressed as base pointer (a scalar register pair) + one 32-bit per-lane byte offset that all planes
 // share (global_load / global_store ... saddr): two scalar registers per plane.  (Buffer descriptors, four scalar
@@ -96,36 +61,50 @@ constexpr int kStampWords = 8, kStampWaves = 1 << 16;
 // lanes and read back, 24 v_readlane per row step.)  Planes stay below 4 GiB (fused_addressable).
 __device__ __forceinline__ float plane_load(const float* plane, unsigned byte_offset)
 {
-#ifdef FLOW2D_FUSED_NT_LOAD  // developer A/B: non-temporal loads of the input rows
-    return __builtin_nontemporal_load(reinterpret_cast<const float*>(reinterpret_cast<const char*>(plane) + static_cast<size_t>(byte_offset)));
-#else
     return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(plane) + static_cast<size_t>(byte_offset));
-#endif
 }
 __device__ __forceinline__ void plane_store(float* plane, unsigned byte_offset, float value)
 {
-#ifdef FLOW2D_FUSED_NT_STORE  // developer A/B: streaming (non-temporal) stores of the result rows
-    __builtin_nontemporal_store(value, reinterpret_cast<float*>(reinterpret_cast<char*>(plane) + static_cast<size_t>(byte_offset)));
-#else
     *reinterpret_cast<float*>(reinterpret_cast<char*>(plane) + static_cast<size_t>(byte_offset)) = value;
-#endif
+}
+
+// One input row of a lane's column on its way from memory: the frames, the flow, the increment.
+struct RowFetch {
+    float f0, f1;
+    v2f uv, duv;
+};
+typedef float v4f __attribute__((ext_vector_type(4)));
+// byte_offset: (row * pitch + column) * 4, the offset all planes share
+__device__ __forceinline__ RowFetch fetch_row(const FusedArgs& a, unsigned byte_offset)
+{
+    if constexpr (probe::kPackedPlanes) {  // probe: (f0, f1, u, v) of a pixel side by side in one plane, (du, dv) in another
+        const v4f q = *reinterpret_cast<const v4f*>(reinterpret_cast<const char*>(a.pack_in) + static_cast<size_t>(byte_offset * 4u));
+        const v2f d = *reinterpret_cast<const v2f*>(reinterpret_cast<const char*>(a.pack_duv) + static_cast<size_t>(byte_offset * 2u));
+        return RowFetch{q.x, q.y, v2f{q.z, q.w}, d};
+    } else {
+        // the increment planes are read whether or not the launch treats them as zero (first outer iteration: they are valid planes
+        // with stale contents) and the zero is selected when the row is committed: no branch around two loads in every step
+        return RowFetch{plane_load(a.f0, byte_offset), plane_load(a.f1, byte_offset), v2f{plane_load(a.u, byte_offset), plane_load(a.v, byte_offset)},
+                        v2f{plane_load(a.du, byte_offset), plane_load(a.dv, byte_offset)}};
+    }
+}
+__device__ __forceinline__ void store_row(const FusedArgs& a, unsigned byte_offset, float du, float dv)
+{
+    if constexpr (probe::kPackedPlanes) {
+        *reinterpret_cast<v2f*>(reinterpret_cast<char*>(a.pack_out) + static_cast<size_t>(byte_offset * 2u)) = v2f{du, dv};
+    } else {
+        plane_store(a.out_du, byte_offset, du);
+        plane_store(a.out_dv, byte_offset, dv);
+    }
+}
+__device__ __forceinline__ unsigned row_offset(const FusedArgs& a, int row, int xc)
+{
+    return (static_cast<unsigned>(row) * static_cast<unsigned>(a.pitch) + static_cast<unsigned>(xc)) * 4u;
 }
 
 // lane i receives lane i-1 (wave_shr:1) / lane i+1 (wave_shl:1); the end lanes of the wave receive 0
 // (bound_ctrl), which only ever reaches halo columns.  No "old" operand, so the move can fold into the
 // consuming VALU instruction.
-#ifdef FLOW2D_FUSED_NO_LANE_SHIFT  // timing probe, WRONG results: the lane's own value, no instruction at all
-__device__ __forceinline__ float from_left(float v)
-{
-    asm volatile("" : "+v"(v));
-    return v;
-}
-__device__ __forceinline__ float from_right(float v)
-{
-    asm volatile("" : "+v"(v));
-    return v;
-}
-#else
 __device__ __forceinline__ float from_left(float v)
 {
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x138, 0xf, 0xf, true));
@@ -134,45 +113,7 @@ __device__ __forceinline__ float from_right(float v)
 {
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x130, 0xf, 0xf, true));
 }
-#endif
 
-// Developer experiment (round 4, -DFLOW2D_FUSED_TURN_SHIFT=15; not in the product build): the two waves of a SIMD take
-// turns at being the one the issue arbiter favours.  Vector issue on a SIMD goes to the wave of higher priority and, among
-// equals, to the OLDER one: the older wave of a SIMD runs its strip at the pace of a lone wave (124 us at 4096^2), the
-// younger one gets the slots it leaves and finishes the rest alone (208 us) -- per-wave stamps, tools/fused_wave_stamps.py.
-// With the priority swapped every 2^shift shader cycles both waves advance at the same pace (185 / 196 us) and the launch
-// is 2-4 % shorter alone, but a pipeline of lanes already fills the slots a lone wave leaves: no gain end to end
-// (profiles/r04_experiments/README.md).
-#ifndef FLOW2D_FUSED_TURN_SHIFT
-#define FLOW2D_FUSED_TURN_SHIFT (-1)
-#endif
-#ifndef FLOW2D_FUSED_ORDER
-#define FLOW2D_FUSED_ORDER 0
-#elif !defined(FLOW2D_DEV_BUILD)
-#error "FLOW2D_FUSED_ORDER is a developer experiment (-DFLOW2D_DEV_BUILD)"
-#endif
-constexpr int kTurnShift = FLOW2D_FUSED_TURN_SHIFT;  // < 0: never
-// the wave's slot on its SIMD (0 or 1 with two waves per SIMD)
-__device__ __forceinline__ unsigned turn_parity()
-{
-    unsigned slot = 0;
-    if (kTurnShift >= 0) asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID, 0, 4)" : "=s"(slot));
-    return slot;
-}
-// clock: a reading of the shader clock taken a row step ago (the read is issued at the end of a step and waited for at
-// the beginning of the next, so its latency stays out of the way)
-__device__ __forceinline__ void take_turns(unsigned long long clock, unsigned parity)
-{
-    if (kTurnShift < 0) return;
-#if FLOW2D_FUSED_WAVES == 3  // (three waves per SIMD: the favoured role goes round the three wave slots)
-    if ((static_cast<unsigned>(clock >> (kTurnShift < 0 ? 0 : kTurnShift)) % 3u) == parity % 3u)
-#else
-    if (((static_cast<unsigned>(clock >> (kTurnShift < 0 ? 0 : kTurnShift)) ^ parity) & 1u) != 0u)
-#endif
-        __builtin_amdgcn_s_setprio(1);
-    else
-        __builtin_amdgcn_s_setprio(0);
-}
 
 // static per-pixel coefficients of one outer iteration (what the sweeps need besides the moving flow)
 struct Coef {
@@ -233,11 +174,7 @@ __device__ __forceinline__ v2f half_inverse_root_pair(v2f s, v2f& twice_root)
 //         large, zero, negative or infinite.  A NaN passes both (minNum / maxNum return the other operand) -- and turns
 //         du, dv of its pixel into NaN in the first sweep, in either form of the division, which `out` sees
 //   out : max of bits(du, dv) << 1 over the stored results: above kOutLimit for an infinity or a NaN
-#ifdef FLOW2D_FUSED_NO_PINS
-#define FLOW2D_GUARD_PIN(x) ((void)0)
-#else
 #define FLOW2D_GUARD_PIN(x) asm volatile("" : "+v"(x))
-#endif
 struct DivGuard {
     unsigned tiny, out;
     float den_lo, den_hi;
@@ -373,13 +310,10 @@ __device__ __forceinline__ v2f pick2(bool c, v2f a, v2f b) { return v2f{c ? a.x 
 // themselves come from compute_phi_ksi in every mode: brightness tensor, true neighbours.
 template <int INNER, int GRAD>
 struct Strip {
-    static constexpr int kHalo = INNER + 1;
-    static constexpr int kValid = 64 - 2 * kHalo;
-#ifdef FLOW2D_FUSED_SHORT_RING
-    static constexpr int kRing = FLOW2D_FUSED_SHORT_RING;  // developer probe (timing only): the sweeps read other rows' coefficients
-#else
+    static constexpr int kHalo = INNER + 1;                          // halo rows above and below a strip
+    static constexpr int kHaloLanes = probe::kNoHalo ? 0 : kHalo;    // halo columns left and right of it (probe: none, wrong edges)
+    static constexpr int kValid = 64 - 2 * kHaloLanes;
     static constexpr int kRing = ((INNER + 1 + 2) / 3) * 3;  // coefficient ring, a multiple of the 3-row windows
-#endif
 
     // 3-row sliding windows, slot = row mod 3; (u, v) and (du, dv) travel as pairs
     float f0w[3], f1w[3];
@@ -393,50 +327,55 @@ struct Strip {
     // brightness derivatives and ksi of the row stage W consumes next (produced by stage P one step earlier)
     float p_fx, p_fy, p_ft, p_ksi;
     // two prefetched input rows in flight: row r+1 (n_*, fetched a step ago) and row r+2 (m_*, fetched in this step)
-    float n_f0, n_f1;
-    v2f n_uv, n_duv;
-    float m_f0, m_f1;
-    v2f m_uv, m_duv;
-#ifdef FLOW2D_FUSED_THREE_AHEAD  // developer A/B: a third input row in flight (row r+3)
-    float l_f0, l_f1;
-    v2f l_uv, l_duv;
-#endif
+    RowFetch n, m;
     // continue_sweeps only: the sweeps' starting increment of row r-2 (start_cur) and the row fetched for the
     // next step (n_start)
     v2f start_cur, n_start;
-#ifdef FLOW2D_FUSED_INJECT
-    v2f inj[4];  // developer probe: registers of the injected instructions
-#endif
     DivGuard guard;  // three-step division: operands outside the proven range leave their mark here
-    unsigned long long turn_clock;  // take_turns: the shader clock a step ago, the wave's slot on its SIMD (both wave-uniform)
-    unsigned turn_parity;
+    // stamps probe: the wave's stalls at the row commit -- lane b of stall[0] counts those of floor(log2(cycles)) == b, lane b of
+    // stall[1] adds their cycles up, lane p of stall[2] the cycles of the row steps 4 p .. 4 p + 3 of the strip
+    unsigned stall[3];
+    unsigned long long stall_t0, stall_t1;  // the clock before and after the last step's wait (scalar registers)
 };
 
-#ifdef FLOW2D_FUSED_INJECT
-// developer probe: six independent instructions of one class (four registers in rotation, so none waits for its predecessor)
+// stamps probe: wait for the row this step commits (its L loads; the L of the next row may stay in flight) between two readings
+// of the shader clock and file the difference.  The readings come back through the scalar data cache: the wave meets them at
+// the end of the step's first stage, not here.
 template <int INNER, int GRAD>
-__device__ __forceinline__ void inject_six(Strip<INNER, GRAD>& s)
+__device__ __forceinline__ void timed_row_wait(Strip<INNER, GRAD>& s, int step)
 {
-#pragma unroll
-    for (int i = 0; i < 6; ++i) {
-        v2f& d = s.inj[i & 3];
-#if FLOW2D_FUSED_INJECT == 1
-        asm volatile("v_add_f32 %0, %0, %0" : "+v"(d.x));
-#elif FLOW2D_FUSED_INJECT == 2
-        asm volatile("v_pk_add_f32 %0, %0, %0" : "+v"(d));
-#elif FLOW2D_FUSED_INJECT == 3
-        asm volatile("v_mov_b32_dpp %0, %0 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "+v"(d.x));
-#elif FLOW2D_FUSED_INJECT == 4
-        asm volatile("v_rcp_f32 %0, %0" : "+v"(d.x));
-#elif FLOW2D_FUSED_INJECT == 5
-        asm volatile("s_nop 0" : "+v"(d.x));
-#endif
-    }
+    constexpr int kLoadsPerRow = probe::kPackedPlanes ? 2 : 6;
+    // (file the PREVIOUS step's pair of readings: they have long arrived, no wait for the scalar cache inside the step)
+    const unsigned dt = static_cast<unsigned>(s.stall_t1 - s.stall_t0);
+    s.stall_t0 = __builtin_amdgcn_s_memtime();
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kLoadsPerRow) : "memory");
+    s.stall_t1 = __builtin_amdgcn_s_memtime();
+    const int bin = 31 - __builtin_clz(dt | 1u), prog = (step >> 2) & 63;
+    const int lane = static_cast<int>(threadIdx.x & 63u);
+    s.stall[0] += lane == bin ? 1u : 0u;
+    s.stall[1] += lane == bin ? dt : 0u;
+    s.stall[2] += lane == prog ? dt : 0u;
 }
-#define FLOW2D_INJECT_SIX(s) do { if (T < 0) inject_six(s); } while (0)
-#else
-#define FLOW2D_INJECT_SIX(s) ((void)0)
-#endif
+
+// exchange probe (with no halo lanes): what handing edge columns from wave to wave would cost a row step -- one barrier among the
+// four waves of the workgroup, n 8-byte LDS writes of live values and n two-address LDS reads whose results reach the guard
+template <int INNER, int GRAD>
+__device__ __forceinline__ void exchange_cost(Strip<INNER, GRAD>& s, int J)
+{
+    constexpr int n = probe::kExchange;
+    __shared__ v2f slab[2][n > 0 ? n : 1][256 + 2];
+    const int col = threadIdx.x + 1, par = J & 1;
+#pragma unroll
+    for (int i = 0; i < n; ++i) slab[par][i][col] = i < INNER ? s.UV[i][0] : s.uvw[i % 3];
+    __builtin_amdgcn_s_barrier();
+    unsigned acc = 0u;
+#pragma unroll
+    for (int i = 0; i < n; ++i) {
+        const v2f l = slab[par ^ 1][i][col - 1], r = slab[par ^ 1][i][col + 1];
+        acc |= __float_as_uint(l.x) & __float_as_uint(r.y);
+    }
+    s.guard.out = max(s.guard.out, acc & 1u);
+}
 
 // EDGE = false: the strip touches no image border, so the reflect substitutions (a v_cndmask per
 // neighbour fetch) are compiled out; EDGE = true keeps them.  Chosen per wave (wave-uniform branch).
@@ -475,69 +414,32 @@ __device__ __forceinline__ void strip_step(Strip<INNER, GRAD>& s, const FusedArg
         const unsigned off = (static_cast<unsigned>(rs) * static_cast<unsigned>(a.pitch) + static_cast<unsigned>(xc)) * 4u;
         s.n_start = v2f{plane_load(a.start_du, off), plane_load(a.start_dv, off)};
     }
-    s.f0w[s0] = s.n_f0;
-    s.f1w[s0] = s.n_f1;
-    s.uvw[s0] = s.n_uv;
-#if defined(FLOW2D_FUSED_SHORT_RING) || defined(FLOW2D_FUSED_THREE_AHEAD)
-    s.duvw[s0] = s.n_duv;
-#else
-    s.duvw[s0] = v2f{a.zero_increment ? 0.f : s.n_duv.x, a.zero_increment ? 0.f : s.n_duv.y};
-#endif
-    if (FAST) guard_flow_row(s.guard, s.n_uv, s.duvw[s0]);
+    if constexpr (probe::kStamps && T < 0) timed_row_wait(s, r - 1 - (y0 - S::kHalo));
+    if constexpr (probe::kExchange >= 0 && T < 0) exchange_cost(s, J);
+    s.f0w[s0] = s.n.f0;
+    s.f1w[s0] = s.n.f1;
+    s.uvw[s0] = s.n.uv;
+    s.duvw[s0] = v2f{a.zero_increment ? 0.f : s.n.duv.x, a.zero_increment ? 0.f : s.n.duv.y};
+    if (FAST) guard_flow_row(s.guard, s.n.uv, s.duvw[s0]);
     if (GRAD == 3) {
-        s.lf0w[s0] = log1p_frame(s.n_f0);
-        s.lf1w[s0] = log1p_frame(s.n_f1);
+        s.lf0w[s0] = log1p_frame(s.n.f0);
+        s.lf1w[s0] = log1p_frame(s.n.f1);
     }
     {  // row r+1 arrived a step ago; fetch row r+2 (clamped: rows outside the image are never used by a stored pixel)
-#ifndef FLOW2D_FUSED_SHORT_RING
-        s.n_f0 = s.m_f0, s.n_f1 = s.m_f1, s.n_uv = s.m_uv, s.n_duv = s.m_duv;
-#endif
-#ifdef FLOW2D_FUSED_THREE_AHEAD
-        constexpr int kAhead = 3;
-#else
+        s.n = s.m;
         constexpr int kAhead = 2;
-#endif
-#ifdef FLOW2D_FUSED_COMPUTE_ONLY  // developer probe (timing only, wrong results): every row folded onto eight cache-resident rows
-        const int rn = (r + kAhead) & 7;
-#else
         // (a strip without EDGE keeps kHalo + 1 + kAhead rows away from the top and bottom border -- the kernel's edge test -- so
         //  its prefetch row needs no clamp: two scalar instructions less per step, each of which costs the wave an issue turn)
-        const int rn = EDGE ? min(max(r + kAhead, 0), h - 1) : r + kAhead;
-#endif
-        const unsigned off = (static_cast<unsigned>(rn) * static_cast<unsigned>(a.pitch) + static_cast<unsigned>(xc)) * 4u;
-#ifdef FLOW2D_FUSED_SHORT_RING  // (probe: one row in flight)
-        s.n_f0 = plane_load(a.f0, off);
-        s.n_f1 = plane_load(a.f1, off);
-        s.n_uv = v2f{plane_load(a.u, off), plane_load(a.v, off)};
-        s.n_duv = a.zero_increment ? v2f{0.f, 0.f} : v2f{plane_load(a.du, off), plane_load(a.dv, off)};
-#elif defined(FLOW2D_FUSED_THREE_AHEAD)
-        s.m_f0 = s.l_f0, s.m_f1 = s.l_f1, s.m_uv = s.l_uv, s.m_duv = s.l_duv;
-        s.l_f0 = plane_load(a.f0, off);
-        s.l_f1 = plane_load(a.f1, off);
-        s.l_uv = v2f{plane_load(a.u, off), plane_load(a.v, off)};
-        s.l_duv = a.zero_increment ? v2f{0.f, 0.f} : v2f{plane_load(a.du, off), plane_load(a.dv, off)};
-#else
-        s.m_f0 = plane_load(a.f0, off);
-        s.m_f1 = plane_load(a.f1, off);
-        s.m_uv = v2f{plane_load(a.u, off), plane_load(a.v, off)};
-        // the increment planes are read whether or not the launch treats them as zero (first outer iteration: they are valid planes
-        // with stale contents) and the zero is selected when the row is committed: no branch around two loads in every step
-        s.m_duv = v2f{plane_load(a.du, off), plane_load(a.dv, off)};
-#endif
+        // compute-only probe: every row folded onto eight cache-resident rows
+        const int rn = probe::kComputeOnly ? (r + kAhead) & 7 : EDGE ? min(max(r + kAhead, 0), h - 1) : r + kAhead;
+        s.m = fetch_row(a, row_offset(a, rn, xc));
     }
-
-#ifdef FLOW2D_FUSED_MEMORY_ONLY  // developer probe (timing only, wrong results): the strip's loads and stores without its arithmetic
-    {
+    if constexpr (probe::kMemoryOnly) {  // the strip's loads and stores without its arithmetic
         const int rk = r - 2 - INNER;
-        if (lane_stores && rk >= y0 && rk < y1) {
-            const unsigned off = (static_cast<unsigned>(rk) * static_cast<unsigned>(a.pitch) + static_cast<unsigned>(xc)) * 4u;
-            plane_store(a.out_du, off, s.f0w[s0] + s.uvw[s0].x + s.duvw[s0].x);
-            plane_store(a.out_dv, off, s.f1w[s0] + s.uvw[s0].y + s.duvw[s0].y);
-        }
+        if (lane_stores && rk >= y0 && rk < y1)
+            store_row(a, row_offset(a, rk, xc), s.f0w[s0] + s.uvw[s0].x + s.duvw[s0].x, s.f1w[s0] + s.uvw[s0].y + s.duvw[s0].y);
         return;
     }
-#endif
-    if (T < 0) take_turns(s.turn_clock, s.turn_parity);
     constexpr bool run_P = T < 0 || T >= 2, run_W = T < 0 || T >= 3;
     if (T >= 0) __builtin_amdgcn_sched_barrier(0);  // keep the straight-line start-up from being interleaved across steps
 
@@ -624,17 +526,11 @@ __device__ __forceinline__ void strip_step(Strip<INNER, GRAD>& s, const FusedArg
         }
     }
     };
-#if FLOW2D_FUSED_ORDER != 2
     stage_P();
-#endif
 
-    FLOW2D_INJECT_SIX(s);
     // ---- stage W, row rw = r-2: face weights and the motion tensor -> coefficient ring --------------------
     // phi ring: slot s1 holds row r-1 (just written), s2 row r-2, s0 row r-3
     const int rw = r - 2;
-    // (developer builds, -DFLOW2D_FUSED_ORDER=1 / 2: the coefficients of row r-2 are first read by sweep 1 in the NEXT step and
-    //  nothing in this step but stage P feeds them, so stage W can also run after the sweeps -- two chains that do not depend
-    //  on each other within a step, {P, W} and {sweep 1 .. sweep INNER}; 2: stage P after the sweeps as well)
     auto stage_W = [&]() {
     if (run_W) {
         constexpr int cw = (J + 2 * kRing - 2) % kRing;
@@ -662,23 +558,11 @@ __device__ __forceinline__ void strip_step(Strip<INNER, GRAD>& s, const FusedArg
         // face_phi * (xp, xm), solve_2d.cu:337-346: xp = [x < w-1] * alpha / hx^2, xm = [x > 0] * alpha / hx^2; an interior
         // strip has no image border, so both are the uniform alpha / hx^2 there
         if (!EDGE && GRAD != 3) {  // the neighbours as DPP operands of the two additions
-#ifdef FLOW2D_FUSED_FULL_WEIGHTS  // (developer A/B: the literal (a + b) / 2.f * w of rounds 1-4; hx_2, hy_2 are the full weights then)
-            c.wx = v2f{scalar_only(from_right(pc) + pc), scalar_only(from_left(pc) + pc)} / 2.f * v2f{hx_2, hx_2};
-#else
             c.wx = v2f{scalar_only(from_right(pc) + pc), scalar_only(from_left(pc) + pc)} * v2f{hx_2, hx_2};
-#endif
         } else {
-#ifdef FLOW2D_FUSED_FULL_WEIGHTS
-            c.wx = (p_rl + pc) / 2.f * (EDGE ? v2f{at_r ? 0.f : hx_2, at_l ? 0.f : hx_2} : v2f{hx_2, hx_2});
-#else
             c.wx = (p_rl + pc) * (EDGE ? v2f{at_r ? 0.f : hx_2, at_l ? 0.f : hx_2} : v2f{hx_2, hx_2});
-#endif
         }
-#ifdef FLOW2D_FUSED_FULL_WEIGHTS
-        c.wy = v2f{face_phi(pD, pc) * yp, face_phi(pU, pc) * ym};
-#else
         c.wy = (v2f{pD, pU} + pc) * v2f{yp, ym};
-#endif
         const float sumH = sum_weights(c.wx.x, c.wx.y, c.wy.x, c.wy.y);
         const float c_ksi = s.p_ksi;
         c.uvc = s.uvw[s2];
@@ -745,22 +629,18 @@ __device__ __forceinline__ void strip_step(Strip<INNER, GRAD>& s, const FusedArg
     };
     // (u + du, v + dv) of row r-2 enters sweep 1's window
     if (run_W) s.UV[0][s2] = s.uvw[s2] + (cont ? s.start_cur : s.duvw[s2]);
-#if FLOW2D_FUSED_ORDER == 0
     stage_W();
     // stage P's outputs of this step are what stage W consumes in the next one
     s.p_fx = fx;
     s.p_fy = fy;
     s.p_ft = ft;
     s.p_ksi = ksi;
-#endif
 
-    FLOW2D_INJECT_SIX(s);
     // ---- sweeps k = 1..INNER, row rk = r-2-k (solve_2d.cu:349-367) ------------------------------------------
     v2f old = duv_row3;  // (du^0, dv^0) of row r-3
 #pragma unroll
     for (int k = 1; k <= INNER; ++k) {
         if (T >= 0 && T < 3 + 2 * k) continue;  // start-up: this sweep's row feeds nothing yet
-        if (k == 3 || k == 5) FLOW2D_INJECT_SIX(s);
         const int rk = r - 2 - k;
         // window slots of rows rk-1, rk, rk+1 (rk = r-2-k  ->  slot (J - 2 - k) mod 3)
         const int sc = (J + 3 * 8 - 2 - k) % 3, su = (sc + 2) % 3, sd = (sc + 1) % 3;
@@ -819,26 +699,9 @@ __device__ __forceinline__ void strip_step(Strip<INNER, GRAD>& s, const FusedArg
             old = s.duvc[k];                    // (du^k, dv^k) of row r-3-k, produced by this sweep one step ago
             s.duvc[k] = v2f{du_new, dv_new};    // of row r-2-k, for the next step
         } else if (lane_stores) {  // (rk is in [y0, y1) in every step that gets here: run_strip's start-up and r_last)
-#ifdef FLOW2D_FUSED_COMPUTE_ONLY
-            const unsigned off = (static_cast<unsigned>(rk & 7) * static_cast<unsigned>(a.pitch) + static_cast<unsigned>(xc)) * 4u;
-#else
-            const unsigned off = (static_cast<unsigned>(rk) * static_cast<unsigned>(a.pitch) + static_cast<unsigned>(xc)) * 4u;
-#endif
-            plane_store(a.out_du, off, du_new);
-            plane_store(a.out_dv, off, dv_new);
+            store_row(a, row_offset(a, probe::kComputeOnly ? rk & 7 : rk, xc), du_new, dv_new);
         }
     }
-#if FLOW2D_FUSED_ORDER != 0
-#if FLOW2D_FUSED_ORDER == 2
-    stage_P();
-#endif
-    stage_W();
-    s.p_fx = fx;
-    s.p_fy = fy;
-    s.p_ft = ft;
-    s.p_ksi = ksi;
-#endif
-    if (T < 0 && kTurnShift >= 0) s.turn_clock = __builtin_amdgcn_s_memtime();
 }
 
 // one turn of the ring starting at ring position J0 (the start-up ends there)
@@ -883,10 +746,12 @@ __device__ __forceinline__ void strip_startup(Strip<INNER, GRAD>& s, const Fused
 // Returns whether any lane met operands the three-step division is not proven for (always false with FAST = false).
 template <int INNER, int GRAD, bool EDGE, bool POW2, bool CONT, bool FAST, bool SOR>
 __device__ __forceinline__ bool run_strip(const FusedArgs& a, int x, int xc, bool at_l, bool at_r, bool lane_stores, int y0,
-                                          int y1, float hx_2, float hy_2)
+                                          int y1, float hx_2, float hy_2, unsigned* stall_out = nullptr)
 {
     using S = Strip<INNER, GRAD>;
     S s;
+    s.stall[0] = s.stall[1] = s.stall[2] = 0u;
+    s.stall_t0 = s.stall_t1 = 0ull;
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
         s.f0w[i] = s.f1w[i] = s.phiw[i] = 0.f;
@@ -905,47 +770,14 @@ __device__ __forceinline__ bool run_strip(const FusedArgs& a, int x, int xc, boo
         s.C[i] = Coef{};
         s.C[i].den = s.C[i].rden = v2f{1.f, 1.f};
     }
-#ifdef FLOW2D_FUSED_INJECT
-    for (int i = 0; i < 4; ++i) s.inj[i] = v2f{1.f, 1.f};
-#endif
     s.p_fx = s.p_fy = s.p_ft = s.p_ksi = 0.f;
     s.guard = DivGuard{0xffffffffu, 0u, 1.f, 1.f, 0x7fffffff};
-    s.turn_parity = turn_parity();
-    s.turn_clock = kTurnShift >= 0 ? __builtin_amdgcn_s_memtime() : 0ull;
 
     // first input row: the strip's first stored row needs INNER+1 rows of halo above it
     const int r_first = y0 - S::kHalo;
     {
-        const int rn = min(max(r_first, 0), a.h - 1);
-        const size_t o = static_cast<size_t>(rn) * a.pitch + xc;
-        s.n_f0 = a.f0[o];
-        s.n_f1 = a.f1[o];
-        s.n_uv = v2f{a.u[o], a.v[o]};
-#if defined(FLOW2D_FUSED_SHORT_RING) || defined(FLOW2D_FUSED_THREE_AHEAD)
-        s.n_duv = a.zero_increment ? v2f{0.f, 0.f} : v2f{a.du[o], a.dv[o]};
-#else
-        s.n_duv = v2f{a.du[o], a.dv[o]};
-#endif
-        {
-            const size_t o2 = static_cast<size_t>(min(max(r_first + 1, 0), a.h - 1)) * a.pitch + xc;
-            s.m_f0 = a.f0[o2];
-            s.m_f1 = a.f1[o2];
-            s.m_uv = v2f{a.u[o2], a.v[o2]};
-#if defined(FLOW2D_FUSED_SHORT_RING) || defined(FLOW2D_FUSED_THREE_AHEAD)
-            s.m_duv = a.zero_increment ? v2f{0.f, 0.f} : v2f{a.du[o2], a.dv[o2]};
-#else
-            s.m_duv = v2f{a.du[o2], a.dv[o2]};
-#endif
-        }
-#ifdef FLOW2D_FUSED_THREE_AHEAD
-        {
-            const size_t o3 = static_cast<size_t>(min(max(r_first + 2, 0), a.h - 1)) * a.pitch + xc;
-            s.l_f0 = a.f0[o3];
-            s.l_f1 = a.f1[o3];
-            s.l_uv = v2f{a.u[o3], a.v[o3]};
-            s.l_duv = a.zero_increment ? v2f{0.f, 0.f} : v2f{a.du[o3], a.dv[o3]};
-        }
-#endif
+        s.n = fetch_row(a, row_offset(a, min(max(r_first, 0), a.h - 1), xc));
+        s.m = fetch_row(a, row_offset(a, min(max(r_first + 1, 0), a.h - 1), xc));
         s.start_cur = s.n_start = v2f{0.f, 0.f};
         if (CONT) {  // the first step commits row r_first - 2 of the starting increment
             const size_t os = static_cast<size_t>(min(max(r_first - 2, 0), a.h - 1)) * a.pitch + xc;
@@ -968,39 +800,19 @@ __device__ __forceinline__ bool run_strip(const FusedArgs& a, int x, int xc, boo
     }
     strip_tail<INNER, GRAD, EDGE, POW2, CONT, FAST, SOR, kJ0>(s, a, r, r_last, x, xc, at_l, at_r, lane_stores, y0, y1, hx_2, hy_2,
                                                          std::make_index_sequence<S::kRing - 1>{});
+    if constexpr (probe::kStamps)
+        if (stall_out) stall_out[0] = s.stall[0], stall_out[1] = s.stall[1], stall_out[2] = s.stall[2];
     return guard_tripped(s.guard);
 }
 
-#ifdef FLOW2D_FUSED_PLAIN_DIVISION
-constexpr bool kThreeStepDivision = false;
-#else
-constexpr bool kThreeStepDivision = true;
-#endif
-
-#ifndef FLOW2D_FUSED_WAVES
-#define FLOW2D_FUSED_WAVES 2
-#endif
-// FLOW2D_FUSED_VGPR_BUDGET=n (developer A/B): at most n vector registers (gfx950's register file is unified, the compiler doubles
-// the attribute's value: n / 2 is what it wants to be told)
-#ifdef FLOW2D_FUSED_VGPR_BUDGET
-#define FLOW2D_FUSED_VGPR_ATTR __attribute__((amdgpu_num_vgpr(FLOW2D_FUSED_VGPR_BUDGET / 2)))
-#else
-#define FLOW2D_FUSED_VGPR_ATTR
-#endif
 template <int INNER, int GRAD, bool POW2, bool CONT, bool SOR = false>
-__global__ __launch_bounds__(256, FLOW2D_FUSED_WAVES) FLOW2D_FUSED_VGPR_ATTR void fused_outer_kernel(FusedArgs a)
+__global__ __launch_bounds__(256, 2) void fused_outer_kernel(FusedArgs a)
 {
     using S = Strip<INNER, GRAD>;
-#ifdef FLOW2D_FUSED_STAGGER  // developer A/B: the waves of a launch start in four phases, n x 64 cycles apart (do their memory bursts collide?)
-    {
-        const unsigned phase = (blockIdx.x + (threadIdx.x >> 6)) & 3u;
-        for (unsigned i = 0; i < phase; ++i) __builtin_amdgcn_s_sleep(FLOW2D_FUSED_STAGGER);
-    }
-#endif
     const int lane = threadIdx.x & 63;
-#ifdef FLOW2D_FUSED_STAMPS
-    const unsigned long long stamp_r0 = __builtin_amdgcn_s_memrealtime(), stamp_c0 = __builtin_amdgcn_s_memtime();
-#endif
+    const unsigned long long stamp_r0 = probe::kStamps ? __builtin_amdgcn_s_memrealtime() : 0ull;
+    const unsigned long long stamp_c0 = probe::kStamps ? __builtin_amdgcn_s_memtime() : 0ull;
+    unsigned stall[3] = {0u, 0u, 0u};
     // block id -> block column bx and strip by: uniform strips row by row; a border-aware plan first the interior
     // block columns (strips_interior strips each), then the first and the last block column (strips of rows_edge)
     int bx, by;
@@ -1026,7 +838,7 @@ __global__ __launch_bounds__(256, FLOW2D_FUSED_WAVES) FLOW2D_FUSED_VGPR_ATTR voi
         a.f0 += off, a.f1 += off, a.u += off, a.v += off, a.du += off, a.dv += off, a.out_du += off, a.out_dv += off;
         if (CONT) a.start_du += off, a.start_dv += off;
     }
-    const int x = strip_x * S::kValid - S::kHalo + lane;
+    const int x = strip_x * S::kValid - S::kHaloLanes + lane;
     const int xc = min(max(x, 0), a.w - 1);
     int y0, y1;
     if (uniform || bx == 0 || bx == a.blocks_x - 1) {
@@ -1042,24 +854,20 @@ __global__ __launch_bounds__(256, FLOW2D_FUSED_WAVES) FLOW2D_FUSED_VGPR_ATTR voi
     }
     if (y0 >= y1) return;  // (a middle strip the rounding of rows_interior left empty)
     const bool at_l = (x == 0), at_r = (x == a.w - 1);
-    const bool lane_stores = lane >= S::kHalo && lane < 64 - S::kHalo && x < a.w;
-#ifdef FLOW2D_FUSED_FULL_WEIGHTS
-    const float hx_2 = a.hx_2, hy_2 = a.hy_2;
-#else
+    const bool lane_stores = lane >= S::kHaloLanes && lane < 64 - S::kHaloLanes && x < a.w;
     const float hx_2 = a.half_hx_2, hy_2 = a.half_hy_2;  // HALF the neighbour weights: see stage W
-#endif
 
     // does any row or column this wave touches sit on an image border?  (a superset test is fine)
-    const int x_first = strip_x * S::kValid - S::kHalo;
+    const int x_first = strip_x * S::kValid - S::kHaloLanes;
     // (rows: the strip reads y0 - kHalo .. y1 + kHalo + 1 + rows in flight; the interior body fetches them unclamped)
     const bool edge = x_first <= 0 || x_first + 63 >= a.w - 1 || y0 <= S::kHalo + 1 || y1 + S::kHalo + 4 >= a.h;
     bool bad = a.plain_only != 0;
     if (bad)
         ;
     else if (__builtin_amdgcn_readfirstlane(edge))
-        bad = run_strip<INNER, GRAD, true, POW2, CONT, kThreeStepDivision, SOR>(a, x, xc, at_l, at_r, lane_stores, y0, y1, hx_2, hy_2);
+        bad = run_strip<INNER, GRAD, true, POW2, CONT, true, SOR>(a, x, xc, at_l, at_r, lane_stores, y0, y1, hx_2, hy_2, stall);
     else
-        bad = run_strip<INNER, GRAD, false, POW2, CONT, kThreeStepDivision, SOR>(a, x, xc, at_l, at_r, lane_stores, y0, y1, hx_2, hy_2);
+        bad = run_strip<INNER, GRAD, false, POW2, CONT, true, SOR>(a, x, xc, at_l, at_r, lane_stores, y0, y1, hx_2, hy_2, stall);
     if (__builtin_amdgcn_ballot_w64(bad) != 0ull) {
         // some lane's operands left the range the three-step division is proven for (or the launch's grid spacing did:
         // plain_only): the whole strip with the plain division (same stores, now from the reference's own arithmetic)
@@ -1067,52 +875,49 @@ __global__ __launch_bounds__(256, FLOW2D_FUSED_WAVES) FLOW2D_FUSED_VGPR_ATTR voi
         // word 0 counts guard trips, word 1 the waves of launches that never tried the short forms
         if (a.fallback_count && lane == 0) atomicAdd(a.fallback_count + (a.plain_only ? 1 : 0), 1u);
     }
-#ifdef FLOW2D_FUSED_STAMPS
-    if (lane == 0) {
+    if constexpr (probe::kStamps) {  // the wave's stamp (probe::kStampWords words) and its stall histogram (probe::kStallRows x 64)
         const unsigned long long r1 = __builtin_amdgcn_s_memrealtime(), c1 = __builtin_amdgcn_s_memtime();
-        const unsigned slot = atomicAdd(a.stamp_count, 1u) % kStampWaves;
-        unsigned long long* o = a.stamps + static_cast<size_t>(slot) * kStampWords;
-        o[0] = stamp_r0, o[1] = r1, o[2] = c1 - stamp_c0;
-        unsigned hw_id, xcc_id;
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_id));
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc_id));
-        o[3] = hw_id, o[4] = xcc_id;
-        o[5] = blockIdx.x | (static_cast<unsigned long long>(blockIdx.z) << 32);
-        o[6] = (threadIdx.x >> 6) | (static_cast<unsigned>(edge) << 8) | (static_cast<unsigned long long>(strip_x) << 32);
-        o[7] = static_cast<unsigned>(y0) | (static_cast<unsigned long long>(y1) << 32);
+        unsigned slot = 0u;
+        if (lane == 0) slot = atomicAdd(a.stamp_count, 1u) % probe::kStampWaves;
+        slot = __builtin_amdgcn_readfirstlane(slot);
+        if (lane == 0) {
+            unsigned long long* o = a.stamps + static_cast<size_t>(slot) * probe::kStampWords;
+            o[0] = stamp_r0, o[1] = r1, o[2] = c1 - stamp_c0;
+            unsigned hw_id, xcc_id;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_id));
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc_id));
+            o[3] = hw_id, o[4] = xcc_id;
+            o[5] = blockIdx.x | (static_cast<unsigned long long>(blockIdx.z) << 32);
+            o[6] = (threadIdx.x >> 6) | (static_cast<unsigned>(edge) << 8) | (static_cast<unsigned long long>(strip_x) << 32);
+            o[7] = static_cast<unsigned>(y0) | (static_cast<unsigned long long>(y1) << 32);
+        }
+        if (slot < probe::kStallWaves)
+            for (int i = 0; i < probe::kStallRows; ++i) a.stalls[(static_cast<size_t>(slot) * probe::kStallRows + i) * 64 + lane] = stall[i];
     }
-#endif
 }
 
-// (developer builds: FLOW2D_FUSED_LDS_PAD bytes of dynamic LDS per workgroup, unused -- fewer workgroups per CU, for occupancy
-//  experiments on one binary: tools/occupancy_exp.sh)
-#ifdef FLOW2D_DEV_BUILD
-static const unsigned kFusedLdsPad = std::getenv("FLOW2D_FUSED_LDS_PAD") ? static_cast<unsigned>(std::atoi(std::getenv("FLOW2D_FUSED_LDS_PAD"))) : 0u;
-#else
-constexpr unsigned kFusedLdsPad = 0u;
-#endif
 #define FUSED_LAUNCH(N)                                                                 \
     do {                                                                                \
-        fused_outer_kernel<N, GRAD, POW2, CONT><<<grid, 256, kFusedLdsPad, stream>>>(a); \
+        fused_outer_kernel<N, GRAD, POW2, CONT><<<grid, 256, 0, stream>>>(a); \
         return 0;                                                                       \
     } while (0)
 
 #define FUSED_LAUNCH_SOR(N)                                                                   \
     do {                                                                                      \
-        fused_outer_kernel<N, GRAD, POW2, CONT, true><<<grid, 256, kFusedLdsPad, stream>>>(a); \
+        fused_outer_kernel<N, GRAD, POW2, CONT, true><<<grid, 256, 0, stream>>>(a); \
         return 0;                                                                             \
     } while (0)
 
 template <int GRAD, bool POW2, bool CONT>
 int launch_for_inner_cont(int inner, dim3 grid, hipStream_t stream, const FusedArgs& a)
 {
-#ifdef FLOW2D_FUSED_DEV  // developer builds (A/B timing): only the instantiations of the 4096^2 benchmark, compiled in a minute
-    if constexpr (GRAD <= 1 && POW2 && !CONT) {
-        if (inner == 5) FUSED_LAUNCH(5);
-        if (inner == 2) FUSED_LAUNCH(2);
-    }
-    return 1;
-#else
+    if constexpr (probe::kDevInstances) {  // developer builds: only the instantiations of the 4096^2 benchmark, half a minute
+        if constexpr (GRAD <= 1 && POW2 && !CONT) {
+            if (inner == 5) FUSED_LAUNCH(5);
+            if (inner == 2) FUSED_LAUNCH(2);
+        }
+        return 1;
+    } else {
     if (a.sor_omega != 0.f) {  // red-black half-sweeps: 2 or 4 stages = one or two iterations per launch (not for solve_2d_log)
         if constexpr (GRAD != 3) {
             if (inner == 2) FUSED_LAUNCH_SOR(2);
@@ -1128,7 +933,7 @@ int launch_for_inner_cont(int inner, dim3 grid, hipStream_t stream, const FusedA
         case 5: FUSED_LAUNCH(5);
         default: return 1;
     }
-#endif
+    }
 }
 
 template <int GRAD, bool POW2>

@@ -166,6 +166,13 @@ void ThreadRendezvous::Raise()
 }
 bool ThreadRendezvous::Raised() const { return state_->raised.load(); }
 
+std::string FreshRunId()
+{
+    const auto now = std::chrono::steady_clock::now().time_since_epoch();
+    return "p" + std::to_string(static_cast<long>(getpid())) + "t" +
+           std::to_string(static_cast<long long>(std::chrono::duration_cast<std::chrono::microseconds>(now).count()));
+}
+
 FileRendezvous::FileRendezvous(const std::string& prefix, const std::string& run_id, int rank, int world, double timeout_seconds)
     : prefix_(prefix), run_id_(run_id.empty() ? "0" : run_id), rank_(rank), world_(world), timeout_(timeout_seconds)
 {

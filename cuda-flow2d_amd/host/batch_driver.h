@@ -86,6 +86,11 @@ private:
 // ranks = processes that share a directory: rank r posts stage s as the file <prefix>.s<s>.r<r> holding "<run id> <0|1>",
 // the flag is the file <prefix>.abort.<run id>.  A stale file of an earlier run carries another run id and is ignored;
 // every rank removes what it wrote when it is destroyed.
+// A run id nobody else uses (process id + clock): for a job whose ranks all live in one process, or have no peers.  A job of
+// several PROCESSES must be given one id by its launcher (--run-id; tools/run_batch8.sh does): with a default id a failed job's
+// flag and posts, which stay behind on purpose, would be taken for the next job's own.
+std::string FreshRunId();
+
 class FileRendezvous : public RankRendezvous {
 public:
     FileRendezvous(const std::string& prefix, const std::string& run_id, int rank, int world, double timeout_seconds = 120.0);

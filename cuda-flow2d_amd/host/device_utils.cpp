@@ -22,6 +22,9 @@ bool CheckFlow2DError(int status, const char* where)
 bool InitDeviceContext(int device_ordinal)
 {
     if (g_context) return true;
+    // eight hardware queues for the lanes of the batched path: must precede the process's first HIP call (a refusal -- the runtime
+    // already runs, or the caller exported a smaller value -- is not an error: OpticalFlowBatch2D::Initialize warns when it matters)
+    (void)flow2d_request_hw_queues(8);
     int count = 0;
     if (flow2d_device_count(&count) != FLOW2D_OK || count == 0) {
         std::printf("Error: no HIP devices supporting flow2d (gfx950) were found.\n");

@@ -263,6 +263,7 @@ int main(int argc, char** argv)
         std::fprintf(stderr, "usage: flow2d_batch %s", BatchUsage());
         return 3;
     }
+    (void)flow2d_request_hw_queues(8);  // four lanes + RCCL's stream per device: before the process's first HIP call
     int devices = 0;
     if (hipGetDeviceCount(&devices) != hipSuccess || devices < 1) {
         std::fprintf(stderr, "flow2d_batch: no HIP device (the flow2d path has no CPU fallback)\n");
@@ -272,20 +273,36 @@ int main(int argc, char** argv)
         ncclUniqueId id;
         if (opt.id_file.empty() || opt.rank >= opt.world) return 3;
         // The file holds "<run id>\n" + the id.  Rank 0 removes whatever an earlier run left at the path before it writes,
-        // the readers skip a file that carries another run id (a run id comes from the launcher -- tools/run_batch8.sh
-        // makes a fresh one, and a fresh directory, per job; without --run-id it is "0" and only the unlink protects), and
-        // rank 0 removes the file again once every rank is past the communicator's rendezvous.
-        const std::string run_id = opt.run_id.empty() ? "0" : opt.run_id;
+        // the readers skip a file that carries another run id, and rank 0 removes the file again once every rank is past the
+        // communicator's rendezvous.  The run id comes from the launcher (tools/run_batch8.sh makes a fresh one, and a fresh
+        // directory, per job) and is MANDATORY for a job of several processes: a failed job leaves its flag and posts behind on
+        // purpose, and under a default id the next job at the same path would take them for its own (every rank leaving at once
+        // with "another rank failed": ADVICE r05).  A lone rank has no peer to agree an id with and makes its own.
+        if (opt.run_id.empty() && opt.world > 1) {
+            std::fprintf(stderr, "flow2d_batch: --rank with --world %d needs --run-id NONCE, the same fresh value on every rank of the job\n", opt.world);
+            return 3;
+        }
+        const std::string run_id = opt.run_id.empty() ? FreshRunId() : opt.run_id;
         const std::string head = run_id + "\n";
         FileRendezvous side(opt.id_file, run_id, opt.rank, opt.world);
         if (opt.rank == 0) {
             std::remove(opt.id_file.c_str());
-            if (ncclGetUniqueId(&id) != ncclSuccess) return 1;
-            const std::string tmp = opt.id_file + ".tmp";
-            std::FILE* f = std::fopen(tmp.c_str(), "wb");
-            if (!f || std::fwrite(head.data(), 1, head.size(), f) != head.size() || std::fwrite(&id, sizeof(id), 1, f) != 1) return 255;
-            std::fclose(f);
-            if (std::rename(tmp.c_str(), opt.id_file.c_str()) != 0) return 255;
+            // (a rank 0 that cannot publish the id raises the side channel's flag: its peers stop polling for the file at once and
+            //  every rank returns 1 -- not 120 s later, and not with a code of rank 0's own)
+            bool published = ncclGetUniqueId(&id) == ncclSuccess;
+            if (published) {
+                const std::string tmp = opt.id_file + ".tmp";
+                std::FILE* f = std::fopen(tmp.c_str(), "wb");
+                published = f && std::fwrite(head.data(), 1, head.size(), f) == head.size() && std::fwrite(&id, sizeof(id), 1, f) == 1;
+                if (f) published = (std::fclose(f) == 0) && published;
+                published = published && std::rename(tmp.c_str(), opt.id_file.c_str()) == 0;
+                if (!published) std::remove(tmp.c_str());
+            }
+            if (!published) {
+                std::fprintf(stderr, "flow2d_batch: rank 0: cannot publish the communicator's id at %s\n", opt.id_file.c_str());
+                side.Raise();
+                return 1;
+            }
         } else {
             bool have = false;
             for (int tries = 0; tries < 1200 && !have && !side.Raised(); ++tries) {

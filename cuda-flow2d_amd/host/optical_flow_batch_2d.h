@@ -12,9 +12,9 @@
 //
 // Every lane needs a hardware queue of its own: the HIP runtime deals a process's streams onto GPU_MAX_HW_QUEUES
 // (default 4) queues, and a lane that shares a queue waits behind its neighbour (measured at 4096^2, four lanes:
-// 205 instead of 224 pairs/s when one more stream -- an idle one, or RCCL's -- exists in the process).  libflow2d_hip.so
-// therefore sets GPU_MAX_HW_QUEUES=8 when it is loaded and the variable is unset (flow2d_hw_queues()); only a process
-// that initialised HIP before loading the library has to export the variable itself.
+// 205 instead of 224 pairs/s when one more stream -- an idle one, or RCCL's -- exists in the process).  The host
+// layer therefore asks for eight queues before its first HIP call (InitDeviceContext -> flow2d_request_hw_queues(8), which sets
+// GPU_MAX_HW_QUEUES when the caller has not); only a process that started HIP before that has to export the variable itself.
 #pragma once
 
 #include <cstddef>

@@ -70,11 +70,15 @@ FLOW2D_API const char* flow2d_last_error(void);
  *      src/utils/cuda_utils.cpp:26-62, and cuCtxDestroy at src/main.cpp:226) ----------------- */
 FLOW2D_API int flow2d_device_count(int* count);
 /* Hardware queues the HIP runtime deals this process's streams onto (GPU_MAX_HW_QUEUES; the runtime reads it once, at
- * its first call).  The library sets the variable to 8 when it is loaded and the caller has not set it: the batched
- * host path runs four lanes (streams) side by side and a lane that shares a queue waits behind its neighbour.  Returns
- * the value the environment holds now (4 = the runtime's default when unset or unparsable).  No reference counterpart
- * (one context, the NULL stream: src/utils/cuda_utils.cpp:43). */
+ * its first call): the batched host path runs four lanes (streams) side by side and a lane that shares a queue waits
+ * behind its neighbour.  flow2d_hw_queues returns the value the environment holds now (4 = the runtime's default when
+ * unset or unparsable).  flow2d_request_hw_queues(n) asks for n queues: it sets the variable when the caller has not
+ * and the process has not started the HIP runtime yet (FLOW2D_OK; also when the environment already grants n), and
+ * reports FLOW2D_ERR_UNSUPPORTED -- with the reason in flow2d_last_error() -- when it came too late or the caller's own
+ * value is smaller; nothing is changed then.  The host layer calls it before its first HIP call (InitDeviceContext).
+ * No reference counterpart (one context, the NULL stream: src/utils/cuda_utils.cpp:43). */
 FLOW2D_API int flow2d_hw_queues(void);
+FLOW2D_API int flow2d_request_hw_queues(int queues);
 FLOW2D_API int flow2d_context_create(int device_ordinal, flow2d_context** out_ctx);
 /* Same, but launches on an existing hipStream_t owned by the caller (e.g. a PyTorch stream). */
 FLOW2D_API int flow2d_context_create_on_stream(int device_ordinal, void* hip_stream, flow2d_context** out_ctx);

@@ -264,6 +264,9 @@ int main(int argc, char** argv)
     }
     const int world = opt.world;
     if (world < 1 || world > 64) return 3;
+    // the ranks are threads of this process: without --run-id they share an id nobody else has (a default id would make the
+    // files a failed job leaves behind count as this job's own)
+    if (!flags.file_prefix.empty() && opt.run_id.empty()) opt.run_id = FreshRunId();
     LoopbackHub hub(world);
     ThreadRendezvous shared_side(world, 20.0);
     std::vector<int> codes(world, 0);

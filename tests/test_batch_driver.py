@@ -137,6 +137,19 @@ def test_file_rendezvous_ignores_another_runs_files(tmp_path):
     assert sorted(os.listdir(tmp_path)) == ["id.abort.old"]
 
 
+def test_a_failed_job_does_not_wedge_the_next_one_at_the_same_prefix(tmp_path):
+    """a failed job leaves its abort flag and posts behind on purpose (slower ranks must still read them).  Without
+    --run-id both jobs used the id "0" and the healthy job took the leftovers for its own: every rank left at once with "another
+    rank failed".  A job whose ranks share a process now makes a fresh id; flow2d_batch refuses --rank with peers and no --run-id."""
+    prefix = tmp_path / "id"
+    p = run(["--world", 3, "--pairs", 7, "--fail-rank", 2, "--fail-phase", "gather-absent", "--file-rendezvous", prefix], timeout=30)
+    assert p.returncode == 1
+    assert [n for n in os.listdir(tmp_path) if ".abort." in n]  # the failed job's flag stays
+    p = run(["--world", 3, "--pairs", 7, "--file-rendezvous", prefix], timeout=30)
+    assert p.returncode == 0, p.stderr[-1000:]
+    assert json.loads(p.stdout.splitlines()[-1])["pairs"] == 7
+
+
 def test_constancy_values_of_the_library_are_accepted():
     for c in (0, 1, 2, 3):  # Grey, Gradient, LogDerivatives, GradientUntiled (data_structs.h)
         assert run(["--world", 2, "--pairs", 2, "--constancy", c], timeout=30).returncode == 0

@@ -352,15 +352,23 @@ def test_plain_c_client_links_and_runs_without_a_device(flow2d, tmp_path):
     assert "flow2d C-ABI v1" in out.stdout
 
 
-def test_library_asks_for_hardware_queues_at_load(flow2d):
-    """Loading libflow2d_hip.so sets GPU_MAX_HW_QUEUES=8 when the caller has not set it (the four lanes of the batched
-    host path need a hardware queue each, next to RCCL's stream), and leaves a caller's value alone."""
-    code = ("import ctypes, os; L = ctypes.CDLL(%r); print(os.environ.get('GPU_MAX_HW_QUEUES'), L.flow2d_hw_queues())"
+def test_hardware_queues_are_requested_not_set_at_load(flow2d):
+    """Loading libflow2d_hip.so leaves the environment alone (rounds 2-5 set GPU_MAX_HW_QUEUES from a library constructor);
+    flow2d_request_hw_queues(8) sets it when the caller has not and HIP is not running yet, leaves a caller's value alone and
+    says so, and refuses once the process holds the driver's device node (a stand-in: any open descriptor of /dev/kfd)."""
+    code = ("import ctypes, os; L = ctypes.CDLL(%r); L.flow2d_last_error.restype = ctypes.c_char_p; a = L.flow2d_hw_queues();"
+            "rc = L.flow2d_request_hw_queues(8); print(a, rc, L.flow2d_hw_queues(), L.flow2d_last_error().decode()[:40].replace(' ', '_') or '-')"
             % flow2d.HIP_LIB_PATH)
     env = {k: v for k, v in os.environ.items() if k != "GPU_MAX_HW_QUEUES"}
     out = subprocess.run([os.sys.executable, "-c", code], env=env, capture_output=True, text=True, check=True).stdout.split()
-    # (os.environ is Python's snapshot of the start-up environment: the library's setenv shows in the C environment)
-    assert out[1] == "8"
+    assert out[:3] == ["4", "0", "8"], out  # untouched by the load, granted by the request
     out = subprocess.run([os.sys.executable, "-c", code], env=dict(env, GPU_MAX_HW_QUEUES="2"), capture_output=True,
                          text=True, check=True).stdout.split()
-    assert out == ["2", "2"]
+    assert out[:3] == ["2", "5", "2"] and out[3].startswith("GPU_MAX_HW_QUEUES"), out
+    out = subprocess.run([os.sys.executable, "-c", code], env=dict(env, GPU_MAX_HW_QUEUES="16"), capture_output=True,
+                         text=True, check=True).stdout.split()
+    assert out[:3] == ["16", "0", "16"], out
+    if os.path.exists("/dev/kfd") and os.access("/dev/kfd", os.R_OK):  # (a GPU box, or a container that maps the node)
+        late = "import os; fd = os.open('/dev/kfd', os.O_RDONLY); " + code
+        out = subprocess.run([os.sys.executable, "-c", late], env=env, capture_output=True, text=True, check=True).stdout.split()
+        assert out[:3] == ["4", "5", "4"] and "HIP" in out[3], out

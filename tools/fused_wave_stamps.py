@@ -19,12 +19,53 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 F = importlib.import_module("cuda-flow2d_amd")
 
 
-def fetch(lib):
+STALL_WAVES = 1 << 12
+
+
+def fetch(lib, with_stalls=False):
+    """the stamps recorded since the last call; with_stalls: also the stall histograms [waves][3][64] of the first 4096 of them"""
     n = C.c_size_t(0)
     buf = np.zeros((1 << 16, 8), np.uint64)
-    rc = lib.flow2d_dev_fused_stamps(buf.ctypes.data_as(C.c_void_p), C.c_size_t(1 << 16), C.byref(n))
+    stalls = np.zeros((STALL_WAVES, 3, 64), np.uint32)
+    rc = lib.flow2d_dev_fused_stamps(buf.ctypes.data_as(C.c_void_p), C.c_size_t(1 << 16), C.byref(n),
+                                     stalls.ctypes.data_as(C.c_void_p) if with_stalls else None)
     assert rc == 0, rc
+    if with_stalls:
+        return buf[:n.value], stalls[:min(n.value, STALL_WAVES)]
     return buf[:n.value]
+
+
+def report_stalls(st, stalls, label):
+    """Where the waves of ONE launch waited at the row commit (s_waitcnt for the row's loads between two clock readings; a reading
+    pair costs ~50 cycles when nothing is outstanding -- the floor of the histogram)."""
+    n = len(stalls)
+    st = st[:n]
+    cyc = st[:, 2].astype(np.float64)
+    hw = st[:, 3].astype(np.int64)
+    xcc = st[:, 4].astype(np.int64) & 15
+    cnt = stalls[:, 0, :32].astype(np.float64)
+    cyc_bin = stalls[:, 1, :32].astype(np.float64)
+    prog = stalls[:, 2, :].astype(np.float64)
+    total = cyc_bin.sum()
+    print("%s: stalls of %d waves: %.0f waits per wave, %.1f %% of the waves' cycles at the row commit (%.0f of %.0f cycles per wave)" %
+          (label, n, cnt.sum() / n, 100 * total / cyc.sum(), total / n, cyc.mean()))
+    print("  by duration   cycles   waits/wave   share of stall cycles   share of wave cycles")
+    for b in range(32):
+        if cnt[:, b].sum() > 0:
+            print("   2^%-2d %7d..%-7d %9.2f %12.1f %% %12.2f %%" % (b, 1 << b, (2 << b) - 1, cnt[:, b].sum() / n,
+                                                                 100 * cyc_bin[:, b].sum() / total, 100 * cyc_bin[:, b].sum() / cyc.sum()))
+    # the floor: a wait that finds its row there costs the two clock readings; everything above ~2x the modal bin is real waiting
+    per_wave = cyc_bin.sum(axis=1) / cyc
+    print("  per wave, stall share of its cycles: min %.1f %%  p10 %.1f  median %.1f  p90 %.1f  max %.1f" %
+          (100 * per_wave.min(), 100 * pct(per_wave, 10), 100 * pct(per_wave, 50), 100 * pct(per_wave, 90), 100 * per_wave.max()))
+    slot = hw & 15
+    print("  by wave slot on the SIMD (waves, median stall share %%): " +
+          "  ".join("%d: %d %.1f" % (k, (slot == k).sum(), 100 * pct(per_wave[slot == k], 50)) for k in sorted(set(slot.tolist()))))
+    print("  by XCC (median stall share %%): " + "  ".join("%d: %.1f" % (k, 100 * pct(per_wave[xcc == k], 50)) for k in sorted(set(xcc.tolist()))))
+    steps = prog.sum(axis=0) / n
+    used = np.nonzero(steps)[0]
+    print("  stall cycles per row step by the wave's progress (four steps per column, mean over waves):")
+    print("   " + " ".join("%4.0f" % (steps[k] / 4) for k in range(used.max() + 1)))
 
 
 def pct(v, q):
@@ -107,18 +148,22 @@ def main():
                             F.SOLVER_FUSED, container_height=h)
         ctx.synchronize()
         fetch(lib)
+        with_stalls = os.environ.get("FLOW2D_STALLS", "1") != "0"
         e0, e1 = ctx.event(), ctx.event()
         ctx.record(e0)
         ctx.solve_level(*planes, du, dv, phi, ksi, tdu, tdv, w, h, 1.0, 1.0, 35.0, 0.001, 0.001, 4, 5, constancy,
                         F.SOLVER_FUSED, container_height=h)
         ctx.record(e1)
         ms = ctx.elapsed_ms(e0, e1)
-        st = fetch(lib)
+        st, stalls = fetch(lib, True)
+        # (the histograms belong to the first 4096 stamps in buffer order: keep that order's index through the sort below)
+        index = np.arange(len(st))
         # split into launches by start time: the waves of one launch start within a few us, launches are >100 us apart
         order = np.argsort(st[:, 0])
-        st = st[order]
+        st, index = st[order], index[order]
         gaps = np.nonzero(np.diff(st[:, 0].astype(np.int64)) > 2000)[0]  # > 20 us
         launches = np.split(st, gaps + 1)
+        launch_index = np.split(index, gaps + 1)
         print("== %dx%d x%d %s: 4 outer iterations %.1f us (%.1f per launch by events); %d launches found" %
               (w, h, inst, mode, ms * 1e3, ms * 1e3 / 4, len(launches)))
         out = os.environ.get("FLOW2D_STAMPS_OUT")
@@ -127,6 +172,10 @@ def main():
         for k, l in enumerate(launches):
             if k in (0, len(launches) - 1):
                 report(l, "  launch %d%s" % (k, " (first of the level: du = dv = 0, not read)" if k == 0 else ""))
+            if with_stalls and k == 1:  # the launches after the first hold the steady state; the histograms cover the first 4096 waves
+                have = launch_index[k] < len(stalls)
+                if have.sum() > 256:
+                    report_stalls(l[have], stalls[launch_index[k][have]], "  launch %d" % k)
     ctx.close()
 
 
