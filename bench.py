@@ -786,15 +786,26 @@ def roofline_sample(job, passes=3):
         finest = [r for r in flow.level_timings() if (r[0], r[1]) == (w, h)]
         # one pair alone on the GPU, launch to done, replayed from its graph (no timing events inside): the latency
         # a single pair sees, as opposed to the pipelined rate of the timed region
-        flow.use_graph(True)
-        latency = None
-        for _ in range(4):  # the first call records
-            e0, e1 = c.event(), c.event()
-            c.record(e0)
-            flow.compute_flow_device(f0.ptr, f1.ptr, u.ptr, v.ptr, job.params, 0)
-            c.record(e1)
-            ms = c.elapsed_ms(e0, e1)
-            latency = ms if latency is None or ms < latency else latency
+        def replayed_latency(obj):
+            obj.use_graph(True)
+            best = None
+            for _ in range(4):  # the first call records
+                e0, e1 = c.event(), c.event()
+                c.record(e0)
+                obj.compute_flow_device(f0.ptr, f1.ptr, u.ptr, v.ptr, job.params, 0)
+                c.record(e1)
+                ms = c.elapsed_ms(e0, e1)
+                best = ms if best is None or ms < best else best
+            return best
+
+        latency = replayed_latency(flow)
+        # the same pair through an object that behaves like a lane of a pipeline (OpticalFlow2D::lone = false: one stream, the
+        # pipeline's build of the strip kernel everywhere): what the second stream and the packed build buy a lone pair
+        plain = flow2d.OpticalFlow(w, h, cfg["constancy"], ctx=c, lone=False)
+        try:
+            job.single_stream_latency_ms = replayed_latency(plain)
+        finally:
+            plain.close()
         return finest, latency
     finally:
         flow.close()
@@ -1240,6 +1251,8 @@ def main():
             "host_entry": host_entry,
             "single_pair_latency_ms": round(pair_latency_ms, 3),  # one pair alone on the GPU, graph replay, launch to done
             "pairs_per_s_single": round(1e3 / pair_latency_ms, 3),  # = 1 / single_pair_latency: no second pair in flight
+            # the same lone pair on one stream with the pipeline's kernels (round 5's single pair; OpticalFlow2D::lone = false)
+            "single_pair_latency_single_stream_ms": round(getattr(sample, "single_stream_latency_ms", float("nan")), 3),
             "finest_level": {
                 "solve_ms": round(solve_ms, 4),
                 "mpix_iters_per_s": round(px_iters / (solve_ms * 1e-3) / 1e6, 1),

@@ -134,6 +134,9 @@ def hip_lib():
         L.flow2d_solve_level.argtypes = [vp] * 11 + [C.POINTER(SolveParams), C.POINTER(i)]
         L.flow2d_timing_enable.argtypes = [vp, i]
         L.flow2d_fused_fallbacks.argtypes = [vp, C.POINTER(C.c_ulonglong)]
+        L.flow2d_clock_probe_start.argtypes = [vp, C.c_double]
+        L.flow2d_clock_probe_read.argtypes = [vp, C.POINTER(C.c_double)]
+        L.flow2d_fused_block_order.argtypes = [vp, sz, sz, sz, sz, C.POINTER(i), sz, C.POINTER(sz)]
         if hasattr(L, "flow2d_fused_plain_waves"):  # (absent from libraries of earlier rounds loaded for an A/B)
             L.flow2d_fused_plain_waves.argtypes = [vp, C.POINTER(C.c_ulonglong)]
         L.flow2d_timing_launch_filter.argtypes = [vp, sz, sz]
@@ -243,6 +246,25 @@ class Context:
         n = C.c_ulonglong()
         _check(hip_lib().flow2d_fused_fallbacks(self.handle, C.byref(n)), "flow2d_fused_fallbacks")
         return n.value
+
+    def clock_probe_start(self, duration_us):
+        """queues one sleeping wave per XCD on this context's stream that brackets duration_us with the 100 MHz and the shader clock"""
+        _check(hip_lib().flow2d_clock_probe_start(self.handle, float(duration_us)), "flow2d_clock_probe_start")
+
+    def clock_probe_read(self):
+        """waits for the probe; the shader clock held per XCD in GHz (0: no wave landed there)"""
+        ghz = (C.c_double * 8)()
+        _check(hip_lib().flow2d_clock_probe_read(self.handle, ghz), "flow2d_clock_probe_read")
+        return list(ghz)
+
+    def fused_block_order(self, width, height, inner, instances=1):
+        """(grid, 4) int array: block column, strip, first row, end row of every launch block of a strip launch (-1: empty id)."""
+        grid = C.c_size_t(0)
+        cap = 1 << 16
+        buf = (C.c_int * (4 * cap))()
+        _check(hip_lib().flow2d_fused_block_order(self.handle, width, height, inner, instances, buf, cap, C.byref(grid)),
+               "flow2d_fused_block_order")
+        return np.frombuffer(buf, np.int32, 4 * grid.value).reshape(-1, 4).copy()
 
     def fused_plain_waves(self):
         """Waves of fused launches that ran the plain expressions throughout (grid spacing outside the proven range)."""
@@ -447,7 +469,7 @@ def host_lib():
         L.flow2d_host_adopt_context.argtypes = [vp]
         L.flow2d_host_context.restype = vp
         L.flow2d_host_flow_create.restype = vp
-        L.flow2d_host_flow_create.argtypes = [sz, sz, i, i]
+        L.flow2d_host_flow_create.argtypes = [sz, sz, i, i, i]
         L.flow2d_host_flow_destroy.argtypes = [vp]
         L.flow2d_host_flow_pitch.restype = sz
         L.flow2d_host_flow_pitch.argtypes = [vp]
@@ -512,7 +534,7 @@ def _fptr(a):
 class OpticalFlow:
     """OpticalFlow2D of the host layer (Initialize / ComputeFlow / ComputeFlowDevice / Destroy)."""
 
-    def __init__(self, width, height, constancy=GREY, device=0, ctx=None, silent=True):
+    def __init__(self, width, height, constancy=GREY, device=0, ctx=None, silent=True, lone=True):
         L = host_lib()
         self._adopted = ctx is not None
         if ctx is not None:
@@ -520,7 +542,7 @@ class OpticalFlow:
         elif L.flow2d_host_init_device(device) != 0:
             raise Flow2DError(2, "InitDeviceContext")
         self.width, self.height = width, height
-        self.handle = L.flow2d_host_flow_create(width, height, _HOST_CONSTANCY[constancy], int(silent))
+        self.handle = L.flow2d_host_flow_create(width, height, _HOST_CONSTANCY[constancy], int(silent), int(lone))
         if not self.handle:
             if self._adopted:
                 L.flow2d_host_adopt_context(None)

@@ -27,9 +27,12 @@ struct flow2d_context {
     int num_cus = 256;
     // flow2d_context_set_batch: every launch runs `batch_count` instances, instance b on plane pointers + b * stride
     unsigned batch_count = 1;
+    // flow2d_context_set_lone: nothing else of the caller's job runs beside this context's launches
+    bool lone = false;
     size_t batch_stride_floats = 0;
     // device counter: waves of the fused kernel that repeated their strip with the plain division (flow2d_fused_fallbacks)
     unsigned int* fused_fallbacks = nullptr;
+    unsigned long long* clock_probe = nullptr;  // flow2d_clock_probe_start: per XCD, ticks of the 100 MHz clock and shader cycles
 };
 
 // How a kernel finds its instance of a batched launch: grid.z = planes x batch_count, plane = z % planes (the

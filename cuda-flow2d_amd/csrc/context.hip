@@ -171,6 +171,7 @@ int flow2d_context_destroy(flow2d_context* ctx)
     ctx->event_pool.clear();
     if (ctx->owns_stream) (void)hipStreamDestroy(ctx->stream);
     if (ctx->fused_fallbacks) (void)hipFree(ctx->fused_fallbacks);
+    if (ctx->clock_probe) (void)hipFree(ctx->clock_probe);
     delete ctx;
     return FLOW2D_OK;
 }
@@ -213,6 +214,52 @@ static int read_fused_counter(flow2d_context* ctx, int word, unsigned long long*
 int flow2d_fused_fallbacks(flow2d_context* ctx, unsigned long long* waves) { return read_fused_counter(ctx, 0, waves); }
 
 int flow2d_fused_plain_waves(flow2d_context* ctx, unsigned long long* waves) { return read_fused_counter(ctx, 1, waves); }
+
+// The shader clock the device holds, sampled by one idle wave per XCD beside whatever else runs: each wave reads the constant
+// 100 MHz clock and the shader clock, sleeps (s_sleep: no issue slots taken from the kernels it runs beside) until `duration_us`
+// have passed, reads both again and files cycles / time under its XCD.  Eight workgroups of one wave are dealt to the eight XCDs.
+namespace {
+__global__ __launch_bounds__(64) void clock_probe_kernel(unsigned long long* out, unsigned long long duration_ticks)
+{
+    if (threadIdx.x != 0) return;
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime(), c0 = __builtin_amdgcn_s_memtime();
+    unsigned long long t1 = t0;
+    while (t1 - t0 < duration_ticks) {
+        __builtin_amdgcn_s_sleep(64);
+        t1 = __builtin_amdgcn_s_memrealtime();
+    }
+    const unsigned long long c1 = __builtin_amdgcn_s_memtime();
+    unsigned xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    out[2 * (xcc & 7u)] = t1 - t0;
+    out[2 * (xcc & 7u) + 1] = c1 - c0;
+}
+}  // namespace
+
+int flow2d_clock_probe_start(flow2d_context* ctx, double duration_us)
+{
+    FLOW2D_ENTER(ctx);
+    if (!(duration_us > 0.0) || duration_us > 1e6) return FLOW2D_ERR_INVALID_ARGUMENT;
+    if (!ctx->clock_probe) FLOW2D_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&ctx->clock_probe), 16 * sizeof(unsigned long long)));
+    FLOW2D_HIP_TRY(hipMemsetAsync(ctx->clock_probe, 0, 16 * sizeof(unsigned long long), ctx->stream));
+    clock_probe_kernel<<<8, 64, 0, ctx->stream>>>(ctx->clock_probe, static_cast<unsigned long long>(duration_us * 100.0));
+    FLOW2D_CHECK_LAUNCH();
+    return FLOW2D_OK;
+}
+
+int flow2d_clock_probe_read(flow2d_context* ctx, double* ghz_per_xcd)
+{
+    FLOW2D_ENTER(ctx);
+    if (!ghz_per_xcd) return FLOW2D_ERR_INVALID_ARGUMENT;
+    for (int i = 0; i < 8; ++i) ghz_per_xcd[i] = 0.0;
+    if (!ctx->clock_probe) return FLOW2D_OK;
+    unsigned long long t[16];
+    FLOW2D_HIP_TRY(hipMemcpyAsync(t, ctx->clock_probe, sizeof(t), hipMemcpyDeviceToHost, ctx->stream));
+    FLOW2D_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    for (int i = 0; i < 8; ++i)
+        if (t[2 * i]) ghz_per_xcd[i] = static_cast<double>(t[2 * i + 1]) / (static_cast<double>(t[2 * i]) * 10.0);  // 100 MHz ticks
+    return FLOW2D_OK;
+}
 
 int flow2d_mem_info(flow2d_context* ctx, size_t* free_bytes, size_t* total_bytes)
 {
@@ -341,6 +388,13 @@ int flow2d_context_set_batch(flow2d_context* ctx, size_t count, size_t stride_by
         return FLOW2D_ERR_INVALID_ARGUMENT;
     ctx->batch_count = static_cast<unsigned>(count);
     ctx->batch_stride_floats = count > 1 ? stride_bytes / sizeof(float) : 0;
+    return FLOW2D_OK;
+}
+
+int flow2d_context_set_lone(flow2d_context* ctx, int lone)
+{
+    if (!ctx) return FLOW2D_ERR_INVALID_ARGUMENT;
+    ctx->lone = lone != 0;
     return FLOW2D_OK;
 }
 

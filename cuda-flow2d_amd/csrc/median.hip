@@ -16,9 +16,11 @@
 // Per image row it loads ONE value per lane, takes the four horizontal neighbours from the adjacent lanes
 // (DPP), sorts the 5-tuple (9 comparators) and keeps the sorted tuples of six consecutive rows in
 // registers.  Two vertically adjacent medians share four of their five rows, so each step merges those four
-// sorted tuples once and finishes both medians from there (median5_pair_network.inc, 81 comparators for two
-// pixels, generated and exhaustively verified by tools/gen_median_network.py).  Per pixel: 1 load instead
-// of 25 and about 50 comparators instead of 104.
+// sorted tuples once and finishes both medians from there (median5_pair_network.inc: an 81-comparator merge network,
+// generated and exhaustively verified by tools/gen_median_network.py, lowered by tools/median_select3.py to one-result
+// instructions -- v_min / v_max and the three-input v_min3 / v_max3 / v_med3 -- and shortened under the same exhaustive
+// check: about 80 instructions for two pixels instead of the 123 two-input halves the comparators leave alive, the
+// five-value sorter of a row 13 instead of 18).  Per pixel: 1 load instead of 25.
 #include <array>
 #include <utility>
 
@@ -191,37 +193,39 @@ __global__ __launch_bounds__(256) void median_kernel(const float* __restrict__ i
 }
 
 // ---- r = 5, streaming -----------------------------------------------------------------------------------------
-struct MedianPairOp {
-    int copy, a, b;
+// One-result selection programs (tools/median_select3.py): node (inputs + i) = kind(node a, node b, node c)
+struct SelectOp {
+    int kind, a, b, c;  // kind 0 min, 1 max (two inputs), 2 min3, 3 max3, 4 med3
 };
+template <int KIND>
+__device__ __forceinline__ float select_op(float a, float b, float c)
+{
+    // (the windows that reach these programs hold no NaN and no -0 -- those are redone by exact_median -- so minimum, maximum and
+    //  median of three are selections of one of their operands; fminf(fminf(a, b), c) with a single-use inner result is v_min3_f32)
+    if constexpr (KIND == 0) return fminf(a, b);
+    else if constexpr (KIND == 1) return fmaxf(a, b);
+    else if constexpr (KIND == 2) return fminf(fminf(a, b), c);
+    else if constexpr (KIND == 3) return fmaxf(fmaxf(a, b), c);
+    else return __builtin_amdgcn_fmed3f(a, b, c);
+}
 #include "median5_pair_network.inc"
 
-template <size_t... I>
-__device__ __forceinline__ void run_pair_program(float (&v)[kMedianPairWires], std::index_sequence<I...>)
+// runs PROGRAM on n[0 .. INPUTS): afterwards n[INPUTS + i] holds node i's value (everything stays in registers: the indices are
+// compile-time constants, values nobody reads are never computed)
+template <int INPUTS, int OPS, const SelectOp (&PROGRAM)[OPS], size_t... I>
+__device__ __forceinline__ void run_select_program(float (&n)[INPUTS + OPS], std::index_sequence<I...>)
 {
-    (
-        [&] {
-            constexpr MedianPairOp op = kMedianPairProgram[I];
-            if constexpr (op.copy) {
-                v[op.b] = v[op.a];
-            } else {
-                const float lo = fminf(v[op.a], v[op.b]);
-                const float hi = fmaxf(v[op.a], v[op.b]);
-                v[op.a] = lo;
-                v[op.b] = hi;
-            }
-        }(),
-        ...);
+    ((n[INPUTS + I] = select_op<PROGRAM[I].kind>(n[PROGRAM[I].a], n[PROGRAM[I].b], n[PROGRAM[I].c])), ...);
 }
 
 __device__ __forceinline__ void sort5(float (&t)[5])
 {
-    auto cx = [&](int a, int b) {
-        const float lo = fminf(t[a], t[b]), hi = fmaxf(t[a], t[b]);
-        t[a] = lo;
-        t[b] = hi;
-    };
-    cx(0, 1); cx(3, 4); cx(2, 4); cx(2, 3); cx(0, 3); cx(0, 2); cx(1, 4); cx(1, 3); cx(1, 2);
+    float n[5 + kSort5Ops];
+#pragma unroll
+    for (int i = 0; i < 5; ++i) n[i] = t[i];
+    run_select_program<5, kSort5Ops, kSort5Program>(n, std::make_index_sequence<kSort5Ops>{});
+#pragma unroll
+    for (int i = 0; i < 5; ++i) t[i] = n[kSort5Out[i]];
 }
 
 __device__ __forceinline__ float lane_left(float v)  // lane i <- lane i-1
@@ -299,14 +303,12 @@ __device__ __forceinline__ void median5_step(float (&ring)[6][5], RowLoad<EDGE, 
     next[1] = next[3];
     next[2] = load_row<EDGE, ADD>(in, ya + 6, h, pitch, xc, xm);
     next[3] = load_row<EDGE, ADD>(in, ya + 7, h, pitch, xc, xm);
-    float v[kMedianPairWires];
+    float v[kMedianPairInputs + kMedianPairOps];
 #pragma unroll
     for (int g = 0; g < 6; ++g)
 #pragma unroll
         for (int e = 0; e < 5; ++e) v[5 * g + e] = ring[(2 * I + g) % 6][e];
-#pragma unroll
-    for (int i = 30; i < kMedianPairWires; ++i) v[i] = 0.f;
-    run_pair_program(v, std::make_index_sequence<kMedianPairOps>{});
+    run_select_program<kMedianPairInputs, kMedianPairOps, kMedianPairProgram>(v, std::make_index_sequence<kMedianPairOps>{});
     if (lane_stores) {
         const unsigned at = (static_cast<unsigned>(ya) * static_cast<unsigned>(pitch) + static_cast<unsigned>(x)) * 4u;
         plane_store(out, at, v[kMedianPairOutA]);
@@ -391,6 +393,9 @@ __global__ __launch_bounds__(256) void median5_stream_kernel(const float* __rest
 // vertically adjacent medians share six of their seven rows: median7_pair_network.inc (generated and verified exhaustively
 // over the 8^8 sorted 0-1 inputs by tools/gen_median7_network.py) merges the six shared tuples once and finishes both.
 // The generic kernel gathers 49 values per pixel and sorts them with a pruned Batcher network: 412 us per 4096^2 plane.
+struct MedianPairOp {
+    int copy, a, b;
+};
 #include "median7_pair_network.inc"
 
 template <size_t... I>

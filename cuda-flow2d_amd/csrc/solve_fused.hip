@@ -182,6 +182,36 @@ static FusedPlan fused_plan_search(const flow2d_context* ctx, size_t w, size_t h
     return plan;
 }
 
+// The launch order of a plan's blocks (fused_block_of, solve_fused_args.hpp): every XCD a contiguous run of the plan's order, and
+// the side blocks of a border-aware plan dealt evenly over those runs -- as long as every run has room for its share.
+void fused_order_for(const FusedPlan& plan, FusedArgs& a)
+{
+    a.blocks_per_xcd = (plan.blocks + 7) / 8;
+    a.side_blocks = 0;
+    if (plan.rows_interior != plan.rows_edge && !probe::kSideLast) {
+        const int side = plan.blocks - (plan.blocks_x - 2) * plan.strips_interior;
+        const int last_run = plan.blocks - 7 * a.blocks_per_xcd;
+        if (side > 0 && last_run >= (side + 7) / 8) a.side_blocks = side;
+    }
+}
+
+// Rows [y0, y1) of the strip `by` in block column `bx` (what the kernel computes for its waves)
+void fused_rows_of(const FusedArgs& a, int bx, int by, int& y0, int& y1)
+{
+    const bool uniform = a.rows_interior == a.rows_edge;
+    if (uniform || bx == 0 || bx == a.blocks_x - 1) {
+        y0 = by * a.rows_edge;
+        y1 = std::min(y0 + a.rows_edge, a.h);
+    } else if (by == 0) {
+        y0 = 0, y1 = a.rows_edge;
+    } else if (by == a.strips_interior - 1) {
+        y0 = a.h - a.rows_edge, y1 = a.h;
+    } else {
+        y0 = a.rows_edge + (by - 1) * a.rows_interior;
+        y1 = std::min(y0 + a.rows_interior, a.h - a.rows_edge);
+    }
+}
+
 // One outer iteration: reads du/dv (previous outer iteration), writes out_du/out_dv (after `inner` sweeps).
 int launch_fused_outer(flow2d_context* ctx, int constancy, const float* f0, const float* f1, const float* u,
                        const float* v, const float* du, const float* dv, size_t w, size_t h, size_t pitch_bytes,
@@ -212,7 +242,7 @@ int launch_fused_outer(flow2d_context* ctx, int constancy, const float* f0, cons
                 static_cast<float>(1.0 / (2.0 * hx)), static_cast<float>(1.0 / (2.0 * hy)), alpha / (hx * hx), alpha / (hy * hy),
                 0.5f * (alpha / (hx * hx)), 0.5f * (alpha / (hy * hy)),
                 sor_omega, 1.f - sor_omega,
-                0, plan.blocks, 0, static_cast<unsigned long long>(ctx->batch_stride_floats),
+                0, plan.blocks, 0, 0, static_cast<unsigned long long>(ctx->batch_stride_floats),
                 nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
                 ctx->fused_fallbacks};
 #ifdef FLOW2D_DEV_BUILD
@@ -233,7 +263,7 @@ int launch_fused_outer(flow2d_context* ctx, int constancy, const float* f0, cons
     // XCD-aware block order: x-adjacent blocks share their halo columns, y-adjacent strips their halo rows; in one XCD
     // they meet in its L2 (reads of a 4096^2 launch 541 -> 455 MB; worth 1-3 % of the launch since the round-3 kernel
     // is within reach of the memory system).
-    a.blocks_per_xcd = (plan.blocks + 7) / 8;
+    fused_order_for(plan, a);
     const dim3 grid(a.blocks_per_xcd ? a.blocks_per_xcd * 8 : plan.blocks, 1, instances_per_launch);
     const bool pow2 = is_power_of_two(hx) && is_power_of_two(hy);
     int rc = 0;
@@ -244,7 +274,16 @@ int launch_fused_outer(flow2d_context* ctx, int constancy, const float* f0, cons
         if (a.continue_sweeps) a.start_du += off, a.start_dv += off;
     }
     const int in = static_cast<int>(inner);
-    if (constancy == FLOW2D_CONSTANCY_GRADIENT)
+    // A context that runs alone (flow2d_context_set_lone) and a launch of at most one workgroup per CU -- one wave per SIMD: nothing
+    // to share issue turns with -- take the build with packed arithmetic: fewer, wider instructions (the same IEEE operations).
+    const bool packed_build = ctx->lone && (long)plan.blocks * (long)instances_per_launch <= (long)(ctx->num_cus > 0 ? ctx->num_cus : 256);
+    if (packed_build && constancy == FLOW2D_CONSTANCY_GRADIENT)
+        rc = pow2 ? fused_launch_g1_p1_k(in, grid, ctx->stream, a) : fused_launch_g1_p0_k(in, grid, ctx->stream, a);
+    else if (packed_build && constancy == FLOW2D_CONSTANCY_GRADIENT_UNTILED)
+        rc = pow2 ? fused_launch_g2_p1_k(in, grid, ctx->stream, a) : fused_launch_g2_p0_k(in, grid, ctx->stream, a);
+    else if (packed_build && constancy != FLOW2D_CONSTANCY_LOG_DERIVATIVES)
+        rc = pow2 ? fused_launch_g0_p1_k(in, grid, ctx->stream, a) : fused_launch_g0_p0_k(in, grid, ctx->stream, a);
+    else if (constancy == FLOW2D_CONSTANCY_GRADIENT)
         rc = pow2 ? fused_launch_g1_p1(in, grid, ctx->stream, a) : fused_launch_g1_p0(in, grid, ctx->stream, a);
     else if (constancy == FLOW2D_CONSTANCY_GRADIENT_UNTILED)
         rc = pow2 ? fused_launch_g2_p1(in, grid, ctx->stream, a) : fused_launch_g2_p0(in, grid, ctx->stream, a);
@@ -264,6 +303,31 @@ int launch_fused_outer(flow2d_context* ctx, int constancy, const float* f0, cons
 }
 
 }  // namespace flow2d
+
+// Diagnostics: the blocks a strip launch of this geometry would run, in launch order -- (block column, strip, first row, end row)
+// per launch block id, -1 for ids beyond the plan (the grid is a multiple of eight).  tests/test_gpu_fused.py checks that the order
+// is a permutation of the plan and the rows a partition of the image.
+extern "C" FLOW2D_API int flow2d_fused_block_order(flow2d_context* ctx, size_t width, size_t height, size_t inner, size_t instances,
+                                                   int* out, size_t capacity_blocks, size_t* grid_blocks)
+{
+    if (!ctx || !out || !grid_blocks || !flow2d::fused_supports(inner) || width == 0 || height == 0 || instances == 0)
+        return FLOW2D_ERR_INVALID_ARGUMENT;
+    const flow2d::FusedPlan plan = flow2d::fused_plan(ctx, width, height, inner, (long)instances);
+    flow2d::FusedArgs a{};
+    a.w = (int)width, a.h = (int)height;
+    a.rows_interior = plan.rows_interior, a.rows_edge = plan.rows_edge, a.strips_interior = plan.strips_interior, a.blocks_x = plan.blocks_x;
+    a.blocks = plan.blocks;
+    flow2d::fused_order_for(plan, a);
+    const size_t grid = (size_t)a.blocks_per_xcd * 8;
+    *grid_blocks = grid;
+    if (grid > capacity_blocks) return FLOW2D_ERR_INVALID_ARGUMENT;
+    for (size_t id = 0; id < grid; ++id) {
+        int bx = -1, by = -1, y0 = -1, y1 = -1;
+        if (flow2d::fused_block_of(a, (int)id, bx, by)) flow2d::fused_rows_of(a, bx, by, y0, y1);
+        out[4 * id + 0] = bx, out[4 * id + 1] = by, out[4 * id + 2] = y0, out[4 * id + 3] = y1;
+    }
+    return FLOW2D_OK;
+}
 
 #ifdef FLOW2D_DEV_BUILD
 // developer builds only: the wave stamps recorded since the last call (kStampWords words per wave), newest launches last, and -- when

@@ -10,7 +10,11 @@
 
 namespace flow2d {
 
+#ifdef FLOW2D_FUSED_INSTANCE_LONE  // the packed build for under-filled launches of a context that runs alone (csrc/Makefile)
+#define FLOW2D_FUSED_INSTANCE_NAME2(g, p) fused_launch_g##g##_p##p##_k
+#else
 #define FLOW2D_FUSED_INSTANCE_NAME2(g, p) fused_launch_g##g##_p##p
+#endif
 #define FLOW2D_FUSED_INSTANCE_NAME(g, p) FLOW2D_FUSED_INSTANCE_NAME2(g, p)
 
 int FLOW2D_FUSED_INSTANCE_NAME(FLOW2D_FUSED_INSTANCE_GRAD, FLOW2D_FUSED_INSTANCE_POW2)(int inner, dim3 grid, hipStream_t stream,

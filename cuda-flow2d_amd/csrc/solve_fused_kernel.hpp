@@ -414,7 +414,7 @@ __device__ __forceinline__ void strip_step(Strip<INNER, GRAD>& s, const FusedArg
         const unsigned off = (static_cast<unsigned>(rs) * static_cast<unsigned>(a.pitch) + static_cast<unsigned>(xc)) * 4u;
         s.n_start = v2f{plane_load(a.start_du, off), plane_load(a.start_dv, off)};
     }
-    if constexpr (probe::kStamps && T < 0) timed_row_wait(s, r - 1 - (y0 - S::kHalo));
+    if constexpr (probe::kStalls && T < 0) timed_row_wait(s, r - 1 - (y0 - S::kHalo));
     if constexpr (probe::kExchange >= 0 && T < 0) exchange_cost(s, J);
     s.f0w[s0] = s.n.f0;
     s.f1w[s0] = s.n.f1;
@@ -813,24 +813,10 @@ __global__ __launch_bounds__(256, 2) void fused_outer_kernel(FusedArgs a)
     const unsigned long long stamp_r0 = probe::kStamps ? __builtin_amdgcn_s_memrealtime() : 0ull;
     const unsigned long long stamp_c0 = probe::kStamps ? __builtin_amdgcn_s_memtime() : 0ull;
     unsigned stall[3] = {0u, 0u, 0u};
-    // block id -> block column bx and strip by: uniform strips row by row; a border-aware plan first the interior
-    // block columns (strips_interior strips each), then the first and the last block column (strips of rows_edge)
+    // launch block id -> block column bx and strip by of the plan (solve_fused_args.hpp: every XCD a contiguous, equally heavy run)
     int bx, by;
     const bool uniform = a.rows_interior == a.rows_edge;
-    const int inner_cols = a.blocks_x - 2, inner_blocks = inner_cols * a.strips_interior;
-    int id = blockIdx.x;
-    if (a.blocks_per_xcd) {  // workgroups are dealt to the eight XCDs in turn: give every XCD a contiguous run of blocks
-        id = (id & 7) * a.blocks_per_xcd + (id >> 3);
-        if (id >= a.blocks) return;
-    }
-    if (uniform) {
-        bx = id % a.blocks_x, by = id / a.blocks_x;
-    } else if (id < inner_blocks) {
-        bx = 1 + id % inner_cols, by = id / inner_cols;
-    } else {
-        const int j = id - inner_blocks;
-        bx = (j & 1) ? a.blocks_x - 1 : 0, by = j >> 1;
-    }
+    if (!fused_block_of(a, static_cast<int>(blockIdx.x), bx, by)) return;
     const int strip_x = bx * 4 + (threadIdx.x >> 6);
     if (strip_x * S::kValid >= a.w) return;  // whole wave leaves; waves never synchronise with each other
     {  // instance of a batched launch

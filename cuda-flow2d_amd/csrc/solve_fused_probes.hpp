@@ -3,14 +3,16 @@
 // library has none of them and reads no environment variable.  The kernel tests them as compile-time constants (`if constexpr`),
 // so a probe that is off leaves no instruction and no register behind.
 //   FLOW2D_FUSED_DEV            only the instantiations of the 4096^2 benchmark (inner 5 and 2, power-of-two spacing): half a minute
-//   FLOW2D_FUSED_STAMPS         per-wave time stamps and the histogram of each wave's stalls at the row commit
-//                               (tools/fused_wave_stamps.py, tools/fused_stall_histogram.py)
+//   FLOW2D_FUSED_STAMPS         per-wave time stamps: start, end, shader cycles, where it ran (tools/fused_wave_stamps.py)
+//   FLOW2D_FUSED_STALLS         (with STAMPS) ... and the histogram of each wave's waits at the row commit, by duration and by the
+//                               wave's progress; about twenty more instructions per row step (+3-5 % on the launch)
 //   FLOW2D_FUSED_COMPUTE_ONLY   timing probe, WRONG results: every row folded onto eight cache-resident rows
 //   FLOW2D_FUSED_MEMORY_ONLY    timing probe, WRONG results: the strip's loads and stores without its arithmetic
 //   FLOW2D_FUSED_NO_HALO        timing probe, WRONG results at strip edges: no halo lanes -- 64 stored columns per wave, the bound
 //                               of any design that exchanges edge columns between waves instead of recomputing them
 //   FLOW2D_FUSED_EXCHANGE=n     (with NO_HALO) ... plus what such an exchange would cost: one s_barrier and n 8-byte LDS writes + n
 //                               two-address LDS reads per row step (0: the barrier alone)
+//   FLOW2D_FUSED_SIDE_LAST      A/B: the side blocks of a border-aware plan all in the last XCD's run, as in rounds 3-5
 //   FLOW2D_FUSED_PACKED_PLANES  f0, f1, u, v read as ONE float4 plane and du, dv as one float2 plane in, one out (the launcher
 //                               packs and unpacks around the launch): 8 -> 3 vector-memory instructions per row step
 // Settled questions of rounds 2-5 (short ring, no lane shifts, three rows in flight, stagger, non-temporal accesses, register
@@ -18,8 +20,8 @@
 // no longer switches: their results are in profiles/r0N_experiments/.
 #pragma once
 
-#if (defined(FLOW2D_FUSED_DEV) || defined(FLOW2D_FUSED_STAMPS) || defined(FLOW2D_FUSED_COMPUTE_ONLY) || defined(FLOW2D_FUSED_MEMORY_ONLY) || \
-     defined(FLOW2D_FUSED_NO_HALO) || defined(FLOW2D_FUSED_EXCHANGE) || defined(FLOW2D_FUSED_PACKED_PLANES)) && !defined(FLOW2D_DEV_BUILD)
+#if (defined(FLOW2D_FUSED_DEV) || defined(FLOW2D_FUSED_STAMPS) || defined(FLOW2D_FUSED_STALLS) || defined(FLOW2D_FUSED_COMPUTE_ONLY) || defined(FLOW2D_FUSED_MEMORY_ONLY) || \
+     defined(FLOW2D_FUSED_NO_HALO) || defined(FLOW2D_FUSED_EXCHANGE) || defined(FLOW2D_FUSED_PACKED_PLANES) || defined(FLOW2D_FUSED_SIDE_LAST)) && !defined(FLOW2D_DEV_BUILD)
 #error "the fused kernel's probes need -DFLOW2D_DEV_BUILD: they are not part of the product library"
 #endif
 
@@ -34,6 +36,11 @@ constexpr bool kDevInstances = false;
 constexpr bool kStamps = true;
 #else
 constexpr bool kStamps = false;
+#endif
+#ifdef FLOW2D_FUSED_STALLS
+constexpr bool kStalls = true;
+#else
+constexpr bool kStalls = false;
 #endif
 #ifdef FLOW2D_FUSED_COMPUTE_ONLY
 constexpr bool kComputeOnly = true;
@@ -54,6 +61,11 @@ constexpr bool kNoHalo = false;
 constexpr int kExchange = FLOW2D_FUSED_EXCHANGE;
 #else
 constexpr int kExchange = -1;  // no exchange probe (0: the barrier alone)
+#endif
+#ifdef FLOW2D_FUSED_SIDE_LAST
+constexpr bool kSideLast = true;
+#else
+constexpr bool kSideLast = false;
 #endif
 #ifdef FLOW2D_FUSED_PACKED_PLANES
 constexpr bool kPackedPlanes = true;

@@ -59,6 +59,7 @@ bool OpticalFlow2D::Initialize(const DataSize3& data_size, DataConstancy data_co
         return false;
     }
     group_ = group_size;
+    (void)flow2d_context_set_lone(context_, lone ? 1 : 0);
     dev_container_size_ = data_size;
     dev_container_size_.pitch = 0;
     data_constancy_ = data_constancy;
@@ -74,7 +75,7 @@ bool OpticalFlow2D::InitMemory()
     if (CheckFlow2DError(flow2d_mem_info(context_, &free_bytes, &total_bytes), "flow2d_mem_info")) return false;
     const size_t pitch = flow2d_plane_pitch_bytes(dev_container_size_.width);
     // (+ the two packed x-pass planes; a lock-step group holds every plane group_ containers tall)
-    const size_t needed = pitch * dev_container_size_.height * group_ * (kContainersCount + 2);
+    const size_t needed = pitch * dev_container_size_.height * group_ * (kContainersCount + 2 + (lone ? 1 : 0));
     if (!silent)
         std::printf("Available\t:\t%.0fMB / %.0fMB\nNeeded\t\t:\t%.0fMB\n", free_bytes / 1048576.f,
                     total_bytes / 1048576.f, needed / 1048576.f);
@@ -104,6 +105,23 @@ bool OpticalFlow2D::InitMemory()
         }
         packed = static_cast<DevicePtr>(reinterpret_cast<uintptr_t>(plane));
     }
+    if (lone) {  // the second stream of a pair, its events and the plane the warp writes (see RunPyramid); failing here only switches the fork off
+        int device = 0;
+        void* plane = nullptr;
+        size_t got_pitch = 0;
+        if (flow2d_context_device(context_, &device) == FLOW2D_OK && flow2d_context_create(device, &side_context_) == FLOW2D_OK &&
+            flow2d_plane_alloc(context_, dev_container_size_.width, dev_container_size_.height * group_, &plane, &got_pitch) == FLOW2D_OK &&
+            got_pitch == pitch) {
+            fork_warp_plane_ = static_cast<DevicePtr>(reinterpret_cast<uintptr_t>(plane));
+            fork_events_.assign(2 + FLOW2D_RESAMPLE_MAX_LEVELS, nullptr);
+            for (void*& e : fork_events_)
+                if (flow2d_event_create(context_, &e) != FLOW2D_OK) e = nullptr;
+        }
+        if (!fork_warp_plane_ || std::find(fork_events_.begin(), fork_events_.end(), nullptr) != fork_events_.end()) {
+            if (plane && !fork_warp_plane_) flow2d_plane_free(context_, plane);
+            ReleaseFork();
+        }
+    }
     dev_container_size_.pitch = pitch;
     return true;
 }
@@ -125,6 +143,13 @@ bool OpticalFlow2D::InitOperations()
         if (!silent) std::printf("%-18s: %s\n", cuop->GetName(), ok ? "OK" : "FAILED");
         if (!ok) return false;
     }
+    if (side_context_) {  // the pre-blur of a forked pair runs on the second stream: an operator bound to that context
+        OperationParameters side;
+        side.PushValuePtr("container_size", &dev_container_size_);
+        side.PushValuePtr("data_constancy", &data_constancy_);
+        side.PushValuePtr("flow2d_context", &side_context_);
+        if (!side_convolution_.Initialize(&side)) ReleaseFork();
+    }
     return true;
 }
 
@@ -133,6 +158,7 @@ void OpticalFlow2D::Destroy()
     CudaOperationBase* ops[] = {&cuop_add_, &cuop_convolution_, &cuop_median_,
                                 &cuop_register_, &cuop_resample_, &cuop_solve_};
     for (CudaOperationBase* cuop : ops) cuop->Destroy();
+    side_convolution_.Destroy();
     if (context_) {
         if (!all_planes_.empty()) flow2d_synchronize(context_);
         DropGraphs();
@@ -148,10 +174,23 @@ void OpticalFlow2D::Destroy()
             if (p) flow2d_plane_free(context_, AsPlane(p));
             p = 0;
         }
+        ReleaseFork();
     }
     all_planes_.clear();
     free_planes_.clear();
     initialized_ = false;
+}
+
+void OpticalFlow2D::ReleaseFork()
+{
+    if (side_context_) (void)flow2d_synchronize(side_context_);
+    for (void* e : fork_events_)
+        if (e) flow2d_event_destroy(context_, e);
+    fork_events_.clear();
+    if (fork_warp_plane_) flow2d_plane_free(context_, AsPlane(fork_warp_plane_));
+    fork_warp_plane_ = 0;
+    if (side_context_) flow2d_context_destroy(side_context_);
+    side_context_ = nullptr;
 }
 
 DevicePtr OpticalFlow2D::Acquire()
@@ -581,6 +620,48 @@ bool OpticalFlow2D::RunPyramid(OperationParameters& params)
     bool failed = false;
 
     const bool sequence = sequence_frames_[0] != nullptr;
+
+    // The reference resamples both frames from FULL resolution at every level (optical_flow_2d.cpp:284-303): one read
+    // of each frame per level.  Here the x passes of all levels > 0 are one trip over the frames (every row read once,
+    // the x-resampled rows of all levels written side by side into a packed plane per frame; same cell sums, same
+    // bits); a level's y pass then reads its segment.  Used when the segments fit one row (scale factors up to ~0.5).
+    std::vector<size_t> packed_width, packed_column;
+    bool packed = false;
+    if (!sequence && level >= 2 && original_size.width <= 15360 && level <= FLOW2D_RESAMPLE_MAX_LEVELS) {
+        size_t column = 0;
+        for (int l = level; l >= 1; --l) {
+            const float s = std::pow(warp_scale_factor, static_cast<float>(l));
+            const size_t lw = static_cast<size_t>(std::ceil(original_size.width * s));
+            packed_width.push_back(lw);
+            packed_column.push_back(column);
+            column += (lw + 3) / 4 * 4;  // 16-byte aligned segments (what a plane pointer must be)
+        }
+        packed = column <= dev_container_size_.pitch / sizeof(float);
+    }
+    const int first_level = level;
+    // A lone object (`lone`, optical_flow_2d.h) forks the flow-independent part of the pair onto its second stream: the pre-blur of
+    // the caller's frames, the x passes, and every level's y pass into a plane region of its own -- the levels one below the other in
+    // the two planes that otherwise hold "the current level's frames" (their heights sum to less than the container's for scale
+    // factors up to 0.5) -- each followed by an event the main stream waits for before that level's warp.  The main stream meanwhile
+    // runs the coarse levels, whose launches leave most of the device idle.  Same kernels on the same values: same bits.
+    std::vector<size_t> fork_row(static_cast<size_t>(first_level) + 1, 0);
+    bool fork = false;
+    if (packed && side_context_ && fork_warp_plane_ && caller_frame_0_ && caller_frame_1_) {
+        size_t rows = 0;
+        for (int l = first_level; l >= 1; --l) {
+            fork_row[static_cast<size_t>(l)] = rows;
+            rows += static_cast<size_t>(std::ceil(original_size.height * std::pow(warp_scale_factor, static_cast<float>(l))));
+        }
+        fork = rows <= dev_container_size_.height;
+    }
+    const size_t pitch_floats = dev_container_size_.pitch / sizeof(float);
+    auto level_ready = [&](int l) { return fork_events_[1 + static_cast<size_t>(l)]; };
+    if (fork) {
+        if (group_ > 1) failed |= CheckFlow2DError(flow2d_context_set_batch(side_context_, active_group_, GroupStrideBytes()), "flow2d_context_set_batch");
+        failed |= CheckFlow2DError(flow2d_event_record(context_, fork_events_[0]), "flow2d_event_record");
+        failed |= CheckFlow2DError(flow2d_stream_wait_event(side_context_, fork_events_[0]), "flow2d_stream_wait_event");
+    }
+
     if (sequence) {  // a frame's level 0 is blurred once (or is the caller's own plane) and then only read
         DevicePtr callers[2] = {caller_frame_0_, caller_frame_1_};
         DevicePtr* level0[2] = {&frame_0, &frame_1};
@@ -613,11 +694,12 @@ bool OpticalFlow2D::RunPyramid(OperationParameters& params)
             op.Clear();
             op.PushValuePtr("dev_input", &sources[i]);
             op.PushValuePtr("dev_output", targets[i]);
-            op.PushValuePtr("dev_temp", &temp);
+            op.PushValuePtr("dev_temp", &temp);  // (not touched: the blur is one launch)
             op.PushValuePtr("data_size", &original_size);
             op.PushValuePtr("gaussian_sigma", &gaussian_sigma);
-            cuop_convolution_.Execute(op);
-        failed |= cuop_convolution_.TakeFailure();
+            CudaOperationConvolution2D& blur = fork ? side_convolution_ : cuop_convolution_;  // forked: on the second stream
+            blur.Execute(op);
+            failed |= blur.TakeFailure();
         }
         Release(temp);
     } else if (gaussian_sigma > 0.0) {  // optical_flow_2d.cpp:218-246: blur into the flow planes, then swap roles
@@ -637,33 +719,28 @@ bool OpticalFlow2D::RunPyramid(OperationParameters& params)
         Release(temp);
     }
 
-    // The reference resamples both frames from FULL resolution at every level (optical_flow_2d.cpp:284-303): one read
-    // of each frame per level.  Here the x passes of all levels > 0 are one trip over the frames (every row read once,
-    // the x-resampled rows of all levels written side by side into a packed plane per frame; same cell sums, same
-    // bits); a level's y pass then reads its segment.  Used when the segments fit one row (scale factors up to ~0.5).
-    std::vector<size_t> packed_width, packed_column;
-    bool packed = false;
-    if (!sequence && level >= 2 && original_size.width <= 15360 && level <= FLOW2D_RESAMPLE_MAX_LEVELS) {
-        size_t column = 0;
-        for (int l = level; l >= 1; --l) {
+    if (packed) {
+        flow2d_context* where = fork ? side_context_ : context_;
+        if (fork)  // the frames as level 0 reads them are complete behind the blur
+            failed |= CheckFlow2DError(flow2d_event_record(side_context_, level_ready(0)), "flow2d_event_record");
+        if (CheckFlow2DError(flow2d_resample_x_levels(where, AsPlane(frame_0), AsPlane(packed_frames_[0]),
+                                                      AsPlane(frame_1), AsPlane(packed_frames_[1]),
+                                                      original_size.width, original_size.height,
+                                                      dev_container_size_.pitch, packed_width.size(),
+                                                      packed_width.data(), packed_column.data()),
+                             "flow2d_resample_x_levels"))
+            failed = true;
+        for (int l = first_level; fork && l >= 1; --l) {  // every level's y pass, coarsest first, each with its event
             const float s = std::pow(warp_scale_factor, static_cast<float>(l));
-            const size_t lw = static_cast<size_t>(std::ceil(original_size.width * s));
-            packed_width.push_back(lw);
-            packed_column.push_back(column);
-            column += (lw + 3) / 4 * 4;  // 16-byte aligned segments (what a plane pointer must be)
-        }
-        if (column <= dev_container_size_.pitch / sizeof(float)) {
-            packed = true;
-            if (CheckFlow2DError(flow2d_resample_x_levels(context_, AsPlane(frame_0), AsPlane(packed_frames_[0]),
-                                                          AsPlane(frame_1), AsPlane(packed_frames_[1]),
-                                                          original_size.width, original_size.height,
-                                                          dev_container_size_.pitch, packed_width.size(),
-                                                          packed_width.data(), packed_column.data()),
-                                 "flow2d_resample_x_levels"))
-                failed = true;
+            const size_t lw = static_cast<size_t>(std::ceil(original_size.width * s)), lh = static_cast<size_t>(std::ceil(original_size.height * s));
+            const size_t column = packed_column[static_cast<size_t>(first_level - l)], at = fork_row[static_cast<size_t>(l)] * pitch_floats;
+            failed |= CheckFlow2DError(flow2d_resample_y_pair(side_context_, AsPlane(packed_frames_[0]) + column, AsPlane(frame_0_res) + at,
+                                                              AsPlane(packed_frames_[1]) + column, AsPlane(frame_1_res) + at, lw, lh,
+                                                              original_size.height, dev_container_size_.pitch),
+                                       "flow2d_resample_y_pair");
+            failed |= CheckFlow2DError(flow2d_event_record(side_context_, level_ready(l)), "flow2d_event_record");
         }
     }
-    const int first_level = level;
 
     DataSize3 current_size = {0, 0, 0}, prev_size = {0, 0, 0};
     for (; level >= 0; --level) {
@@ -702,6 +779,8 @@ bool OpticalFlow2D::RunPyramid(OperationParameters& params)
                 sequence_level[i] = plane;
             }
             if (temp) Release(temp);
+        } else if (fork) {  // this level's frames come from the second stream: wait for them (the host does not)
+            failed |= CheckFlow2DError(flow2d_stream_wait_event(context_, level_ready(level)), "flow2d_stream_wait_event");
         } else if (level == 0) {
             std::swap(frame_0, frame_0_res);
             std::swap(frame_1, frame_1_res);
@@ -755,7 +834,24 @@ bool OpticalFlow2D::RunPyramid(OperationParameters& params)
         }
 
         DevicePtr solve_frame_0 = frame_0_res;  // what the solver reads as frame 0 of this level
-        if (sequence) {  // the level planes are kept for the next pair: warp into the pool plane, read the rest
+        DevicePtr solve_frame_1 = 0;            // ... and as (warped) frame 1: frame_1_res unless set
+        if (fork) {  // the level planes stay where the second stream put them; the warp writes the plane kept for it
+            const size_t at = level > 0 ? fork_row[static_cast<size_t>(level)] * dev_container_size_.pitch : 0;
+            DevicePtr level_0 = (level > 0 ? frame_0_res : frame_0) + at, level_1 = (level > 0 ? frame_1_res : frame_1) + at;
+            op.Clear();
+            op.PushValuePtr("dev_frame_0", &level_0);
+            op.PushValuePtr("dev_frame_1", &level_1);
+            op.PushValuePtr("dev_flow_u", &flow_u);
+            op.PushValuePtr("dev_flow_v", &flow_v);
+            op.PushValuePtr("dev_output", &fork_warp_plane_);
+            op.PushValuePtr("data_size", &current_size);
+            op.PushValuePtr("hx", &hx);
+            op.PushValuePtr("hy", &hy);
+            cuop_register_.Execute(op);
+            failed |= cuop_register_.TakeFailure();
+            solve_frame_0 = level_0;
+            solve_frame_1 = fork_warp_plane_;
+        } else if (sequence) {  // the level planes are kept for the next pair: warp into the pool plane, read the rest
             op.Clear();
             op.PushValuePtr("dev_frame_0", &sequence_level[0]);
             op.PushValuePtr("dev_frame_1", &sequence_level[1]);
@@ -789,7 +885,7 @@ bool OpticalFlow2D::RunPyramid(OperationParameters& params)
             DevicePtr phi = Acquire(), ksi = Acquire(), temp_du = Acquire(), temp_dv = Acquire();
             op.Clear();
             op.PushValuePtr("dev_frame_0", &solve_frame_0);
-            op.PushValuePtr("dev_frame_1", &frame_1_res);
+            op.PushValuePtr("dev_frame_1", solve_frame_1 ? &solve_frame_1 : &frame_1_res);
             op.PushValuePtr("dev_flow_u", &flow_u);
             op.PushValuePtr("dev_flow_v", &flow_v);
             op.PushValuePtr("dev_flow_du", &flow_du);
@@ -854,6 +950,7 @@ bool OpticalFlow2D::RunPyramid(OperationParameters& params)
     }
     dev_flow_u_ = flow_u;
     dev_flow_v_ = flow_v;
+    if (fork && group_ > 1) flow2d_context_set_batch(side_context_, 1, 0);
     Release(frame_0_res);
     Release(frame_1_res);
     Release(flow_du);

@@ -118,6 +118,15 @@ public:
 
     bool silent = false;
 
+    // Set BEFORE Initialize.  true: this object runs its pairs one after the other with nothing else of the same job beside them on
+    // the device (the CLI, a lone ComputeFlowDevice user, a batch of one lane) -- latency is what counts, so (i) the part of a pair
+    // that does not depend on the flow -- pre-blur, the x passes of all pyramid levels, every level's y pass (the reference resamples
+    // both frames from full resolution at every level, optical_flow_2d.cpp:284-303) -- runs on a second stream beside the
+    // launch-bound coarse levels and joins before each level's warp (recorded into the same graph), and (ii) strip launches that
+    // leave half the wave slots empty use the build of the strip kernel with packed arithmetic (flow2d_context_set_lone).
+    // OpticalFlowBatch2D clears it for its lanes when there are several: in a pipeline the other lanes' work fills the device.
+    bool lone = true;
+
 private:
     bool InitMemory();
     bool InitOperations();
@@ -128,6 +137,7 @@ private:
                              const DevicePtr* dev_flows_u, const DevicePtr* dev_flows_v, OperationParameters& params);
     bool ReplayOrRecord(std::vector<unsigned char> key, const std::function<bool()>& queue);
     void DropGraphs();
+    void ReleaseFork();
     DevicePtr Acquire();
     void Release(DevicePtr p);
 
@@ -159,6 +169,12 @@ private:
     DevicePtr SequenceLevelPlane(FramePyramid& pyramid, size_t level, size_t rows);
     void FreeSequenceCache();
     flow2d_context* context_ = nullptr;
+    // lone objects: the second stream of a pair (a context of its own on the same device), the events that hand its results to the
+    // main stream -- [0] the forking point, [1 + l] "level l's frames are ready" -- and two planes beside the pool: the warped frame
+    // of a level (the level planes stay where the side stream put them) -- see RunPyramid
+    flow2d_context* side_context_ = nullptr;
+    std::vector<void*> fork_events_;
+    DevicePtr fork_warp_plane_ = 0;
     float last_total_ms_ = 0.f;
     bool last_run_ok_ = false;
     // recorded pyramids, keyed by the caller buffers and parameters they were recorded for
@@ -172,6 +188,7 @@ private:
 
     CudaOperationAdd2D cuop_add_;
     CudaOperationConvolution2D cuop_convolution_;
+    CudaOperationConvolution2D side_convolution_;  // lone objects: the pre-blur on the second stream
     CudaOperationMedian2D cuop_median_;
     CudaOperationRegistration2D cuop_register_;
     CudaOperationResample2D cuop_resample_;

@@ -35,6 +35,7 @@ bool OpticalFlowBatch2D::Initialize(const DataSize3& data_size, DataConstancy da
             ScopedDeviceContext current(lane->context);
             lane->flow.silent = silent;
             lane->flow.group_size = group_size;
+            lane->flow.lone = lanes == 1;  // several lanes fill the device with each other's work: no second stream per lane
             ok = lane->flow.Initialize(data_size, data_constancy);
             if (!ok) lane->flow.Destroy();
         }

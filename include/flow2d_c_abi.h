@@ -95,6 +95,12 @@ FLOW2D_API int flow2d_synchronize(flow2d_context* ctx); /* cuStreamSynchronize(N
  * two-plane launches put 2 x count into grid.z). */
 #define FLOW2D_BATCH_MAX 32767
 FLOW2D_API int flow2d_context_set_batch(flow2d_context* ctx, size_t count, size_t stride_bytes);
+/* A hint, not a mode: lone != 0 says that the caller runs this context's launches alone on the device -- one pair after the
+ * other, no other lane of the same job beside them (OpticalFlow2D::lone sets it; no reference counterpart, the reference has one
+ * context and blocks after every launch, cuda_operation_solve_2d.cpp:291).  Strip launches of the solver that leave half the
+ * device's wave slots empty then take the build of the strip kernel with packed arithmetic (a wave alone on its SIMD has nothing
+ * to share issue turns with; the same IEEE operations, the same bits).  Default 0. */
+FLOW2D_API int flow2d_context_set_lone(flow2d_context* ctx, int lone);
 /* cuMemGetInfo, optical_flow_2d.cpp:91 */
 FLOW2D_API int flow2d_mem_info(flow2d_context* ctx, size_t* free_bytes, size_t* total_bytes);
 FLOW2D_API int flow2d_device_name(flow2d_context* ctx, char* buf, size_t buf_len);
@@ -373,6 +379,22 @@ FLOW2D_API int flow2d_fused_fallbacks(flow2d_context* ctx, unsigned long long* w
  * proven for (2h or 4h outside [2^-30, 2^40], a NaN spacing): such a launch runs the plain expressions throughout.  Counted
  * apart from the guard trips above (synchronises the stream). */
 FLOW2D_API int flow2d_fused_plain_waves(flow2d_context* ctx, unsigned long long* waves);
+/* The shader clock the device holds while other work runs.  flow2d_clock_probe_start queues, on this context's stream, one
+ * sleeping wave per XCD that brackets `duration_us` microseconds with the constant 100 MHz clock and the shader clock (it takes
+ * no issue slots from the kernels it runs beside: queue it on a context of its own while the work of interest runs on others);
+ * flow2d_clock_probe_read waits for it and returns cycles / time per XCD in GHz (0 for an XCD no wave landed on).  Why it matters:
+ * the chip's power management moves the clock between about 1.6 and 2.4 GHz with the power the running kernels draw -- the strip
+ * kernel's instruction stream takes 13-16 % longer beside its own HBM traffic than on cache-resident rows AT THE SAME CYCLE COUNT,
+ * and the eight XCDs of one chip differ by 3-5 % -- so a launch duration is only comparable at a known clock. */
+FLOW2D_API int flow2d_clock_probe_start(flow2d_context* ctx, double duration_us);
+FLOW2D_API int flow2d_clock_probe_read(flow2d_context* ctx, double* ghz_per_xcd);
+/* The blocks a strip launch of a width x height level with `inner` sweeps and `instances` lock-step instances runs on this
+ * device, in launch order: out[4 i .. 4 i + 3] = block column, strip, first row, end row of launch block i (all -1 for an id the
+ * plan leaves empty); *grid_blocks = the launch's grid (a multiple of eight: workgroups are dealt to the eight XCDs in turn and
+ * every XCD gets a contiguous, equally heavy run of the plan).  FLOW2D_ERR_INVALID_ARGUMENT when capacity_blocks is too small
+ * (*grid_blocks is set).  A test hook: the order must be a permutation of the plan, the strips a partition of the level. */
+FLOW2D_API int flow2d_fused_block_order(flow2d_context* ctx, size_t width, size_t height, size_t inner, size_t instances,
+                                        int* out, size_t capacity_blocks, size_t* grid_blocks);
 
 FLOW2D_API int flow2d_timing_enable(flow2d_context* ctx, int mode);
 /* mode 2 brackets individual launches only for levels of at least min_width x min_height pixels

@@ -579,6 +579,44 @@ def test_graph_replay_matches_eager(flow2d, oracle, ctx):
         flow.close()
 
 
+@pytest.mark.parametrize("constancy", [0, 1])
+@pytest.mark.parametrize("w,h,levels", [(512, 384, 6), (200, 136, 4), (1024, 1024, 7)])
+def test_forked_frame_pyramid_matches_the_single_stream(flow2d, oracle, ctx, w, h, levels, constancy):
+    """Round 6: a lone OpticalFlow2D runs the flow-independent part of a pair -- pre-blur, the x passes of all levels, every level's
+    y pass -- on a second stream, joined by events before each level's warp (eager and recorded into the graph).  Same kernels
+    on the same values: the flow equals the single-stream object's and the oracle's, bit for bit, also when the same graph is
+    replayed on new frames and when back-to-back pairs reuse the level planes (the next pair's second stream must not overtake)."""
+    p = flow2d.OpticalFlow.params(levels, 0.5, 3, 5, 35.0, 0.001, 0.001, 5, 1.5)
+    pairs = [oracle.synthetic_pair(w, h, 1.25 + k, -0.5 * k, seed=20 + k, noise=True) for k in range(3)]
+    wanted = [oracle.compute_flow(f0, f1, levels, 0.5, 3, 5, 35.0, 0.001, 0.001, 5, 1.5, constancy)[:2] for f0, f1 in pairs]
+    for lone in (True, False):
+        flow = flow2d.OpticalFlow(w, h, constancy, ctx=ctx, lone=lone)
+        try:
+            planes = [ctx.plane(w, h), ctx.plane(w, h), ctx.plane(w, h), ctx.plane(w, h)]
+            outs = [(ctx.plane(w, h), ctx.plane(w, h)) for _ in pairs]
+            for graph in (False, True):
+                flow.use_graph(graph)
+                for (f0, f1), (ou, ov) in zip(pairs, wanted):
+                    planes[0].upload(f0)
+                    planes[1].upload(f1)
+                    planes[2].fill_bytes(0x55)
+                    planes[3].fill_bytes(0x55)
+                    flow.compute_flow_device(*[pl.ptr for pl in planes], p)
+                    ctx.synchronize()
+                    assert np.array_equal(planes[2].download(), ou) and np.array_equal(planes[3].download(), ov), (lone, graph)
+                # three pairs queued back to back without a host wait, each into flow planes of its own
+                frames = [(ctx.plane(w, h, f0), ctx.plane(w, h, f1)) for f0, f1 in pairs]
+                for (a, b), (u, v) in zip(frames, outs):
+                    u.fill_bytes(0x55)
+                    v.fill_bytes(0x55)
+                    flow.compute_flow_device(a.ptr, b.ptr, u.ptr, v.ptr, p)
+                ctx.synchronize()
+                for (u, v), (ou, ov) in zip(outs, wanted):
+                    assert np.array_equal(u.download(), ou) and np.array_equal(v.download(), ov), (lone, graph, "back to back")
+        finally:
+            flow.close()
+
+
 def test_graph_cache_evicts_the_least_recently_used(flow2d, oracle, ctx):
     """More (buffers, parameters) combinations than the cache of recorded pyramids holds (32): the least recently replayed
     graph goes, one at a time, and whatever is replayed or re-recorded afterwards still computes the right flow."""

@@ -262,3 +262,28 @@ def test_a_spacing_outside_the_guarded_range_takes_the_plain_divisions(ctx, orac
     assert np.array_equal(bits(a), bits(odu)) and np.array_equal(bits(b), bits(odv))
     assert ctx.fused_plain_waves() > plain_before
     assert ctx.fused_fallbacks() == before  # the guard counter is for guard trips only
+
+
+@pytest.mark.parametrize("inner", [1, 2, 5])
+def test_launch_order_is_a_permutation_of_the_plan(ctx, inner):
+    """Round 6: every XCD takes a contiguous run of the plan's blocks AND its share of the side blocks (first / last block column) of a
+    border-aware plan, so that the eight XCDs carry equal work.  Whatever the geometry, the launch order must name every block of
+    the plan exactly once, the strips of a block column must tile the level's rows, and the side blocks must be spread over the runs."""
+    valid = 64 - 2 * (inner + 1)
+    for w, h, inst in [(4096, 4096, 1), (2048, 2048, 1), (1024, 1024, 1), (1920, 1080, 8), (584, 388, 32), (8192, 8192, 1), (640, 520, 1),
+                       (300, 200, 1), (4096, 2048, 2), (700, 4000, 1), (5000, 333, 3), (97, 61, 1), (2049, 1023, 1)]:
+        order = ctx.fused_block_order(w, h, inner, inst)
+        assert len(order) % 8 == 0
+        live = order[order[:, 0] >= 0]
+        blocks = set(map(tuple, live[:, :2].tolist()))
+        assert len(blocks) == len(live), (w, h, inst, "a block named twice")
+        blocks_x = (-(-w // valid) + 3) // 4
+        assert {bx for bx, _ in blocks} == set(range(blocks_x)), (w, h, inst)
+        for bx in range(blocks_x):
+            rows = sorted((y0, y1) for cx, _, y0, y1 in live.tolist() if cx == bx and y1 > y0)
+            assert rows[0][0] == 0 and rows[-1][1] == h, (w, h, inst, bx, rows[:2], rows[-2:])
+            assert all(a[1] == b[0] for a, b in zip(rows, rows[1:])), (w, h, inst, bx)
+        # the runs of the eight XCDs (launch ids k, k + 8, ...) carry the side blocks evenly (the 4096^2 plan: 62 of them, 7 or 8 per run)
+        if (w, h, inst, inner) == (4096, 4096, 1, 5):
+            side = [int(((order[k::8, 0] == 0) | (order[k::8, 0] == blocks_x - 1)).sum()) for k in range(8)]
+            assert sum(side) == 62 and max(side) - min(side) <= 1, side

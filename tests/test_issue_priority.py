@@ -92,18 +92,26 @@ def test_the_library_in_the_tree_is_built_that_way(flow2d, tmp_path):
     work = tmp_path / "lib.so"
     os.symlink(lib, work)
     subprocess.run([OBJDUMP, "--offloading", str(work)], cwd=tmp_path, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=True)
-    checked = 0
+    pipeline = lone = 0
     for name in sorted(os.listdir(tmp_path)):
         if "gfx950" not in name:
             continue
         dis = subprocess.run([OBJDUMP, "-d", str(tmp_path / name)], stdout=subprocess.PIPE, text=True, check=True).stdout
-        for kernel in re.split(r"\n(?=[0-9a-f]+ <)", dis):
-            head = kernel.split("\n", 1)[0]
-            m = re.search(r"fused_outer_kernelILi\d+ELi([0-3])E", head)
-            if not m:
-                continue
-            checked += 1
-            assert "s_setprio 3" in kernel and "s_setprio 0" in kernel, head
-            if m.group(1) != "3":  # the log-derivative term keeps the packed forms (csrc/Makefile)
-                assert "v_pk_" not in kernel, head
-    assert checked >= 60  # 80 instantiations of the strip kernel (developer builds hold fewer and are not what ships)
+        kernels = [(k.split("\n", 1)[0], k) for k in re.split(r"\n(?=[0-9a-f]+ <)", dis) if re.search(r"fused_outer_kernelILi\d+ELi[0-3]E", k.split("\n", 1)[0])]
+        if not kernels:
+            continue
+        # a code object holds one build of the kernel: the pipeline's (priority filter, no packed fp32 arithmetic outside the
+        # log-derivative term) or the one for under-filled launches of a lone context (packed arithmetic, no filter: csrc/Makefile)
+        filtered = ["s_setprio 3" in k for _, k in kernels]
+        assert all(filtered) or not any(filtered), name
+        for head, kernel in kernels:
+            grad = re.search(r"fused_outer_kernelILi\d+ELi([0-3])E", head).group(1)
+            if filtered[0]:
+                pipeline += 1
+                assert "s_setprio 0" in kernel, head
+                if grad != "3":
+                    assert "v_pk_" not in kernel, head
+            else:
+                lone += 1
+                assert grad != "3" and "v_pk_" in kernel and "s_setprio" not in kernel, head
+    assert pipeline >= 60 and lone >= 40  # 80 + 60 instantiations (developer builds hold fewer and are not what ships)

@@ -119,6 +119,28 @@ def report(st, label):
           dict(collections.Counter(tuple(sorted(v)) for v in slots.values()).most_common(6)))
     cus = collections.Counter((key // 4).tolist())
     print("  CUs used %d; waves per CU: %s" % (len(cus), dict(collections.Counter(cus.values()))))
+    # The launch lasts as long as its last wave.  How far is that from the mean, and where does the spread come from: the XCDs' clocks
+    # (cycles per wave are the work, cycles / lifetime the clock the wave saw), the SIMD a wave shared, its age on that SIMD?
+    clock = cyc / (life * 1e3)
+    end = (t1 - base) / 1e3
+    print("  launch span %.1f = mean wave end %.1f + %.1f (%.1f %%);  per XCC: clock GHz / median cycles per wave (10^3) / median end / last end:" %
+          (span, end.mean(), span - end.mean(), 100 * (span - end.mean()) / span))
+    print("    " + "  ".join("%d: %.3f / %.0f / %.1f / %.1f" % (x, pct(clock[xcc == x], 50), pct(cyc[xcc == x], 50) / 1e3, pct(end[xcc == x], 50),
+                                                              end[xcc == x].max()) for x in sorted(set(xcc.tolist()))))
+    simd_end = collections.defaultdict(float)
+    simd_cyc = collections.defaultdict(float)
+    for k, e, c in zip(key.tolist(), end.tolist(), cyc.tolist()):
+        simd_end[k] = max(simd_end[k], e)
+        simd_cyc[k] += c
+    se = np.array(list(simd_end.values()))
+    print("  SIMD done (its last wave's end) us: p10 %.1f  median %.1f  p90 %.1f  max %.1f;  ends of the older / younger wave of a SIMD, median: %s" %
+          (pct(se, 10), pct(se, 50), pct(se, 90), se.max(),
+           " / ".join("%.1f" % pct(end[(hw & 15) == k], 50) for k in sorted(set((hw & 15).tolist())))))
+    cu_end = collections.defaultdict(float)
+    for k, e in zip((key // 4).tolist(), end.tolist()):
+        cu_end[k] = max(cu_end[k], e)
+    ce = np.array(list(cu_end.values()))
+    print("  CU done us: p10 %.1f  median %.1f  p90 %.1f  max %.1f" % (pct(ce, 10), pct(ce, 50), pct(ce, 90), ce.max()))
 
 
 def main():
@@ -150,6 +172,12 @@ def main():
         fetch(lib)
         with_stalls = os.environ.get("FLOW2D_STALLS", "1") != "0"
         e0, e1 = ctx.event(), ctx.event()
+        # FLOW2D_STAMPS_SUSTAIN=n: n level solves of ten launches queued back to back before the stamped one -- the clock a launch
+        # holds under SUSTAINED load (the ring keeps the last 32 launches; the trend over them is printed)
+        sustain = int(os.environ.get("FLOW2D_STAMPS_SUSTAIN", "0"))
+        for rep in range(sustain):
+            ctx.solve_level(*planes, du, dv, phi, ksi, tdu, tdv, w, h, 1.0, 1.0, 35.0, 0.001, 0.001, 10, 5, constancy,
+                            F.SOLVER_FUSED, container_height=h)
         ctx.record(e0)
         ctx.solve_level(*planes, du, dv, phi, ksi, tdu, tdv, w, h, 1.0, 1.0, 35.0, 0.001, 0.001, 4, 5, constancy,
                         F.SOLVER_FUSED, container_height=h)
@@ -166,6 +194,15 @@ def main():
         launch_index = np.split(index, gaps + 1)
         print("== %dx%d x%d %s: 4 outer iterations %.1f us (%.1f per launch by events); %d launches found" %
               (w, h, inst, mode, ms * 1e3, ms * 1e3 / 4, len(launches)))
+        if sustain:
+            print("  per launch (oldest first): span us / median clock GHz / median cycles per interior wave (10^3):")
+            rows = []
+            for l in launches:
+                lt0, lt1 = l[:, 0].astype(np.int64) * 10, l[:, 1].astype(np.int64) * 10
+                life = (lt1 - lt0) / 1e3
+                inner = ((l[:, 6].astype(np.int64) >> 8) & 1) == 0
+                rows.append("%.1f/%.3f/%.0f" % ((lt1.max() - lt0.min()) / 1e3, pct(l[:, 2] / (life * 1e3), 50), pct(l[inner, 2], 50) / 1e3))
+            print("   " + "  ".join(rows))
         out = os.environ.get("FLOW2D_STAMPS_OUT")
         if out:  # raw stamps of the last launch, for offline analysis
             np.save("%s_%dx%dx%d_%s.npy" % (out, w, h, inst, mode), launches[-1])

@@ -9,7 +9,10 @@ trial and the program re-verified.  Verification is exhaustive over the 0-1 inpu
 cases, evaluated bit-parallel: min = AND, max = OR on packed bits): by the 0-1 principle for selection (thresholding commutes
 with min / max and keeps sorted groups sorted) that proves the program for all inputs.  A random-float check runs on top.
 
-usage: python tools/gen_median7_network.py        (a few minutes)
+Round 6: the comparator program is then lowered to one-result instructions (v_min / v_max / v_min3 / v_max3 / v_med3) and shortened by
+tools/median_select3.py under the same exhaustive check, like the window-5 program.
+
+usage: python tools/gen_median7_network.py        (about half an hour; MEDIAN7_STEPS=n bounds the shortening walk)
 """
 import os
 import random
@@ -129,7 +132,26 @@ def run(prog, v):
     return v
 
 
+SORT7 = [(0, 6), (2, 3), (4, 5), (0, 2), (1, 4), (3, 6), (0, 1), (2, 5), (3, 4), (1, 2), (4, 6), (2, 3), (4, 5), (1, 2), (3, 4), (5, 6)]
+
+
+def case_vectors():
+    """all 0-1 inputs with sorted groups as uint64 words, in a fixed random order (a prefix of the bits is a fair sample)"""
+    n = (R + 1) ** GROUPS
+    c = np.random.default_rng(1).permutation(n).astype(np.int64)
+    zeros = [(c // (R + 1) ** g) % (R + 1) for g in range(GROUPS)]
+    pack = lambda b: np.packbits(b, bitorder="little").view(np.uint64)  # (n is a multiple of 64)
+    inv = [pack(j >= zeros[g]) for g in range(GROUPS) for j in range(R)]
+    want = [pack(sum(zeros[0:R]) <= MEDIAN), pack(sum(zeros[1:R + 1]) <= MEDIAN)]
+    return inv, want
+
+
 def main():
+    import sys
+
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import median_select3 as S
+
     prog, wa, wb = build()
     tests = inputs01()
     assert ok(prog, wa, wb, tests)
@@ -145,27 +167,40 @@ def main():
         i -= 1
     prog = prune_dead(prog, [wa, wb])
     assert ok(prog, wa, wb, tests)
+    n = sum(1 for o in prog if o[0] == "x")
+    print("%d comparators for two medians (merge tree before pruning: %d)" % (n, full), flush=True)
+    del tests
+    # comparators -> one-result instructions (min / max / min3 / max3 / med3), shortened (tools/median_select3.py; candidates from a
+    # node's fan-in cone of depth 4: the program is four times the window-5 one and its value vectors are 2 MB each)
+    inv, want = case_vectors()
+    steps = int(os.environ.get("MEDIAN7_STEPS", "12000"))
+    ops, outs = S.lower(prog, WIRES, COPY_BASE, inv, [wa, wb], want, steps=steps, seed=7, cone_depth=4, log=lambda m: print(m, flush=True))
+    sort_ops, sort_outs = S.sorter(SORT7, R, steps=4000, seed=1, log=lambda m: print("sort7:", m, flush=True))
     rng = random.Random(7)
     for _ in range(5000):
         groups = [sorted(rng.choice([rng.random(), float(rng.randint(0, 3))]) for _ in range(R)) for _ in range(GROUPS)]
-        v = [x for grp in groups for x in grp] + [0.0] * SHARED
-        r = run(prog, v)
-        assert r[wa] == sorted(v[0:R * R])[MEDIAN] and r[wb] == sorted(v[R:R * R + R])[MEDIAN]
-    n = sum(1 for o in prog if o[0] == "x")
-    print("%d comparators for two medians (merge tree before pruning: %d)" % (n, full))
-    body = ", ".join("{%d, %d, %d}" % (1 if k == "c" else 0, a, b) for k, a, b in prog)
+        v = [x for grp in groups for x in grp]
+        r = S.evaluate(ops, COPY_BASE, v)
+        assert r[outs[0]] == sorted(v[0:R * R])[MEDIAN] and r[outs[1]] == sorted(v[R:R * R + R])[MEDIAN]
+        t = [rng.choice([rng.random(), float(rng.randint(0, 2))]) for _ in range(R)]
+        r = S.evaluate(sort_ops, R, t)
+        assert [r[o] for o in sort_outs] == sorted(t)
     out = [
-        "// Generated by tools/gen_median7_network.py -- do not edit.",
-        "// Program on %d wires: wires 7g..7g+6 = ascending 7-tuple of row g (g = 0..7), wires %d.. = scratch." % (WIRES, COPY_BASE),
-        "// {0, a, b}: (wire a, wire b) <- (min, max);  {1, a, b}: wire b <- wire a.",
-        "// Afterwards wire kMedian7PairOutA holds the median of rows 0..6, wire kMedian7PairOutB that of rows 1..7.",
-        "constexpr int kMedian7PairWires = %d;" % WIRES,
-        "constexpr int kMedian7PairOps = %d;  // %d comparators" % (len(prog), n),
-        "constexpr int kMedian7PairOutA = %d, kMedian7PairOutB = %d;" % (wa, wb),
-        "constexpr MedianPairOp kMedian7PairProgram[kMedian7PairOps] = {%s};" % body,
+        "// Generated by tools/gen_median7_network.py (comparator networks lowered by tools/median_select3.py) -- do not edit.",
+        "// One-result selection programs, {kind, a, b, c} as in median5_pair_network.inc.  Pair program: inputs 7g..7g+6 = ascending",
+        "// 7-tuple of row g (g = 0..7); node kMedian7PairOutA = median of rows 0..6, node kMedian7PairOutB = median of rows 1..7.",
+        "// %d instructions (%s) for the %d comparators of the merge network; verified over the 8^8 sorted 0-1 inputs." % (len(ops), S.histogram(ops), n),
+        "constexpr int kMedian7PairInputs = %d;" % COPY_BASE,
+        "constexpr int kMedian7PairOps = %d;" % len(ops),
+        "constexpr int kMedian7PairOutA = %d, kMedian7PairOutB = %d;" % (outs[0], outs[1]),
+        "constexpr SelectOp kMedian7PairProgram[kMedian7PairOps] = {%s};" % S.emit(ops, ""),
+        "// Sorter of a row's seven values (x-3 .. x+3): %d instructions (%s) for a 16-comparator network; node kSort7Out[k] = k-th smallest." % (len(sort_ops), S.histogram(sort_ops)),
+        "constexpr int kSort7Ops = %d;" % len(sort_ops),
+        "constexpr int kSort7Out[7] = {%s};" % ", ".join(str(o) for o in sort_outs),
+        "constexpr SelectOp kSort7Program[kSort7Ops] = {%s};" % S.emit(sort_ops, ""),
     ]
-    dst = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "cuda-flow2d_amd", "csrc",
-                       "median7_pair_network.inc")
+    dst = os.environ.get("MEDIAN7_OUT") or os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "cuda-flow2d_amd", "csrc",
+                                                        "median7_pair_network.inc")
     open(dst, "w").write("\n".join(out) + "\n")
 
 

@@ -10,7 +10,11 @@ inputs with sorted groups (6^6 = 46656): by the 0-1 principle for selection (thr
 min/max and keeps sorted groups sorted) that proves the program for all inputs.  A random-float check runs
 on top before the file is written.
 
-usage: python tools/gen_median_network.py        (takes about half a minute)
+Round 6: the comparator program is then lowered to one-result instructions -- v_min / v_max and the three-input v_min3 / v_max3 /
+v_med3 -- and shortened by tools/median_select3.py (semantic rewrites verified on the same exhaustive case set): 81 comparators =
+123 live two-input instructions -> 78, and the five-value sorter of a row 18 -> 13.
+
+usage: python tools/gen_median_network.py        (takes a few minutes)
 """
 import itertools
 import os
@@ -111,7 +115,28 @@ def prune_dead(prog, outs):
     return keep[::-1]
 
 
+SORT5 = [(0, 1), (3, 4), (2, 4), (2, 3), (0, 3), (0, 2), (1, 4), (1, 3), (1, 2)]  # 9 comparators
+
+
+def case_vectors():
+    """all 0-1 inputs with sorted groups, in a fixed random order (a prefix of the bits is a fair sample: median_select3's filter)"""
+    import numpy as np
+
+    import median_select3 as S
+
+    cases = np.array(list(itertools.product(range(R + 1), repeat=6)))
+    cases = cases[np.random.default_rng(1).permutation(len(cases))]
+    inv = [S.pack_cases(i >= R - cases[:, g]) for g in range(6) for i in range(R)]
+    want = [S.pack_cases(25 - cases[:, 0:5].sum(axis=1) <= 12), S.pack_cases(25 - cases[:, 1:6].sum(axis=1) <= 12)]
+    return inv, want
+
+
 def main():
+    import sys
+
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import median_select3 as S
+
     prog, wa, wb = build()
     tests = tests01()
     assert ok(prog, wa, wb, tests)
@@ -126,24 +151,35 @@ def main():
         i -= 1
     prog = prune_dead(prog, [wa, wb])
     assert ok(prog, wa, wb, tests)
+    n = sum(1 for o in prog if o[0] == "x")
+    print("%d comparators for two medians (merge tree before pruning: %d)" % (n, full), flush=True)
+    # comparators -> one-result instructions (min / max / min3 / max3 / med3), shortened (tools/median_select3.py)
+    inv, want = case_vectors()
+    ops, outs = S.lower(prog, COPY_BASE + 20, 6 * R, inv, [wa, wb], want, steps=9000, seed=15, log=lambda m: print(m, flush=True))
+    sort_ops, sort_outs = S.sorter(SORT5, R, steps=3000, seed=1, log=lambda m: print("sort5:", m, flush=True))
     rng = random.Random(5)
     for _ in range(20000):
         groups = [sorted(rng.choice([rng.random(), float(rng.randint(0, 3))]) for _ in range(R)) for _ in range(6)]
-        v = [x for grp in groups for x in grp] + [0.0] * 20
-        r = run(prog, v)
-        assert r[wa] == sorted(v[0:25])[12] and r[wb] == sorted(v[5:30])[12]
-    n = sum(1 for o in prog if o[0] == "x")
-    print("%d comparators for two medians (merge tree before pruning: %d)" % (n, full))
-    body = ", ".join("{%d, %d, %d}" % (1 if k == "c" else 0, a, b) for k, a, b in prog)
+        v = [x for grp in groups for x in grp]
+        r = S.evaluate(ops, 6 * R, v)
+        assert r[outs[0]] == sorted(v[0:25])[12] and r[outs[1]] == sorted(v[5:30])[12]
+        t = [rng.choice([rng.random(), float(rng.randint(0, 2))]) for _ in range(R)]
+        r = S.evaluate(sort_ops, R, t)
+        assert [r[o] for o in sort_outs] == sorted(t)
     out = [
-        "// Generated by tools/gen_median_network.py -- do not edit.",
-        "// Program on %d wires: wires 5g..5g+4 = ascending 5-tuple of row g (g = 0..5), wires %d.. = scratch." % (COPY_BASE + 20, COPY_BASE),
-        "// {0, a, b}: (wire a, wire b) <- (min, max);  {1, a, b}: wire b <- wire a.",
-        "// Afterwards wire kMedianPairOutA holds the median of rows 0..4, wire kMedianPairOutB that of rows 1..5.",
-        "constexpr int kMedianPairWires = %d;" % (COPY_BASE + 20),
-        "constexpr int kMedianPairOps = %d;  // %d comparators" % (len(prog), n),
-        "constexpr int kMedianPairOutA = %d, kMedianPairOutB = %d;" % (wa, wb),
-        "constexpr MedianPairOp kMedianPairProgram[kMedianPairOps] = {%s};" % body,
+        "// Generated by tools/gen_median_network.py (comparator networks lowered by tools/median_select3.py) -- do not edit.",
+        "// One-result selection programs: {kind, a, b, c} defines node (inputs + index) = kind(node a, node b, node c);",
+        "// kind 0 min, 1 max (two inputs), 2 min3, 3 max3, 4 med3.  Verified over all 0-1 inputs with sorted groups.",
+        "// Pair program: inputs 5g..5g+4 = ascending 5-tuple of row g (g = 0..5); node kMedianPairOutA = median of rows 0..4,",
+        "// node kMedianPairOutB = median of rows 1..5.  %d instructions (%s) for the %d comparators of the merge network." % (len(ops), S.histogram(ops), n),
+        "constexpr int kMedianPairInputs = %d;" % (6 * R),
+        "constexpr int kMedianPairOps = %d;" % len(ops),
+        "constexpr int kMedianPairOutA = %d, kMedianPairOutB = %d;" % (outs[0], outs[1]),
+        "constexpr SelectOp kMedianPairProgram[kMedianPairOps] = {%s};" % S.emit(ops, ""),
+        "// Sorter of a row's five values (x-2 .. x+2): %d instructions (%s) for a 9-comparator network; node kSort5Out[k] = k-th smallest." % (len(sort_ops), S.histogram(sort_ops)),
+        "constexpr int kSort5Ops = %d;" % len(sort_ops),
+        "constexpr int kSort5Out[5] = {%s};" % ", ".join(str(o) for o in sort_outs),
+        "constexpr SelectOp kSort5Program[kSort5Ops] = {%s};" % S.emit(sort_ops, ""),
     ]
     dst = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "cuda-flow2d_amd", "csrc",
                        "median5_pair_network.inc")

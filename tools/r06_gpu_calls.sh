@@ -46,4 +46,105 @@ call1() {  # the probes of VERDICT r05 items 1 and 2: stall histogram, compute-o
     grep -c . "$OUT/call1_counters_available.txt"
 }
 
+# one rocprofv3 --pmc pass (counters in their own run, kernel trace only) over tools/pmc_workload.py; prints the strip kernel's rows
+pmc_pass() {
+    local name=$1; shift
+    rm -rf "$OUT/pmc_$name"
+    (cd /tmp && timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv --pmc "$@" -d "$OUT/pmc_$name" -- python3 "$R/tools/pmc_workload.py" 4096 \
+        > "$OUT/pmc_$name.log" 2>&1) || { echo "pass $name ($*): failed"; tail -3 "$OUT/pmc_$name.log"; rm -rf "$OUT/pmc_$name"; return 0; }
+    cp "$OUT"/pmc_$name/*/*counter_collection.csv "$OUT/pmc_$name.csv" 2>/dev/null
+    rm -rf "$OUT/pmc_$name"
+    python3 - "$OUT/pmc_$name.csv" <<'PY'
+import csv, sys, collections
+d = collections.defaultdict(lambda: collections.defaultdict(list))
+for r in csv.DictReader(open(sys.argv[1])):
+    if "fused_outer" not in r["Kernel_Name"]: continue
+    key = r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0]
+    d[key][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    d[key]["_us"].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+for k, cs in sorted(d.items()):
+    print(k)
+    for c, v in sorted(cs.items()):
+        print("   %-40s steady launches (mean of the last %d) %.6g" % (c, len(v) - 1, sum(v[1:]) / max(1, len(v) - 1)))
+PY
+}
+
+call2() {  # wave stamps without the stall timing (full / compute-only / memory-only / no halo lanes / packed), raw stamps kept; vector-memory counters
+    for v in stampsl stampsl_compute stampsl_memory stampsl_nohalo stampsl_packed; do
+        FLOW2D_STALLS=0 FLOW2D_STAMPS_OUT="$OUT/raw_$v" FLOW2D_HIP_LIB=$(lib $v) timeout -k 10 200 python3 tools/fused_wave_stamps.py 4096x4096 > "$OUT/call2_$v.txt" 2>&1 \
+            || { tail "$OUT/call2_$v.txt"; return 1; }
+        grep -E "^==|launch span|clock held|SIMD done" "$OUT/call2_$v.txt"
+    done
+    ab_level dev compute memory > "$OUT/call2_ab_level.txt" 2>&1 || { tail "$OUT/call2_ab_level.txt"; return 1; }
+    cat "$OUT/call2_ab_level.txt"
+    {
+        pmc_pass sq1 SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_VMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR
+        pmc_pass sq2 SQ_INST_CYCLES_VMEM_RD SQ_INST_CYCLES_VMEM_WR SQ_INST_LEVEL_VMEM SQ_ACTIVE_INST_SCA SQ_INSTS_SALU SQ_INSTS_VALU SQ_WAVES SQ_ACTIVE_INST_ANY
+        pmc_pass ta TA_BUSY_avr TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_DATA_STALLED_BY_TC_CYCLES_sum TA_TOTAL_WAVEFRONTS_sum
+        pmc_pass tcp1 TCP_PENDING_STALL_CYCLES_sum TCP_TCC_READ_REQ_LATENCY_sum TCP_TCC_READ_REQ_sum TCP_TCP_TA_DATA_STALL_CYCLES_sum
+        pmc_pass tcp2 TCP_TCC_WRITE_REQ_LATENCY_sum TCP_TCC_WRITE_REQ_sum TCP_RFIFO_STALL_CYCLES_sum TCP_LFIFO_STALL_CYCLES_sum
+        pmc_pass tcp3 TCP_UTCL1_TRANSLATION_MISS_sum TCP_UTCL1_TRANSLATION_HIT_sum TCP_UTCL1_REQUEST_sum TCP_TCR_TCP_STALL_CYCLES_sum
+        pmc_pass tcc1 TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_LEVEL_sum
+        pmc_pass tcc2 TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_STALL_sum TCC_EA0_RDREQ_DRAM_CREDIT_STALL_sum TCC_TAG_STALL_sum
+        pmc_pass tcc3 TCC_BUSY_avr TCC_CYCLE_sum TCC_EA0_WRREQ_LEVEL_sum TCC_REQ_sum
+    } > "$OUT/call2_pmc.txt" 2>&1
+    cat "$OUT/call2_pmc.txt"
+}
+
+call3() {  # is the "memory cost" a clock effect?  full / compute-only / memory-only strips under SUSTAINED load: clock held and cycles per wave
+    for v in stampsl stampsl_compute stampsl_memory; do
+        FLOW2D_STALLS=0 FLOW2D_STAMPS_SUSTAIN=6 FLOW2D_HIP_LIB=$(lib $v) timeout -k 10 200 python3 tools/fused_wave_stamps.py 4096x4096 > "$OUT/call3_$v.txt" 2>&1 \
+            || { tail "$OUT/call3_$v.txt"; return 1; }
+        grep -E "^==|per launch|^   [0-9]" "$OUT/call3_$v.txt"
+    done
+}
+
+call4() {  # equal work per XCD (side blocks dealt over the runs): old order (dev, stampsl) against new (dev2, stampsl2)
+    timeout -k 10 600 python3 -m pytest tests/test_gpu_fused.py -x -q > "$OUT/call4_fused_tests.log" 2>&1 || { tail -20 "$OUT/call4_fused_tests.log"; return 1; }
+    tail -1 "$OUT/call4_fused_tests.log"
+    ab_level dev dev2 > "$OUT/call4_ab_level.txt" 2>&1 || { tail "$OUT/call4_ab_level.txt"; return 1; }
+    cat "$OUT/call4_ab_level.txt"
+    for v in stampsl stampsl2; do
+        FLOW2D_STALLS=0 FLOW2D_HIP_LIB=$(lib $v) timeout -k 10 200 python3 tools/fused_wave_stamps.py 4096x4096 > "$OUT/call4_$v.txt" 2>&1 || { tail "$OUT/call4_$v.txt"; return 1; }
+        grep -E "^==|launch span .* =|    0: |SIMD done" "$OUT/call4_$v.txt"
+    done
+}
+
+call5() {  # call4 again + the medians with three-input selection (product) against round 5's comparator programs (ab/median_old.so)
+    call4 || return 1
+    timeout -k 10 600 python3 -m pytest tests/test_gpu_kernels.py tests/test_gpu_reference.py -x -q -k "median" > "$OUT/call5_median_tests.log" 2>&1 || { tail -20 "$OUT/call5_median_tests.log"; return 1; }
+    tail -1 "$OUT/call5_median_tests.log"
+    for rep in 1 2; do
+        for so in ab/median_old.so cuda-flow2d_amd/csrc/libflow2d_hip.so; do
+            echo "== $so"
+            FLOW2D_HIP_LIB="$R/$so" timeout -k 10 120 python3 tools/time_ops.py 4096 2>&1 | grep -i "median" || return 1
+        done
+    done > "$OUT/call5_median_ab.txt" 2>&1
+    cat "$OUT/call5_median_ab.txt"
+}
+
+call6() {  # the forked frame pyramid + packed build for lone contexts: flow tests, then the lone pair's latency on every workload
+    timeout -k 10 900 python3 -m pytest tests/test_gpu_flow.py tests/test_gpu_fused.py -x -q > "$OUT/call6_flow_tests.log" 2>&1 || { tail -30 "$OUT/call6_flow_tests.log"; return 1; }
+    tail -1 "$OUT/call6_flow_tests.log"
+    for wl in cfg3_4096_gradient cfg2_1024_grey cfg1_rub cfg4_1080p_batch; do
+        timeout -k 10 300 python3 bench.py --workload $wl --no-pmc --no-oracle-check --no-host-entry-leg --no-cpu-baseline --no-reference-baseline --no-batch-leg 2>"$OUT/call6_$wl.err" |
+            python3 -c "
+import json,sys
+d=json.loads(sys.stdin.read())
+print('%-22s pairs/s %8.1f  ms/step %7.3f  launch_ms %s  lone pair ms %s  (one stream, pipeline kernels: %s)' % ('$wl', d['pairs_per_s'], d['ms_per_step'], d['roofline'].get('avg_launch_ms'), d.get('single_pair_latency_ms'), d.get('single_pair_latency_single_stream_ms')))" || { tail -5 "$OUT/call6_$wl.err"; return 1; }
+    done
+}
+
+call7() {  # timeline of a lone config-3 pair, forked (lone 1) and on one stream (lone 0): where does the fork lose what it should gain?
+    for lone in 1 0; do
+        rm -rf "$OUT/lone_trace_$lone"
+        (cd /tmp && timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d "$OUT/lone_trace_$lone" -- python3 "$R/tools/lone_pair_trace.py" cfg3_4096_gradient $lone 4 \
+            > "$OUT/call7_lone$lone.log" 2>&1) || { tail -5 "$OUT/call7_lone$lone.log"; return 1; }
+        grep "pair:" "$OUT/call7_lone$lone.log"
+        python3 tools/lone_pair_timeline.py "$OUT"/lone_trace_$lone/*/*kernel_trace.csv 400 > "$OUT/call7_timeline_lone$lone.txt"
+        rm -rf "$OUT/lone_trace_$lone"
+        head -3 "$OUT/call7_timeline_lone$lone.txt"
+    done
+}
+
 "$@"
