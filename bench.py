@@ -43,6 +43,7 @@ import hashlib
 import importlib
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -668,6 +669,44 @@ def output_check(job):
     }
 
 
+def pcie_ceiling(flow2d, local_rank, w=4096, h=4096, copies=16):
+    """The box's own page-locked copy rates through the C-ABI, GB/s per direction: upload alone, download alone, both at once on
+    two streams (what the host-entry leg's pcie_gbs_each_way is a fraction of).  None when page-locked memory is refused."""
+    L = flow2d.hip_lib()
+    up, down = flow2d.Context(local_rank), flow2d.Context(local_rank)
+    imgs = []
+    try:
+        imgs = [flow2d.HostImage(w, h, True) for _ in range(4)]
+        planes = [up.plane(w, h) for _ in range(4)]
+        nbytes = w * h * 4
+
+        def h2d(n):
+            for k in range(n):
+                L.flow2d_copy_h2d_2d(up.handle, planes[k % 2].ptr, planes[0].pitch, imgs[k % 2].array.ctypes.data, w * 4, w * 4, h)
+
+        def d2h(n):
+            for k in range(n):
+                L.flow2d_copy_d2h_2d(down.handle, imgs[2 + k % 2].array.ctypes.data, w * 4, planes[2 + k % 2].ptr, planes[0].pitch, w * 4, h)
+
+        out = {}
+        for name, fn in (("upload_alone", lambda: h2d(copies)), ("download_alone", lambda: d2h(copies)),
+                         ("both_at_once_each_way", lambda: (h2d(copies), d2h(copies)))):
+            fn()
+            up.synchronize(), down.synchronize()
+            t0 = time.perf_counter()
+            fn()
+            up.synchronize(), down.synchronize()
+            out[name] = round(copies * nbytes / (time.perf_counter() - t0) / 1e9, 1)
+        return out
+    except Exception as e:  # noqa: BLE001 - an informational leg
+        print("bench: pcie ceiling: %r" % (e,), file=sys.stderr)
+        return None
+    finally:
+        for q in imgs:
+            q.close()
+        up.close(), down.close()
+
+
 def host_entry_leg(job, batch, torch, steps):
     """SURVEY 8(d) metric 2 in the reference's own bracket (optical_flow_2d.cpp:173-179,214-215,544-554): host images in,
     host flows out, uploads and downloads INSIDE the timed region.  OpticalFlowBatch2D::ComputeFlowBatch queues upload,
@@ -732,6 +771,8 @@ def host_entry_leg(job, batch, torch, steps):
             "host_memory": "page-locked Data2D" if pinned else "pageable Data2D (pinned allocation failed)",
             "pcie_bytes_per_pair": bytes_per_pair,
             "pcie_gbs_each_way": round(pairs / job.world * bytes_per_pair / 2 / elapsed / 1e9, 2),
+            # ... against what this box's page-locked copies reach with nothing else running (tools/pcie_pinned.py's measurement)
+            "pcie_ceiling_gbs": pcie_ceiling(job.flow2d, job.local_rank) if job.rank == 0 else None,
             "flows_bit_identical_to_device_resident_run": bool(same),
         }
     finally:
@@ -763,6 +804,25 @@ def oracle_check(job):
             "_timing": (seconds, t_finest)}
 
 
+def probe_builds(args, cfg):
+    """Level-solve time / 10 of the strip kernel's timing probes (developer libraries ab/memory.so, ab/compute.so: wrong results by
+    design, never loaded into this process) at the workload's finest level, each in a child process of its own."""
+    out = {}
+    root = os.path.dirname(os.path.abspath(__file__))
+    for key, lib in (("memory_only_us", "memory"), ("compute_only_us", "compute")):
+        path = os.path.join(root, "ab", lib + ".so")
+        if not os.path.exists(path):
+            continue
+        try:
+            r = subprocess.run([sys.executable, os.path.join(root, "tools", "time_sweep.py"), str(cfg["w"]), str(cfg["h"]), "2", str(min(cfg["inner"], 5))],
+                               env=dict(os.environ, FLOW2D_HIP_LIB=path), capture_output=True, text=True, timeout=120)
+            lines = [l for l in r.stdout.splitlines() if l.startswith("constancy %d " % (1 if cfg["constancy"] == 1 else 0))]
+            out[key] = round(float(lines[-1].split("level solve")[1].split("ms")[0]) * 100.0, 1)  # ms per 10 launches -> us per launch
+        except Exception as e:  # noqa: BLE001 - an informational leg
+            print("bench: timing probe %s: %r" % (lib, e), file=sys.stderr)
+    return out
+
+
 def roofline_sample(job, passes=3):
     """Eager passes of the first pair on a stream of its own, alone on the GPU, with HIP events on that stream around
     every level's solve and every finest-level solver launch (flow2d_timing_enable mode 2)."""
@@ -783,29 +843,64 @@ def roofline_sample(job, passes=3):
         for _ in range(passes):
             flow.compute_flow_device(f0.ptr, f1.ptr, u.ptr, v.ptr, job.params, 2)
         c.synchronize()
+        # The clock the chip HOLDS under the finest level's solver launches: three level solves of the workload's counts back to
+        # back on this stream, bracketed by one sleeping wave per XCD on a context of its own (flow2d_clock_probe_start).
+        probe = flow2d.Context(job.local_rank)
+        try:
+            scratch = [c.plane(w, h).fill_bytes(0) for _ in range(6)]
+
+            def level_solve():
+                c.solve_level(f0, f1, u, v, *scratch, w, h, 1.0, 1.0, cfg["alpha"], 0.001, 0.001, cfg["outer"], cfg["inner"],
+                              cfg["constancy"], flow2d.SOLVER_AUTO, sor_omega=cfg.get("sor_omega", 0.0))
+
+            u.fill_bytes(0), v.fill_bytes(0)
+            level_solve()
+            e0, e1 = c.event(), c.event()
+            c.record(e0)
+            level_solve()
+            c.record(e1)
+            solve_ms = c.elapsed_ms(e0, e1)
+            probe.clock_probe_start(max(100.0, 0.85 * 3 * solve_ms * 1e3))
+            for _ in range(3):
+                level_solve()
+            c.synchronize()
+            job.sample_clock_ghz = [round(g, 4) for g in probe.clock_probe_read()]
+        except Exception as e:  # noqa: BLE001 - an informational leg
+            print("bench: clock probe: %r" % (e,), file=sys.stderr)
+        finally:
+            probe.close()
         finest = [r for r in flow.level_timings() if (r[0], r[1]) == (w, h)]
         # one pair alone on the GPU, launch to done, replayed from its graph (no timing events inside): the latency
         # a single pair sees, as opposed to the pipelined rate of the timed region
-        def replayed_latency(obj):
-            obj.use_graph(True)
-            best = None
-            for _ in range(4):  # the first call records
-                e0, e1 = c.event(), c.event()
-                c.record(e0)
-                obj.compute_flow_device(f0.ptr, f1.ptr, u.ptr, v.ptr, job.params, 0)
-                c.record(e1)
-                ms = c.elapsed_ms(e0, e1)
-                best = ms if best is None or ms < best else best
-            return best
+        def replayed_ms(obj, cx=None):
+            cx = cx or c
+            e0, e1 = cx.event(), cx.event()
+            cx.record(e0)
+            obj.compute_flow_device(f0.ptr, f1.ptr, u.ptr, v.ptr, job.params, 0)
+            cx.record(e1)
+            cx.synchronize()
+            return cx.elapsed_ms(e0, e1)
 
-        latency = replayed_latency(flow)
-        # the same pair through an object that behaves like a lane of a pipeline (OpticalFlow2D::lone = false: one stream, the
-        # pipeline's build of the strip kernel everywhere): what the second stream and the packed build buy a lone pair
-        plain = flow2d.OpticalFlow(w, h, cfg["constancy"], ctx=c, lone=False)
+        # ... and the same pair through an object that behaves like a lane of a pipeline (OpticalFlow2D::lone = false: the
+        # pipeline's build of the strip kernel everywhere) and through one with the opt-in second stream for the frame pyramid:
+        # what the packed build buys a lone pair, and what the second stream costs it.  The three take turns (the chip's clock ramps over tens of milliseconds: whoever is measured later would look better) and
+        # each reports the median of its replays after the recording one.
+        # (`lone` is a property of the CONTEXT -- flow2d_context_set_lone -- so each object gets a context of its own)
+        c_plain, c_forked = flow2d.Context(job.local_rank), flow2d.Context(job.local_rank)
+        plain = flow2d.OpticalFlow(w, h, cfg["constancy"], ctx=c_plain, lone=False)
+        forked = flow2d.OpticalFlow(w, h, cfg["constancy"], ctx=c_forked, lone=True, second_stream=True)
         try:
-            job.single_stream_latency_ms = replayed_latency(plain)
+            objs = ((flow, c), (plain, c_plain), (forked, c_forked))
+            for o, cx in objs:
+                o.use_graph(True)
+                replayed_ms(o, cx)  # these record
+            times = [[replayed_ms(o, cx) for o, cx in objs] for _ in range(7)]
+            latency, job.single_stream_latency_ms, job.second_stream_latency_ms = (float(np.median([t[k] for t in times])) for k in range(3))
         finally:
             plain.close()
+            forked.close()
+            c_plain.close()
+            c_forked.close()
         return finest, latency
     finally:
         flow.close()
@@ -1163,6 +1258,12 @@ def main():
         phys_gbs = phys / (kernel_ms * 1e-3) / 1e9 if phys else None
         valu_frac = valu * VALU_ISSUE_CYCLES / (SIMDS * CLOCK_HZ * kernel_ms * 1e-3) if valu else None
         temporal = algorithm_used in (2, 3, 4)  # several sweeps per trip through HBM: not bound by the per-sweep bytes
+        # the launch's distance to each bound.  Clock: per XCD, held during the sampled passes (above).
+        clocks = [g for g in getattr(sample, "sample_clock_ghz", []) if g > 0]
+        clock_ghz = float(np.mean(clocks)) if clocks else None
+        compulsory = float(w) * h * 4 * 8  # a fused pass reads f0, f1, u, v, du, dv and writes du, dv: eight planes once
+        hbm_floor_us = compulsory / (copy_gbs * 1e9) * 1e6 if copy_gbs else None
+        probes = probe_builds(args, cfg) if rank == 0 and algorithm_used == 2 else {}
         kernel_name = {1: "Jacobi sweep kernel (%s)" % {0: "solve_2d", 1: "solve_2d_grad", 3: "solve_2d_log"}.get(
                            cfg["constancy"], "gradient-untiled"),
                        2: ("fused outer-iteration strip kernel (phi/ksi + %d red-black SOR iterations per launch)" % min(cfg["inner"], 2))
@@ -1194,6 +1295,19 @@ def main():
             "valu_instr_per_launch": valu,
             "valu_issue_frac": round(valu_frac, 4) if valu_frac else None,  # of one wave64 instruction per 2 cycles per SIMD
             "valu_peak_instr_per_s": SIMDS * CLOCK_HZ / VALU_ISSUE_CYCLES,
+            # ... and at the clock the chip held while these launches ran (round 6): the shader clock is not 2.4 GHz under this
+            # kernel -- power management holds 1.6-2.1 GHz, per XCD 3-5 % apart -- so the nominal fraction mixes DVFS into issue efficiency
+            "shader_clock_ghz": round(clock_ghz, 3) if clock_ghz else None,
+            "shader_clock_ghz_per_xcd": getattr(sample, "sample_clock_ghz", None),
+            "valu_issue_frac_at_clock": round(valu * VALU_ISSUE_CYCLES / (SIMDS * clock_ghz * 1e9 * kernel_ms * 1e-3), 4) if valu and clock_ghz else None,
+            # the launch's floor on the memory side: the eight planes a fused pass must move once, at this box's plain streaming rate
+            "compulsory_bytes_per_launch": compulsory if temporal else None,
+            "hbm_floor_us": round(hbm_floor_us, 1) if hbm_floor_us and temporal else None,
+            # timing probes of the same kernel (developer builds under ab/, when present): its loads and stores without the arithmetic,
+            # its arithmetic on cache-resident rows -- each at the clock IT holds (memory-only ~2.35 GHz, compute-only 2.0-2.3, the
+            # whole kernel 1.6-2.1: the same cycle count per wave with and without the HBM traffic, profiles/r06_experiments)
+            "memory_only_us": probes.get("memory_only_us"),
+            "compute_only_us": probes.get("compute_only_us"),
             # SIMD cycles (at the nominal 2.4 GHz; the kernel holds 2.05-2.3) per wave64 VALU instruction of the launch: two
             # waves of this kernel's instruction mix on a SIMD get through one per about 4.3 cycles when both are busy
             # (per-wave stamps, profiles/r04_experiments/README.md sections 2-3) -- that, not one per 2 cycles, is its ceiling
@@ -1251,8 +1365,10 @@ def main():
             "host_entry": host_entry,
             "single_pair_latency_ms": round(pair_latency_ms, 3),  # one pair alone on the GPU, graph replay, launch to done
             "pairs_per_s_single": round(1e3 / pair_latency_ms, 3),  # = 1 / single_pair_latency: no second pair in flight
-            # the same lone pair on one stream with the pipeline's kernels (round 5's single pair; OpticalFlow2D::lone = false)
-            "single_pair_latency_single_stream_ms": round(getattr(sample, "single_stream_latency_ms", float("nan")), 3),
+            # the same lone pair with the pipeline's kernels (round 5's single pair; OpticalFlow2D::lone = false)
+            "single_pair_latency_pipeline_kernels_ms": round(getattr(sample, "single_stream_latency_ms", float("nan")), 3),
+            # ... and with the opt-in second stream for the frame pyramid (OpticalFlow2D::second_stream; off by default: it does not pay)
+            "single_pair_latency_second_stream_ms": round(getattr(sample, "second_stream_latency_ms", float("nan")), 3),
             "finest_level": {
                 "solve_ms": round(solve_ms, 4),
                 "mpix_iters_per_s": round(px_iters / (solve_ms * 1e-3) / 1e6, 1),

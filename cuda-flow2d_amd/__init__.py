@@ -534,7 +534,7 @@ def _fptr(a):
 class OpticalFlow:
     """OpticalFlow2D of the host layer (Initialize / ComputeFlow / ComputeFlowDevice / Destroy)."""
 
-    def __init__(self, width, height, constancy=GREY, device=0, ctx=None, silent=True, lone=True):
+    def __init__(self, width, height, constancy=GREY, device=0, ctx=None, silent=True, lone=True, second_stream=False):
         L = host_lib()
         self._adopted = ctx is not None
         if ctx is not None:
@@ -542,7 +542,7 @@ class OpticalFlow:
         elif L.flow2d_host_init_device(device) != 0:
             raise Flow2DError(2, "InitDeviceContext")
         self.width, self.height = width, height
-        self.handle = L.flow2d_host_flow_create(width, height, _HOST_CONSTANCY[constancy], int(silent), int(lone))
+        self.handle = L.flow2d_host_flow_create(width, height, _HOST_CONSTANCY[constancy], int(silent), int(bool(lone)) | (2 if second_stream else 0))
         if not self.handle:
             if self._adopted:
                 L.flow2d_host_adopt_context(None)

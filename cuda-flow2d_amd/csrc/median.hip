@@ -390,42 +390,20 @@ __global__ __launch_bounds__(256) void median5_stream_kernel(const float* __rest
 // ---- r = 7, streaming (round 4) -----------------------------------------------------------------------------------
 // The same scheme one size up: a lane loads ONE value per image row, takes three neighbours per side from the adjacent
 // lanes (DPP), sorts the 7-tuple (16 comparators) and keeps the sorted tuples of eight consecutive rows in registers.  Two
-// vertically adjacent medians share six of their seven rows: median7_pair_network.inc (generated and verified exhaustively
-// over the 8^8 sorted 0-1 inputs by tools/gen_median7_network.py) merges the six shared tuples once and finishes both.
+// vertically adjacent medians share six of their seven rows: median7_pair_network.inc (a 212-comparator merge network generated and
+// verified exhaustively over the 8^8 sorted 0-1 inputs by tools/gen_median7_network.py, lowered to 254 one-result instructions with
+// three-input minima, maxima and medians by tools/median_select3.py) merges the six shared tuples once and finishes both.
 // The generic kernel gathers 49 values per pixel and sorts them with a pruned Batcher network: 412 us per 4096^2 plane.
-struct MedianPairOp {
-    int copy, a, b;
-};
 #include "median7_pair_network.inc"
-
-template <size_t... I>
-__device__ __forceinline__ void run_pair7_program(float (&v)[kMedian7PairWires], std::index_sequence<I...>)
-{
-    (
-        [&] {
-            constexpr MedianPairOp op = kMedian7PairProgram[I];
-            if constexpr (op.copy) {
-                v[op.b] = v[op.a];
-            } else {
-                const float lo = fminf(v[op.a], v[op.b]);
-                const float hi = fmaxf(v[op.a], v[op.b]);
-                v[op.a] = lo;
-                v[op.b] = hi;
-            }
-        }(),
-        ...);
-}
 
 __device__ __forceinline__ void sort7(float (&t)[7])
 {
-    auto cx = [&](int a, int b) {
-        const float lo = fminf(t[a], t[b]), hi = fmaxf(t[a], t[b]);
-        t[a] = lo;
-        t[b] = hi;
-    };
-    // 16 comparators, 6 layers (checked over the 128 0-1 inputs)
-    cx(0, 6); cx(2, 3); cx(4, 5); cx(0, 2); cx(1, 4); cx(3, 6); cx(0, 1); cx(2, 5); cx(3, 4); cx(1, 2); cx(4, 6); cx(2, 3); cx(4, 5);
-    cx(1, 2); cx(3, 4); cx(5, 6);
+    float n[7 + kSort7Ops];
+#pragma unroll
+    for (int i = 0; i < 7; ++i) n[i] = t[i];
+    run_select_program<7, kSort7Ops, kSort7Program>(n, std::make_index_sequence<kSort7Ops>{});
+#pragma unroll
+    for (int i = 0; i < 7; ++i) t[i] = n[kSort7Out[i]];
 }
 
 constexpr int kStream7Valid = 58;  // lanes 3..60 of a wave have three neighbours on either side
@@ -490,14 +468,12 @@ __device__ __forceinline__ void median7_step(float (&ring)[8][7], Row7Load<EDGE,
     next[1] = next[3];
     next[2] = load_row7<EDGE, ADD>(in, ya + 7, h, pitch, xc, xm);
     next[3] = load_row7<EDGE, ADD>(in, ya + 8, h, pitch, xc, xm);
-    float v[kMedian7PairWires];
+    float v[kMedian7PairInputs + kMedian7PairOps];
 #pragma unroll
     for (int g = 0; g < 8; ++g)
 #pragma unroll
         for (int e = 0; e < 7; ++e) v[7 * g + e] = ring[(2 * I + g) % 8][e];
-#pragma unroll
-    for (int i = 56; i < kMedian7PairWires; ++i) v[i] = 0.f;
-    run_pair7_program(v, std::make_index_sequence<kMedian7PairOps>{});
+    run_select_program<kMedian7PairInputs, kMedian7PairOps, kMedian7PairProgram>(v, std::make_index_sequence<kMedian7PairOps>{});
     if (lane_stores) {
         const unsigned at = (static_cast<unsigned>(ya) * static_cast<unsigned>(pitch) + static_cast<unsigned>(x)) * 4u;
         plane_store(out, at, v[kMedian7PairOutA]);

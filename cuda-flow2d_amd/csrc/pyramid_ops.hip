@@ -985,6 +985,114 @@ int flow2d_resample_x_levels(flow2d_context* ctx, const float* input_a, float* p
     return FLOW2D_OK;
 }
 
+// ---- the y passes of several levels in one launch (round 6) -----------------------------------------------------------
+// After flow2d_resample_x_levels the packed planes hold, for every level, the x-resampled rows at full height; each level's y
+// pass (resample_2d.cu:77-118) reads its column segment.  One launch per level cost a config-3 pair seven launches of 7-39 us,
+// most of them far too small to fill the device; here block rows [first_y[l], first_y[l + 1]) of the grid belong to level l and
+// run the body of resample_kernel<false> on that level's geometry: the same cell sums in the same order, the same bits.
+struct ResampleYLevels {
+    int count;
+    int out_w[FLOW2D_RESAMPLE_MAX_LEVELS], out_h[FLOW2D_RESAMPLE_MAX_LEVELS], col[FLOW2D_RESAMPLE_MAX_LEVELS];
+    int out_row[FLOW2D_RESAMPLE_MAX_LEVELS];   // first row of the level's plane region in the output planes
+    int first_y[FLOW2D_RESAMPLE_MAX_LEVELS + 1];  // grid rows (blockIdx.y) of the level
+    int rows_per_thread[FLOW2D_RESAMPLE_MAX_LEVELS];
+    float delta[FLOW2D_RESAMPLE_MAX_LEVELS], normalization[FLOW2D_RESAMPLE_MAX_LEVELS];
+};
+
+__global__ __launch_bounds__(256) void resample_y_levels_kernel(const float* __restrict__ in_a, float* __restrict__ out_a,
+                                                                const float* __restrict__ in_b, float* __restrict__ out_b,
+                                                                int in_h, int pitch, ResampleYLevels lv, BatchArg batch)
+{
+    int l = 0;
+    while (l + 1 < lv.count && static_cast<int>(blockIdx.y) >= lv.first_y[l + 1]) ++l;
+    const int out_w = lv.out_w[l], out_h = lv.out_h[l], rows_per_thread = lv.rows_per_thread[l];
+    const float delta = lv.delta[l], normalization = lv.normalization[l];
+    const float* __restrict__ in = (batch_plane(batch) ? in_b : in_a) + batch_offset(batch) + lv.col[l];
+    float* __restrict__ out = (batch_plane(batch) ? out_b : out_a) + batch_offset(batch) + static_cast<size_t>(lv.out_row[l]) * pitch;
+    const int x = blockIdx.x * kBlockX + threadIdx.x;
+    if (x >= out_w) return;
+    const int block_y = static_cast<int>(blockIdx.y) - lv.first_y[l];
+    for (int row = 0; row < rows_per_thread; ++row) {
+        const int y = (block_y * rows_per_thread + row) * kBlockY + threadIdx.y;
+        if (y >= out_h) return;
+        const float left_f = static_cast<float>(static_cast<unsigned>(y)) * delta;
+        const float right_f = static_cast<float>(static_cast<unsigned>(y) + 1u) * delta;
+        const int left_i = static_cast<int>(floorf(left_f));
+        const int right_i = min(in_h, static_cast<int>(ceilf(right_f)));
+        const int cells = right_i - left_i;
+        const float* base = in + x;
+        const size_t stride = pitch;
+        float value = 0.f;
+        // (the body of resample_kernel<false>: cells summed in order, only the first and the last carry a fraction)
+        if (cells == 1) {
+            value += base[static_cast<size_t>(left_i) * stride] * delta;
+        } else if (cells > 1) {
+            const int last = left_i + cells - 1;
+            value += base[static_cast<size_t>(left_i) * stride] * (static_cast<float>(left_i + 1) - left_f);
+            int k = left_i + 1;
+            for (; k + 32 <= last; k += 32) {
+                float v[32];
+#pragma unroll
+                for (int i = 0; i < 32; ++i) v[i] = base[static_cast<size_t>(k + i) * stride];
+#pragma unroll
+                for (int i = 0; i < 32; ++i) value += v[i];
+            }
+            for (; k + 8 <= last; k += 8) {
+                float v[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) v[i] = base[static_cast<size_t>(k + i) * stride];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) value += v[i];
+            }
+            for (; k < last; ++k) value += base[static_cast<size_t>(k) * stride];
+            value += base[static_cast<size_t>(last) * stride] * (right_f - static_cast<float>(last));
+        }
+        out[static_cast<size_t>(y) * pitch + x] = value * normalization;
+    }
+}
+
+int flow2d_resample_y_levels(flow2d_context* ctx, const float* packed_a, float* output_a, const float* packed_b, float* output_b,
+                             size_t in_height, size_t pitch_bytes, size_t level_count, const size_t* out_widths,
+                             const size_t* out_heights, const size_t* column_offsets, const size_t* output_rows)
+{
+    FLOW2D_ENTER(ctx);
+    if (!out_widths || !out_heights || !column_offsets || !output_rows || level_count == 0 || !packed_a || !output_a ||
+        packed_a == output_a || pitch_bytes == 0 || pitch_bytes % 16 != 0 || in_height == 0)
+        return FLOW2D_ERR_INVALID_ARGUMENT;
+    if (level_count > FLOW2D_RESAMPLE_MAX_LEVELS) return FLOW2D_ERR_UNSUPPORTED;
+    const bool pair = packed_b || output_b;
+    if (pair && (!packed_b || !output_b || packed_b == output_b || output_b == output_a || output_b == packed_a || output_a == packed_b))
+        return FLOW2D_ERR_INVALID_ARGUMENT;
+    const size_t pitch = pitch_bytes / 4;
+    ResampleYLevels lv{};
+    lv.count = static_cast<int>(level_count);
+    unsigned grid_x = 1, grid_y = 0;
+    for (size_t l = 0; l < level_count; ++l) {
+        if (out_widths[l] == 0 || out_heights[l] == 0 || out_heights[l] >= (1u << 30) || column_offsets[l] + out_widths[l] > pitch ||
+            output_rows[l] >= (1u << 30))
+            return FLOW2D_ERR_INVALID_ARGUMENT;
+        for (size_t m = 0; m < l; ++m)  // the levels' output regions must not overlap
+            if (output_rows[l] < output_rows[m] + out_heights[m] && output_rows[m] < output_rows[l] + out_heights[l])
+                return FLOW2D_ERR_INVALID_ARGUMENT;
+        lv.out_w[l] = static_cast<int>(out_widths[l]), lv.out_h[l] = static_cast<int>(out_heights[l]);
+        lv.col[l] = static_cast<int>(column_offsets[l]), lv.out_row[l] = static_cast<int>(output_rows[l]);
+        // delta = in_n / (float) out_n, normalization = out_n / (float) in_n (resample_2d.cu:88-89), as launch_resample evaluates them
+        const float out_n = static_cast<float>(out_heights[l]), in_n = static_cast<float>(in_height);
+        lv.delta[l] = in_n / out_n, lv.normalization[l] = out_n / in_n;
+        lv.rows_per_thread[l] = out_widths[l] * out_heights[l] >= (size_t)512 * 512 ? 4 : 1;
+        lv.first_y[l] = static_cast<int>(grid_y);
+        grid_y += static_cast<unsigned>(flow2d::div_up(flow2d::div_up(out_heights[l], lv.rows_per_thread[l]), kBlockY));
+        grid_x = std::max(grid_x, static_cast<unsigned>(flow2d::div_up(out_widths[l], kBlockX)));
+    }
+    lv.first_y[level_count] = static_cast<int>(grid_y);
+    if (grid_y > 65535u) return FLOW2D_ERR_UNSUPPORTED;
+    const unsigned planes = pair ? 2 : 1;
+    resample_y_levels_kernel<<<dim3(grid_x, grid_y, flow2d::batch_z(ctx, planes)), dim3(kBlockX, kBlockY), 0, ctx->stream>>>(
+        packed_a, output_a, packed_b, output_b, static_cast<int>(in_height), static_cast<int>(pitch), lv, flow2d::batch_arg(ctx, planes));
+    FLOW2D_CHECK_LAUNCH();
+    return FLOW2D_OK;
+}
+
 int flow2d_resample_x(flow2d_context* ctx, const float* input, float* output, size_t out_width, size_t out_height,
                       size_t in_width, size_t pitch_bytes)
 {

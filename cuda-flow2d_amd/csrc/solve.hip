@@ -639,12 +639,15 @@ int launch_phi_ksi(flow2d_context* ctx, const float* f0, const float* f1, const 
 
 // levels of 8 Mpixel and more (below, the ten planes sit in the Infinity Cache and the short-lived waves of the tile forms are faster)
 static bool sweep_streams(size_t w, size_t h) { return w >= 2 * kSweepValid && h >= 8 && w * h >= kSweepStreamMinPixels; }
+// (rows per strip, round 6: 16 / 32 / 64 rows take 155.6 / 152.7-155.8 / 165-167 us per 4096^2 sweep and fetch 718 / 655 / 626 MB --
+//  the halo rows of a strip are re-read by its neighbour -- for 537 MB of algorithmic reads: 32 costs no time and moves 9 % less,
+//  64 leaves too few waves per SIMD; profiles/r06_experiments/per_sweep_strip_rows_ab.txt)
 static unsigned sweep_strip_rows()
 {
 #ifdef FLOW2D_DEV_BUILD  // (developer builds: strip height override, a multiple of 16)
     if (const char* e = std::getenv("FLOW2D_SWEEP_ROWS")) return std::max(16, std::atoi(e) / 16 * 16);
 #endif
-    return 16;
+    return 32;
 }
 static XcdTiles sweep_stream_tiles(size_t w, size_t h, int constancy)
 {

@@ -75,7 +75,7 @@ bool OpticalFlow2D::InitMemory()
     if (CheckFlow2DError(flow2d_mem_info(context_, &free_bytes, &total_bytes), "flow2d_mem_info")) return false;
     const size_t pitch = flow2d_plane_pitch_bytes(dev_container_size_.width);
     // (+ the two packed x-pass planes; a lock-step group holds every plane group_ containers tall)
-    const size_t needed = pitch * dev_container_size_.height * group_ * (kContainersCount + 2 + (lone ? 1 : 0));
+    const size_t needed = pitch * dev_container_size_.height * group_ * (kContainersCount + 2 + (second_stream ? 1 : 0));
     if (!silent)
         std::printf("Available\t:\t%.0fMB / %.0fMB\nNeeded\t\t:\t%.0fMB\n", free_bytes / 1048576.f,
                     total_bytes / 1048576.f, needed / 1048576.f);
@@ -105,7 +105,7 @@ bool OpticalFlow2D::InitMemory()
         }
         packed = static_cast<DevicePtr>(reinterpret_cast<uintptr_t>(plane));
     }
-    if (lone) {  // the second stream of a pair, its events and the plane the warp writes (see RunPyramid); failing here only switches the fork off
+    if (second_stream) {  // the second stream of a pair, its events and the plane the warp writes (see RunPyramid); failing here only switches the fork off
         int device = 0;
         void* plane = nullptr;
         size_t got_pitch = 0;
@@ -639,7 +639,7 @@ bool OpticalFlow2D::RunPyramid(OperationParameters& params)
         packed = column <= dev_container_size_.pitch / sizeof(float);
     }
     const int first_level = level;
-    // A lone object (`lone`, optical_flow_2d.h) forks the flow-independent part of the pair onto its second stream: the pre-blur of
+    // An object with `second_stream` (optical_flow_2d.h) forks the flow-independent part of the pair onto its second stream: the pre-blur of
     // the caller's frames, the x passes, and every level's y pass into a plane region of its own -- the levels one below the other in
     // the two planes that otherwise hold "the current level's frames" (their heights sum to less than the container's for scale
     // factors up to 0.5) -- each followed by an event the main stream waits for before that level's warp.  The main stream meanwhile

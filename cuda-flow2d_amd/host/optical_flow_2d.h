@@ -118,14 +118,18 @@ public:
 
     bool silent = false;
 
-    // Set BEFORE Initialize.  true: this object runs its pairs one after the other with nothing else of the same job beside them on
-    // the device (the CLI, a lone ComputeFlowDevice user, a batch of one lane) -- latency is what counts, so (i) the part of a pair
-    // that does not depend on the flow -- pre-blur, the x passes of all pyramid levels, every level's y pass (the reference resamples
-    // both frames from full resolution at every level, optical_flow_2d.cpp:284-303) -- runs on a second stream beside the
-    // launch-bound coarse levels and joins before each level's warp (recorded into the same graph), and (ii) strip launches that
-    // leave half the wave slots empty use the build of the strip kernel with packed arithmetic (flow2d_context_set_lone).
+    // Set BEFORE Initialize.  lone: this object runs its pairs one after the other with nothing else of the same job beside them on
+    // the device (the CLI, a lone ComputeFlowDevice user, a batch of one lane) -- latency is what counts, and strip launches that leave
+    // half the wave slots empty use the build of the strip kernel with packed arithmetic (flow2d_context_set_lone).
     // OpticalFlowBatch2D clears it for its lanes when there are several: in a pipeline the other lanes' work fills the device.
     bool lone = true;
+    // second_stream (opt-in): the part of a pair that does not depend on the flow -- pre-blur, the x passes of all pyramid levels,
+    // every level's y pass (the reference resamples both frames from full resolution at every level, optical_flow_2d.cpp:284-303) --
+    // runs on a second stream beside the launch-bound coarse levels and joins before each level's warp (recorded into the same
+    // graph).  Bit-identical (test_forked_frame_pyramid_matches_the_single_stream); measured it does NOT pay on this runtime: the
+    // y passes (100 us of a 3.7 ms config-3 pair) do overlap, but a replayed graph with cross-queue edges loses more than that
+    // (config 3: 3.70 against 3.64 ms, config 2: 0.70 / 0.68, one 1080p pair: 1.23 / 1.20; profiles/r06_experiments) -- hence off.
+    bool second_stream = false;
 
 private:
     bool InitMemory();
@@ -169,7 +173,7 @@ private:
     DevicePtr SequenceLevelPlane(FramePyramid& pyramid, size_t level, size_t rows);
     void FreeSequenceCache();
     flow2d_context* context_ = nullptr;
-    // lone objects: the second stream of a pair (a context of its own on the same device), the events that hand its results to the
+    // second_stream objects: the second stream of a pair (a context of its own on the same device), the events that hand its results to the
     // main stream -- [0] the forking point, [1 + l] "level l's frames are ready" -- and two planes beside the pool: the warped frame
     // of a level (the level planes stay where the side stream put them) -- see RunPyramid
     flow2d_context* side_context_ = nullptr;
@@ -188,7 +192,7 @@ private:
 
     CudaOperationAdd2D cuop_add_;
     CudaOperationConvolution2D cuop_convolution_;
-    CudaOperationConvolution2D side_convolution_;  // lone objects: the pre-blur on the second stream
+    CudaOperationConvolution2D side_convolution_;  // second_stream objects: the pre-blur on that stream
     CudaOperationMedian2D cuop_median_;
     CudaOperationRegistration2D cuop_register_;
     CudaOperationResample2D cuop_resample_;

@@ -252,6 +252,16 @@ FLOW2D_API int flow2d_resample_x_levels(flow2d_context* ctx, const float* input_
                                         float* packed_b, size_t in_width, size_t height, size_t pitch_bytes,
                                         size_t level_count, const size_t* out_widths, const size_t* column_offsets);
 
+/* The y passes of resample_2d.cu:77-118 for SEVERAL levels in one launch, the counterpart of flow2d_resample_x_levels: level l
+ * reads columns [column_offsets[l], column_offsets[l] + out_widths[l]) of the packed plane (in_height rows) and writes an
+ * out_widths[l] x out_heights[l] plane region whose first row is row output_rows[l] of the output plane (regions disjoint;
+ * the region of a level is a plane of its own: pointer = output + output_rows[l] * pitch).  Each output is the same top-to-bottom
+ * cell sum as flow2d_resample_y produces for that level (bit-identical).  packed_b / output_b: optional second plane. */
+FLOW2D_API int flow2d_resample_y_levels(flow2d_context* ctx, const float* packed_a, float* output_a, const float* packed_b,
+                                        float* output_b, size_t in_height, size_t pitch_bytes, size_t level_count,
+                                        const size_t* out_widths, const size_t* out_heights, const size_t* column_offsets,
+                                        const size_t* output_rows);
+
 /* compute_phi_ksi (src/kernels/solve_2d.cu:43-198). */
 FLOW2D_API int flow2d_compute_phi_ksi(flow2d_context* ctx, const float* frame_0, const float* frame_1,
                                       const float* flow_u, const float* flow_v, const float* flow_du,

@@ -582,7 +582,7 @@ def test_graph_replay_matches_eager(flow2d, oracle, ctx):
 @pytest.mark.parametrize("constancy", [0, 1])
 @pytest.mark.parametrize("w,h,levels", [(512, 384, 6), (200, 136, 4), (1024, 1024, 7)])
 def test_forked_frame_pyramid_matches_the_single_stream(flow2d, oracle, ctx, w, h, levels, constancy):
-    """Round 6: a lone OpticalFlow2D runs the flow-independent part of a pair -- pre-blur, the x passes of all levels, every level's
+    """Round 6 (opt-in, OpticalFlow2D::second_stream): the object runs the flow-independent part of a pair -- pre-blur, the x passes of all levels, every level's
     y pass -- on a second stream, joined by events before each level's warp (eager and recorded into the graph).  Same kernels
     on the same values: the flow equals the single-stream object's and the oracle's, bit for bit, also when the same graph is
     replayed on new frames and when back-to-back pairs reuse the level planes (the next pair's second stream must not overtake)."""
@@ -590,7 +590,7 @@ def test_forked_frame_pyramid_matches_the_single_stream(flow2d, oracle, ctx, w, 
     pairs = [oracle.synthetic_pair(w, h, 1.25 + k, -0.5 * k, seed=20 + k, noise=True) for k in range(3)]
     wanted = [oracle.compute_flow(f0, f1, levels, 0.5, 3, 5, 35.0, 0.001, 0.001, 5, 1.5, constancy)[:2] for f0, f1 in pairs]
     for lone in (True, False):
-        flow = flow2d.OpticalFlow(w, h, constancy, ctx=ctx, lone=lone)
+        flow = flow2d.OpticalFlow(w, h, constancy, ctx=ctx, lone=lone, second_stream=lone)
         try:
             planes = [ctx.plane(w, h), ctx.plane(w, h), ctx.plane(w, h), ctx.plane(w, h)]
             outs = [(ctx.plane(w, h), ctx.plane(w, h)) for _ in pairs]

@@ -1,6 +1,6 @@
 """Developer tool (round 6): the LAST replay of tools/lone_pair_trace.py kernel by kernel from a rocprofv3 kernel trace:
 queue, start and end relative to the replay's first kernel, duration, idle gap before it on its own queue, name and grid.
-usage: python tools/lone_pair_timeline.py <kernel_trace.csv> [max rows]"""
+usage: python tools/lone_pair_timeline.py <kernel_trace.csv> [replays in the trace] [max rows]"""
 import csv
 import sys
 
@@ -11,11 +11,10 @@ def short(name):
 
 def main():
     rows = sorted(csv.DictReader(open(sys.argv[1])), key=lambda r: int(r["Start_Timestamp"]))
-    limit = int(sys.argv[2]) if len(sys.argv) > 2 else 400
-    # replays are separated by host synchronisation: gaps of more than 200 us between consecutive kernel starts
-    starts = [int(r["Start_Timestamp"]) for r in rows]
-    cut = [0] + [i for i in range(1, len(rows)) if starts[i] - max(int(r["End_Timestamp"]) for r in rows[:i]) > 200000]
-    last = rows[cut[-1]:]
+    replays = int(sys.argv[2]) if len(sys.argv) > 2 else 4
+    limit = int(sys.argv[3]) if len(sys.argv) > 3 else 400
+    # every replay launches the same kernels: the last replay is the last len / replays rows
+    last = rows[len(rows) - len(rows) // replays:]
     t0 = int(last[0]["Start_Timestamp"])
     end = max(int(r["End_Timestamp"]) for r in last)
     queues = sorted({r["Queue_Id"] for r in last})

@@ -141,10 +141,57 @@ call7() {  # timeline of a lone config-3 pair, forked (lone 1) and on one stream
         (cd /tmp && timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d "$OUT/lone_trace_$lone" -- python3 "$R/tools/lone_pair_trace.py" cfg3_4096_gradient $lone 4 \
             > "$OUT/call7_lone$lone.log" 2>&1) || { tail -5 "$OUT/call7_lone$lone.log"; return 1; }
         grep "pair:" "$OUT/call7_lone$lone.log"
-        python3 tools/lone_pair_timeline.py "$OUT"/lone_trace_$lone/*/*kernel_trace.csv 400 > "$OUT/call7_timeline_lone$lone.txt"
+        python3 tools/lone_pair_timeline.py "$OUT"/lone_trace_$lone/*/*kernel_trace.csv 4 400 > "$OUT/call7_timeline_lone$lone.txt"
         rm -rf "$OUT/lone_trace_$lone"
         head -3 "$OUT/call7_timeline_lone$lone.txt"
     done
+}
+
+call8() {  # lone pair latency again (forked / one stream taking turns), the median tests incl. window 7, and the new bench fields
+    timeout -k 10 600 python3 -m pytest tests/test_gpu_kernels.py tests/test_gpu_reference.py -x -q -k "median" > "$OUT/call8_median_tests.log" 2>&1 || { tail -20 "$OUT/call8_median_tests.log"; return 1; }
+    tail -1 "$OUT/call8_median_tests.log"
+    FLOW2D_HIP_LIB="$R/ab/median_old.so" timeout -k 10 120 python3 tools/time_ops.py 4096 2>&1 | grep -i "median"
+    timeout -k 10 120 python3 tools/time_ops.py 4096 2>&1 | grep -i "median"
+    for wl in cfg3_4096_gradient cfg2_1024_grey cfg4_1080p_batch; do
+        timeout -k 10 300 python3 bench.py --workload $wl --no-pmc --no-oracle-check --no-host-entry-leg --no-cpu-baseline --no-reference-baseline --no-batch-leg 2>"$OUT/call8_$wl.err" > "$OUT/call8_$wl.json" || { tail -5 "$OUT/call8_$wl.err"; return 1; }
+        python3 -c "
+import json
+d=json.load(open('$OUT/call8_$wl.json')); r=d['roofline']
+print('%-22s pairs/s %8.1f  launch_ms %s  lone pair ms %s  (one stream, pipeline kernels: %s)  clock %s %s  valu frac %s at clock %s  hbm floor %s  memory-only %s compute-only %s' % ('$wl', d['pairs_per_s'], r.get('avg_launch_ms'), d.get('single_pair_latency_ms'), str(d.get('single_pair_latency_pipeline_kernels_ms')) + ' second stream: ' + str(d.get('single_pair_latency_second_stream_ms')), r.get('shader_clock_ghz'), r.get('shader_clock_ghz_per_xcd'), r.get('valu_issue_frac'), r.get('valu_issue_frac_at_clock'), r.get('hbm_floor_us'), r.get('memory_only_us'), r.get('compute_only_us')))"
+    done
+}
+
+call9() {  # the whole GPU suite on the current tree, then call8's lines again (three-way lone latency, clock under the finest level's solves)
+    timeout -k 10 1150 python3 -m pytest tests -q -m gpu -x > "$OUT/call9_gpu_tests.log" 2>&1 || { tail -30 "$OUT/call9_gpu_tests.log"; return 1; }
+    tail -2 "$OUT/call9_gpu_tests.log"
+    call8
+}
+
+call10() {  # the streaming per-sweep kernel at strips of 16 (product) / 32 / 64 rows: time and FETCH_SIZE per launch
+    for rows in 16 32 64; do
+        echo "== strips of $rows rows"
+        export FLOW2D_SWEEP_ROWS=$rows FLOW2D_HIP_LIB=$(lib dev2)
+        timeout -k 10 120 python3 tools/time_per_sweep.py 4096 4096 2>&1 | grep -E "grey|gradient" || return 1
+        rm -rf "$OUT/pmc_sweep"
+        (cd /tmp && timeout -k 10 200 rocprofv3 --kernel-trace --output-format csv --pmc FETCH_SIZE -d "$OUT/pmc_sweep" -- python3 "$R/tools/time_per_sweep.py" 4096 4096 > "$OUT/pmc_sweep.log" 2>&1) || { tail -3 "$OUT/pmc_sweep.log"; return 1; }
+        python3 - "$OUT"/pmc_sweep/*/*counter_collection.csv <<'PY'
+import csv, sys, collections
+d = collections.defaultdict(list)
+for r in csv.DictReader(open(sys.argv[1])):
+    if "sweep_stream" in r["Kernel_Name"] and r["Counter_Name"] == "FETCH_SIZE":
+        d[r["Kernel_Name"].split("(")[0][-34:]].append(float(r["Counter_Value"]))
+for k, v in sorted(d.items()):
+    print("   %-34s FETCH_SIZE per launch %.1f KB x 2 (gfx950 counts 128-byte requests as 64) = %.1f MB; algorithmic reads 8 x 64 MiB = 536.9 MB" % (k, sum(v) / len(v), 2 * sum(v) / len(v) / 1e3))
+PY
+        rm -rf "$OUT/pmc_sweep"
+    done
+    unset FLOW2D_SWEEP_ROWS FLOW2D_HIP_LIB
+}
+
+call11() {  # per-sweep strips A/B, then the three lone-pair variants on contexts of their own
+    call10 > "$OUT/call10_per_sweep_rows_ab.txt" 2>&1 || { tail "$OUT/call10_per_sweep_rows_ab.txt"; return 1; }
+    cat "$OUT/call10_per_sweep_rows_ab.txt"
+    call8 2>&1 | grep -v "median\|passed"
 }
 
 "$@"
