@@ -22,8 +22,10 @@ Order of a run
      every plane set in flight holds a DIFFERENT synthetic pair (distinct_pairs_in_flight)
   4. host-entry leg: the same pairs from HOST images to HOST flows (uploads and downloads inside the bracket, pipelined
      against the pyramids by OpticalFlowBatch2D::ComputeFlowBatch): pairs_per_s_incl_h2d, SURVEY 8(d) metric 2 as defined
-  5. roofline sample: eager passes with HIP events on the launch stream around every finest-level solver launch; the per-sweep
-     kernel alone; a device-to-device copy for scale
+  5. roofline sample: eager passes with HIP events on the launch stream around every finest-level solver launch; the shader clock
+     the chip HOLDS under the finest level's solves (one sleeping wave per XCD, flow2d_clock_probe_*); a lone pair's latency (a lone
+     object and a pipeline lane's taking turns); the per-sweep kernel alone; a device-to-device copy for scale; the strip kernel's
+     timing probes (developer libraries under ab/) when present
   6. baselines on rank 0 at N = 1: the CPU oracle on the workload's pair; the reference's own kernels (oracle/_ref,
      compiled from its sources for gfx950) with the reference's launch schedule on this GPU
   (--workload cfg3_4096_sor: the opt-in red-black SOR mode and its leg against Jacobi on the whole pyramid)
@@ -37,6 +39,9 @@ roofline: the finest level's dominant solver kernel.  achieved/frac/traffic are 
           40 B per pixel-sweep, 32 B per pixel for phi/ksi, i.e. the reference's per-sweep schedule) over the same
           duration -- above 1 for the fused kernel because it does not move those bytes.  bound says what limits the
           kernel: "valu" (vector-instruction issue, valu_issue_frac) for the temporally blocked kernels, "hbm" otherwise.
+          Round 6 adds the launch's distance to each bound: shader_clock_ghz (+ per XCD; the power management holds 1.6-2.1 GHz under
+          the strip kernel, not the nominal 2.4) and valu_issue_frac_at_clock, hbm_floor_us (compulsory bytes / this box's copy rate),
+          memory_only_us / compute_only_us (the probes; each at the clock IT holds).
 """
 import argparse
 import hashlib
@@ -882,25 +887,21 @@ def roofline_sample(job, passes=3):
             return cx.elapsed_ms(e0, e1)
 
         # ... and the same pair through an object that behaves like a lane of a pipeline (OpticalFlow2D::lone = false: the
-        # pipeline's build of the strip kernel everywhere) and through one with the opt-in second stream for the frame pyramid:
-        # what the packed build buys a lone pair, and what the second stream costs it.  The three take turns (the chip's clock ramps over tens of milliseconds: whoever is measured later would look better) and
+        # pipeline's build of the strip kernel everywhere): what the packed build buys a lone pair.  The two take turns (the chip's clock ramps over tens of milliseconds: whoever is measured later would look better) and
         # each reports the median of its replays after the recording one.
         # (`lone` is a property of the CONTEXT -- flow2d_context_set_lone -- so each object gets a context of its own)
-        c_plain, c_forked = flow2d.Context(job.local_rank), flow2d.Context(job.local_rank)
+        c_plain = flow2d.Context(job.local_rank)
         plain = flow2d.OpticalFlow(w, h, cfg["constancy"], ctx=c_plain, lone=False)
-        forked = flow2d.OpticalFlow(w, h, cfg["constancy"], ctx=c_forked, lone=True, second_stream=True)
         try:
-            objs = ((flow, c), (plain, c_plain), (forked, c_forked))
+            objs = ((flow, c), (plain, c_plain))
             for o, cx in objs:
                 o.use_graph(True)
                 replayed_ms(o, cx)  # these record
-            times = [[replayed_ms(o, cx) for o, cx in objs] for _ in range(7)]
-            latency, job.single_stream_latency_ms, job.second_stream_latency_ms = (float(np.median([t[k] for t in times])) for k in range(3))
+            times = [[replayed_ms(o, cx) for o, cx in objs] for _ in range(9)]
+            latency, job.single_stream_latency_ms = (float(np.median([t[k] for t in times])) for k in range(2))
         finally:
             plain.close()
-            forked.close()
             c_plain.close()
-            c_forked.close()
         return finest, latency
     finally:
         flow.close()
@@ -1367,8 +1368,6 @@ def main():
             "pairs_per_s_single": round(1e3 / pair_latency_ms, 3),  # = 1 / single_pair_latency: no second pair in flight
             # the same lone pair with the pipeline's kernels (round 5's single pair; OpticalFlow2D::lone = false)
             "single_pair_latency_pipeline_kernels_ms": round(getattr(sample, "single_stream_latency_ms", float("nan")), 3),
-            # ... and with the opt-in second stream for the frame pyramid (OpticalFlow2D::second_stream; off by default: it does not pay)
-            "single_pair_latency_second_stream_ms": round(getattr(sample, "second_stream_latency_ms", float("nan")), 3),
             "finest_level": {
                 "solve_ms": round(solve_ms, 4),
                 "mpix_iters_per_s": round(px_iters / (solve_ms * 1e-3) / 1e6, 1),

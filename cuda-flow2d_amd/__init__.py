@@ -134,6 +134,8 @@ def hip_lib():
         L.flow2d_solve_level.argtypes = [vp] * 11 + [C.POINTER(SolveParams), C.POINTER(i)]
         L.flow2d_timing_enable.argtypes = [vp, i]
         L.flow2d_fused_fallbacks.argtypes = [vp, C.POINTER(C.c_ulonglong)]
+        L.flow2d_context_set_lone.argtypes = [vp, i]
+        L.flow2d_resample_y_levels.argtypes = [vp, vp, vp, vp, vp, sz, sz, sz, C.POINTER(sz), C.POINTER(sz), C.POINTER(sz), C.POINTER(sz)]
         L.flow2d_clock_probe_start.argtypes = [vp, C.c_double]
         L.flow2d_clock_probe_read.argtypes = [vp, C.POINTER(C.c_double)]
         L.flow2d_fused_block_order.argtypes = [vp, sz, sz, sz, sz, C.POINTER(i), sz, C.POINTER(sz)]
@@ -246,6 +248,18 @@ class Context:
         n = C.c_ulonglong()
         _check(hip_lib().flow2d_fused_fallbacks(self.handle, C.byref(n)), "flow2d_fused_fallbacks")
         return n.value
+
+    def set_lone(self, lone):
+        """flow2d_context_set_lone: this context's launches run alone on the device (packed strip build for under-filled launches)"""
+        _check(hip_lib().flow2d_context_set_lone(self.handle, int(bool(lone))), "flow2d_context_set_lone")
+
+    def resample_y_levels(self, packed_a, out_a, in_height, widths, heights, columns, rows, packed_b=None, out_b=None):
+        """the y passes of several pyramid levels in one launch (flow2d_resample_y_levels)"""
+        n = len(widths)
+        arr = lambda v: (C.c_size_t * n)(*v)
+        _check(hip_lib().flow2d_resample_y_levels(self.handle, packed_a.ptr, out_a.ptr, packed_b.ptr if packed_b else None,
+                                                  out_b.ptr if out_b else None, in_height, packed_a.pitch, n, arr(widths), arr(heights),
+                                                  arr(columns), arr(rows)), "flow2d_resample_y_levels")
 
     def clock_probe_start(self, duration_us):
         """queues one sleeping wave per XCD on this context's stream that brackets duration_us with the 100 MHz and the shader clock"""
@@ -534,7 +548,7 @@ def _fptr(a):
 class OpticalFlow:
     """OpticalFlow2D of the host layer (Initialize / ComputeFlow / ComputeFlowDevice / Destroy)."""
 
-    def __init__(self, width, height, constancy=GREY, device=0, ctx=None, silent=True, lone=True, second_stream=False):
+    def __init__(self, width, height, constancy=GREY, device=0, ctx=None, silent=True, lone=True):
         L = host_lib()
         self._adopted = ctx is not None
         if ctx is not None:
@@ -542,7 +556,7 @@ class OpticalFlow:
         elif L.flow2d_host_init_device(device) != 0:
             raise Flow2DError(2, "InitDeviceContext")
         self.width, self.height = width, height
-        self.handle = L.flow2d_host_flow_create(width, height, _HOST_CONSTANCY[constancy], int(silent), int(bool(lone)) | (2 if second_stream else 0))
+        self.handle = L.flow2d_host_flow_create(width, height, _HOST_CONSTANCY[constancy], int(silent), int(bool(lone)))
         if not self.handle:
             if self._adopted:
                 L.flow2d_host_adopt_context(None)

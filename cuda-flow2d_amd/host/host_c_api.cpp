@@ -56,15 +56,14 @@ HOST_API flow2d_context* flow2d_host_context(void) { return CurrentDeviceContext
 HOST_API void flow2d_host_shutdown(void) { DestroyDeviceContext(); }
 
 // constancy: enum class DataConstancy (0 Grey, 1 Gradient, 2 LogDerivatives, 3 GradientUntiled).  nullptr on failure.
-// lone: bit 0 OpticalFlow2D::lone (the object's pairs run alone on the device: packed strip kernel for under-filled launches; clear:
-// one worker among several), bit 1 OpticalFlow2D::second_stream (opt-in: the frame pyramid on a second stream)
+// lone: OpticalFlow2D::lone (1: the object's pairs run alone on the device -- packed strip kernel for under-filled launches; 0: one
+// worker among several)
 HOST_API flow2d_host_flow* flow2d_host_flow_create(size_t width, size_t height, int constancy, int silent, int lone)
 {
     flow2d_host_flow* h = new (std::nothrow) flow2d_host_flow();
     if (!h) return nullptr;
     h->flow.silent = silent != 0;
-    h->flow.lone = (lone & 1) != 0;
-    h->flow.second_stream = (lone & 2) != 0;
+    h->flow.lone = lone != 0;
     DataSize3 size = {width, height, 1};
     if (!h->flow.Initialize(size, static_cast<DataConstancy>(constancy))) {
         delete h;

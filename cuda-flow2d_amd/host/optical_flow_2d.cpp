@@ -75,7 +75,7 @@ bool OpticalFlow2D::InitMemory()
     if (CheckFlow2DError(flow2d_mem_info(context_, &free_bytes, &total_bytes), "flow2d_mem_info")) return false;
     const size_t pitch = flow2d_plane_pitch_bytes(dev_container_size_.width);
     // (+ the two packed x-pass planes; a lock-step group holds every plane group_ containers tall)
-    const size_t needed = pitch * dev_container_size_.height * group_ * (kContainersCount + 2 + (second_stream ? 1 : 0));
+    const size_t needed = pitch * dev_container_size_.height * group_ * (kContainersCount + 3);
     if (!silent)
         std::printf("Available\t:\t%.0fMB / %.0fMB\nNeeded\t\t:\t%.0fMB\n", free_bytes / 1048576.f,
                     total_bytes / 1048576.f, needed / 1048576.f);
@@ -105,21 +105,12 @@ bool OpticalFlow2D::InitMemory()
         }
         packed = static_cast<DevicePtr>(reinterpret_cast<uintptr_t>(plane));
     }
-    if (second_stream) {  // the second stream of a pair, its events and the plane the warp writes (see RunPyramid); failing here only switches the fork off
-        int device = 0;
+    {  // ... and the plane the warp writes when the levels are stacked (RunPyramid); without it the levels are resampled one by one
         void* plane = nullptr;
         size_t got_pitch = 0;
-        if (flow2d_context_device(context_, &device) == FLOW2D_OK && flow2d_context_create(device, &side_context_) == FLOW2D_OK &&
-            flow2d_plane_alloc(context_, dev_container_size_.width, dev_container_size_.height * group_, &plane, &got_pitch) == FLOW2D_OK &&
-            got_pitch == pitch) {
-            fork_warp_plane_ = static_cast<DevicePtr>(reinterpret_cast<uintptr_t>(plane));
-            fork_events_.assign(2 + FLOW2D_RESAMPLE_MAX_LEVELS, nullptr);
-            for (void*& e : fork_events_)
-                if (flow2d_event_create(context_, &e) != FLOW2D_OK) e = nullptr;
-        }
-        if (!fork_warp_plane_ || std::find(fork_events_.begin(), fork_events_.end(), nullptr) != fork_events_.end()) {
-            if (plane && !fork_warp_plane_) flow2d_plane_free(context_, plane);
-            ReleaseFork();
+        if (flow2d_plane_alloc(context_, dev_container_size_.width, dev_container_size_.height * group_, &plane, &got_pitch) == FLOW2D_OK) {
+            if (got_pitch == pitch) level_warp_plane_ = static_cast<DevicePtr>(reinterpret_cast<uintptr_t>(plane));
+            else flow2d_plane_free(context_, plane);
         }
     }
     dev_container_size_.pitch = pitch;
@@ -143,13 +134,6 @@ bool OpticalFlow2D::InitOperations()
         if (!silent) std::printf("%-18s: %s\n", cuop->GetName(), ok ? "OK" : "FAILED");
         if (!ok) return false;
     }
-    if (side_context_) {  // the pre-blur of a forked pair runs on the second stream: an operator bound to that context
-        OperationParameters side;
-        side.PushValuePtr("container_size", &dev_container_size_);
-        side.PushValuePtr("data_constancy", &data_constancy_);
-        side.PushValuePtr("flow2d_context", &side_context_);
-        if (!side_convolution_.Initialize(&side)) ReleaseFork();
-    }
     return true;
 }
 
@@ -158,7 +142,6 @@ void OpticalFlow2D::Destroy()
     CudaOperationBase* ops[] = {&cuop_add_, &cuop_convolution_, &cuop_median_,
                                 &cuop_register_, &cuop_resample_, &cuop_solve_};
     for (CudaOperationBase* cuop : ops) cuop->Destroy();
-    side_convolution_.Destroy();
     if (context_) {
         if (!all_planes_.empty()) flow2d_synchronize(context_);
         DropGraphs();
@@ -174,23 +157,12 @@ void OpticalFlow2D::Destroy()
             if (p) flow2d_plane_free(context_, AsPlane(p));
             p = 0;
         }
-        ReleaseFork();
+        if (level_warp_plane_) flow2d_plane_free(context_, AsPlane(level_warp_plane_));
+        level_warp_plane_ = 0;
     }
     all_planes_.clear();
     free_planes_.clear();
     initialized_ = false;
-}
-
-void OpticalFlow2D::ReleaseFork()
-{
-    if (side_context_) (void)flow2d_synchronize(side_context_);
-    for (void* e : fork_events_)
-        if (e) flow2d_event_destroy(context_, e);
-    fork_events_.clear();
-    if (fork_warp_plane_) flow2d_plane_free(context_, AsPlane(fork_warp_plane_));
-    fork_warp_plane_ = 0;
-    if (side_context_) flow2d_context_destroy(side_context_);
-    side_context_ = nullptr;
 }
 
 DevicePtr OpticalFlow2D::Acquire()
@@ -639,27 +611,23 @@ bool OpticalFlow2D::RunPyramid(OperationParameters& params)
         packed = column <= dev_container_size_.pitch / sizeof(float);
     }
     const int first_level = level;
-    // An object with `second_stream` (optical_flow_2d.h) forks the flow-independent part of the pair onto its second stream: the pre-blur of
-    // the caller's frames, the x passes, and every level's y pass into a plane region of its own -- the levels one below the other in
-    // the two planes that otherwise hold "the current level's frames" (their heights sum to less than the container's for scale
-    // factors up to 0.5) -- each followed by an event the main stream waits for before that level's warp.  The main stream meanwhile
-    // runs the coarse levels, whose launches leave most of the device idle.  Same kernels on the same values: same bits.
-    std::vector<size_t> fork_row(static_cast<size_t>(first_level) + 1, 0);
-    bool fork = false;
-    if (packed && side_context_ && fork_warp_plane_ && caller_frame_0_ && caller_frame_1_) {
+    // Round 6: with the x passes done in one trip, the y passes of ALL levels are one launch too (flow2d_resample_y_levels; they were
+    // seven launches of 7-39 us for a config-3 pair, most of them far too small to fill the device).  Every level then needs a plane
+    // region of its own: the levels sit one below the other in the two planes that otherwise hold "the current level's frames"
+    // (their heights sum to less than the container's for scale factors up to 0.5), and the warp of a level writes the plane kept
+    // for it instead of replacing the level's frame 1.  Same kernels' arithmetic on the same values: same bits.
+    std::vector<size_t> level_row(static_cast<size_t>(first_level) + 1, 0), level_width(level_row.size(), 0), level_height(level_row.size(), 0);
+    bool stacked = false;
+    if (packed && level_warp_plane_) {
         size_t rows = 0;
         for (int l = first_level; l >= 1; --l) {
-            fork_row[static_cast<size_t>(l)] = rows;
-            rows += static_cast<size_t>(std::ceil(original_size.height * std::pow(warp_scale_factor, static_cast<float>(l))));
+            const float s = std::pow(warp_scale_factor, static_cast<float>(l));
+            level_row[static_cast<size_t>(l)] = rows;
+            level_width[static_cast<size_t>(l)] = static_cast<size_t>(std::ceil(original_size.width * s));
+            level_height[static_cast<size_t>(l)] = static_cast<size_t>(std::ceil(original_size.height * s));
+            rows += level_height[static_cast<size_t>(l)];
         }
-        fork = rows <= dev_container_size_.height;
-    }
-    const size_t pitch_floats = dev_container_size_.pitch / sizeof(float);
-    auto level_ready = [&](int l) { return fork_events_[1 + static_cast<size_t>(l)]; };
-    if (fork) {
-        if (group_ > 1) failed |= CheckFlow2DError(flow2d_context_set_batch(side_context_, active_group_, GroupStrideBytes()), "flow2d_context_set_batch");
-        failed |= CheckFlow2DError(flow2d_event_record(context_, fork_events_[0]), "flow2d_event_record");
-        failed |= CheckFlow2DError(flow2d_stream_wait_event(side_context_, fork_events_[0]), "flow2d_stream_wait_event");
+        stacked = rows <= dev_container_size_.height;
     }
 
     if (sequence) {  // a frame's level 0 is blurred once (or is the caller's own plane) and then only read
@@ -697,9 +665,8 @@ bool OpticalFlow2D::RunPyramid(OperationParameters& params)
             op.PushValuePtr("dev_temp", &temp);  // (not touched: the blur is one launch)
             op.PushValuePtr("data_size", &original_size);
             op.PushValuePtr("gaussian_sigma", &gaussian_sigma);
-            CudaOperationConvolution2D& blur = fork ? side_convolution_ : cuop_convolution_;  // forked: on the second stream
-            blur.Execute(op);
-            failed |= blur.TakeFailure();
+            cuop_convolution_.Execute(op);
+            failed |= cuop_convolution_.TakeFailure();
         }
         Release(temp);
     } else if (gaussian_sigma > 0.0) {  // optical_flow_2d.cpp:218-246: blur into the flow planes, then swap roles
@@ -720,25 +687,25 @@ bool OpticalFlow2D::RunPyramid(OperationParameters& params)
     }
 
     if (packed) {
-        flow2d_context* where = fork ? side_context_ : context_;
-        if (fork)  // the frames as level 0 reads them are complete behind the blur
-            failed |= CheckFlow2DError(flow2d_event_record(side_context_, level_ready(0)), "flow2d_event_record");
-        if (CheckFlow2DError(flow2d_resample_x_levels(where, AsPlane(frame_0), AsPlane(packed_frames_[0]),
+        if (CheckFlow2DError(flow2d_resample_x_levels(context_, AsPlane(frame_0), AsPlane(packed_frames_[0]),
                                                       AsPlane(frame_1), AsPlane(packed_frames_[1]),
                                                       original_size.width, original_size.height,
                                                       dev_container_size_.pitch, packed_width.size(),
                                                       packed_width.data(), packed_column.data()),
                              "flow2d_resample_x_levels"))
             failed = true;
-        for (int l = first_level; fork && l >= 1; --l) {  // every level's y pass, coarsest first, each with its event
-            const float s = std::pow(warp_scale_factor, static_cast<float>(l));
-            const size_t lw = static_cast<size_t>(std::ceil(original_size.width * s)), lh = static_cast<size_t>(std::ceil(original_size.height * s));
-            const size_t column = packed_column[static_cast<size_t>(first_level - l)], at = fork_row[static_cast<size_t>(l)] * pitch_floats;
-            failed |= CheckFlow2DError(flow2d_resample_y_pair(side_context_, AsPlane(packed_frames_[0]) + column, AsPlane(frame_0_res) + at,
-                                                              AsPlane(packed_frames_[1]) + column, AsPlane(frame_1_res) + at, lw, lh,
-                                                              original_size.height, dev_container_size_.pitch),
-                                       "flow2d_resample_y_pair");
-            failed |= CheckFlow2DError(flow2d_event_record(side_context_, level_ready(l)), "flow2d_event_record");
+        if (stacked) {  // every level's y pass, both frames, one launch
+            std::vector<size_t> widths, heights, rows;
+            for (int l = first_level; l >= 1; --l) {
+                widths.push_back(level_width[static_cast<size_t>(l)]);
+                heights.push_back(level_height[static_cast<size_t>(l)]);
+                rows.push_back(level_row[static_cast<size_t>(l)]);
+            }
+            if (CheckFlow2DError(flow2d_resample_y_levels(context_, AsPlane(packed_frames_[0]), AsPlane(frame_0_res), AsPlane(packed_frames_[1]),
+                                                          AsPlane(frame_1_res), original_size.height, dev_container_size_.pitch, widths.size(),
+                                                          widths.data(), heights.data(), packed_column.data(), rows.data()),
+                                 "flow2d_resample_y_levels"))
+                failed = true;
         }
     }
 
@@ -779,8 +746,7 @@ bool OpticalFlow2D::RunPyramid(OperationParameters& params)
                 sequence_level[i] = plane;
             }
             if (temp) Release(temp);
-        } else if (fork) {  // this level's frames come from the second stream: wait for them (the host does not)
-            failed |= CheckFlow2DError(flow2d_stream_wait_event(context_, level_ready(level)), "flow2d_stream_wait_event");
+        } else if (stacked) {  // every level's frames are in place already
         } else if (level == 0) {
             std::swap(frame_0, frame_0_res);
             std::swap(frame_1, frame_1_res);
@@ -835,22 +801,22 @@ bool OpticalFlow2D::RunPyramid(OperationParameters& params)
 
         DevicePtr solve_frame_0 = frame_0_res;  // what the solver reads as frame 0 of this level
         DevicePtr solve_frame_1 = 0;            // ... and as (warped) frame 1: frame_1_res unless set
-        if (fork) {  // the level planes stay where the second stream put them; the warp writes the plane kept for it
-            const size_t at = level > 0 ? fork_row[static_cast<size_t>(level)] * dev_container_size_.pitch : 0;
+        if (stacked) {  // the level planes stay where the y pass of all levels put them; the warp writes the plane kept for it
+            const size_t at = level > 0 ? level_row[static_cast<size_t>(level)] * dev_container_size_.pitch : 0;
             DevicePtr level_0 = (level > 0 ? frame_0_res : frame_0) + at, level_1 = (level > 0 ? frame_1_res : frame_1) + at;
             op.Clear();
             op.PushValuePtr("dev_frame_0", &level_0);
             op.PushValuePtr("dev_frame_1", &level_1);
             op.PushValuePtr("dev_flow_u", &flow_u);
             op.PushValuePtr("dev_flow_v", &flow_v);
-            op.PushValuePtr("dev_output", &fork_warp_plane_);
+            op.PushValuePtr("dev_output", &level_warp_plane_);
             op.PushValuePtr("data_size", &current_size);
             op.PushValuePtr("hx", &hx);
             op.PushValuePtr("hy", &hy);
             cuop_register_.Execute(op);
             failed |= cuop_register_.TakeFailure();
             solve_frame_0 = level_0;
-            solve_frame_1 = fork_warp_plane_;
+            solve_frame_1 = level_warp_plane_;
         } else if (sequence) {  // the level planes are kept for the next pair: warp into the pool plane, read the rest
             op.Clear();
             op.PushValuePtr("dev_frame_0", &sequence_level[0]);
@@ -950,7 +916,6 @@ bool OpticalFlow2D::RunPyramid(OperationParameters& params)
     }
     dev_flow_u_ = flow_u;
     dev_flow_v_ = flow_v;
-    if (fork && group_ > 1) flow2d_context_set_batch(side_context_, 1, 0);
     Release(frame_0_res);
     Release(frame_1_res);
     Release(flow_du);

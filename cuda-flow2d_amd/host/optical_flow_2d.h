@@ -123,13 +123,6 @@ public:
     // half the wave slots empty use the build of the strip kernel with packed arithmetic (flow2d_context_set_lone).
     // OpticalFlowBatch2D clears it for its lanes when there are several: in a pipeline the other lanes' work fills the device.
     bool lone = true;
-    // second_stream (opt-in): the part of a pair that does not depend on the flow -- pre-blur, the x passes of all pyramid levels,
-    // every level's y pass (the reference resamples both frames from full resolution at every level, optical_flow_2d.cpp:284-303) --
-    // runs on a second stream beside the launch-bound coarse levels and joins before each level's warp (recorded into the same
-    // graph).  Bit-identical (test_forked_frame_pyramid_matches_the_single_stream); measured it does NOT pay on this runtime: the
-    // y passes (100 us of a 3.7 ms config-3 pair) do overlap, but a replayed graph with cross-queue edges loses more than that
-    // (config 3: 3.70 against 3.64 ms, config 2: 0.70 / 0.68, one 1080p pair: 1.23 / 1.20; profiles/r06_experiments) -- hence off.
-    bool second_stream = false;
 
 private:
     bool InitMemory();
@@ -141,7 +134,6 @@ private:
                              const DevicePtr* dev_flows_u, const DevicePtr* dev_flows_v, OperationParameters& params);
     bool ReplayOrRecord(std::vector<unsigned char> key, const std::function<bool()>& queue);
     void DropGraphs();
-    void ReleaseFork();
     DevicePtr Acquire();
     void Release(DevicePtr p);
 
@@ -173,12 +165,9 @@ private:
     DevicePtr SequenceLevelPlane(FramePyramid& pyramid, size_t level, size_t rows);
     void FreeSequenceCache();
     flow2d_context* context_ = nullptr;
-    // second_stream objects: the second stream of a pair (a context of its own on the same device), the events that hand its results to the
-    // main stream -- [0] the forking point, [1 + l] "level l's frames are ready" -- and two planes beside the pool: the warped frame
-    // of a level (the level planes stay where the side stream put them) -- see RunPyramid
-    flow2d_context* side_context_ = nullptr;
-    std::vector<void*> fork_events_;
-    DevicePtr fork_warp_plane_ = 0;
+    // One plane beside the pool: the warped frame of a level, when the levels of both frames are computed up front into plane
+    // regions of their own (RunPyramid: "stacked" levels) and therefore cannot be overwritten by the warp
+    DevicePtr level_warp_plane_ = 0;
     float last_total_ms_ = 0.f;
     bool last_run_ok_ = false;
     // recorded pyramids, keyed by the caller buffers and parameters they were recorded for
@@ -192,7 +181,6 @@ private:
 
     CudaOperationAdd2D cuop_add_;
     CudaOperationConvolution2D cuop_convolution_;
-    CudaOperationConvolution2D side_convolution_;  // second_stream objects: the pre-blur on that stream
     CudaOperationMedian2D cuop_median_;
     CudaOperationRegistration2D cuop_register_;
     CudaOperationResample2D cuop_resample_;

@@ -580,17 +580,17 @@ def test_graph_replay_matches_eager(flow2d, oracle, ctx):
 
 
 @pytest.mark.parametrize("constancy", [0, 1])
-@pytest.mark.parametrize("w,h,levels", [(512, 384, 6), (200, 136, 4), (1024, 1024, 7)])
-def test_forked_frame_pyramid_matches_the_single_stream(flow2d, oracle, ctx, w, h, levels, constancy):
-    """Round 6 (opt-in, OpticalFlow2D::second_stream): the object runs the flow-independent part of a pair -- pre-blur, the x passes of all levels, every level's
-    y pass -- on a second stream, joined by events before each level's warp (eager and recorded into the graph).  Same kernels
-    on the same values: the flow equals the single-stream object's and the oracle's, bit for bit, also when the same graph is
-    replayed on new frames and when back-to-back pairs reuse the level planes (the next pair's second stream must not overtake)."""
+@pytest.mark.parametrize("w,h,levels", [(512, 384, 6), (200, 136, 4), (1024, 1024, 7), (250, 150, 5)])
+def test_levels_resampled_up_front_match_the_oracle(flow2d, oracle, ctx, w, h, levels, constancy):
+    """Round 6: with a scale factor of 0.5 every level of both frames is resampled up front -- the x passes of all levels in one
+    launch, the y passes of all levels in one launch -- into plane regions one below the other, and a level's warp writes a plane of
+    its own instead of replacing the level's frame.  Same cell sums: the flow equals the oracle's bit for bit, eager and replayed, for
+    a lone object (packed strip build on under-filled launches) and a pipeline lane's, and when pairs are queued back to back."""
     p = flow2d.OpticalFlow.params(levels, 0.5, 3, 5, 35.0, 0.001, 0.001, 5, 1.5)
     pairs = [oracle.synthetic_pair(w, h, 1.25 + k, -0.5 * k, seed=20 + k, noise=True) for k in range(3)]
     wanted = [oracle.compute_flow(f0, f1, levels, 0.5, 3, 5, 35.0, 0.001, 0.001, 5, 1.5, constancy)[:2] for f0, f1 in pairs]
     for lone in (True, False):
-        flow = flow2d.OpticalFlow(w, h, constancy, ctx=ctx, lone=lone, second_stream=lone)
+        flow = flow2d.OpticalFlow(w, h, constancy, ctx=ctx, lone=lone)
         try:
             planes = [ctx.plane(w, h), ctx.plane(w, h), ctx.plane(w, h), ctx.plane(w, h)]
             outs = [(ctx.plane(w, h), ctx.plane(w, h)) for _ in pairs]
@@ -615,6 +615,7 @@ def test_forked_frame_pyramid_matches_the_single_stream(flow2d, oracle, ctx, w, 
                     assert np.array_equal(u.download(), ou) and np.array_equal(v.download(), ov), (lone, graph, "back to back")
         finally:
             flow.close()
+    ctx.set_lone(False)
 
 
 def test_graph_cache_evicts_the_least_recently_used(flow2d, oracle, ctx):

@@ -122,6 +122,39 @@ def test_resample_x_levels(ctx, flow2d, oracle, w, h, scale, levels):
         ctx.resample_x_levels(a, pa, w, h, widths[:2], [0, 0])
 
 
+@pytest.mark.parametrize("w,h,scale,levels", [(4096, 512, 0.5, 7), (1920, 1080, 0.5, 7), (1000, 330, 0.45, 5), (257, 400, 0.3, 3), (640, 120, 0.5, 2),
+                                              (100, 70, 0.33, 3), (2048, 2048, 0.5, 10)])
+def test_resample_y_levels(ctx, flow2d, oracle, w, h, scale, levels):
+    """Round 6: the y passes of all pyramid levels in one launch (flow2d_resample_y_levels) behind the x passes of all levels: every
+    level's plane region is bit-identical to the two-pass resample of that level alone (resample_2d.cu:34-118), for both planes."""
+    f0, f1, *_ = level_fields(oracle, w, h, 35)
+    widths = [int(np.ceil(np.float32(w) * np.float32(scale) ** np.float32(l))) for l in range(levels, 0, -1)]
+    heights = [int(np.ceil(np.float32(h) * np.float32(scale) ** np.float32(l))) for l in range(levels, 0, -1)]
+    columns, col, rows, row = [], 0, [], 0
+    for lw, lh in zip(widths, heights):
+        columns.append(col)
+        col += (lw + 3) // 4 * 4
+        rows.append(row)
+        row += lh
+    assert col <= ctx.plane(w, h).pitch // 4 and row <= h
+    a, b = up(ctx, f0, w, h), up(ctx, f1, w, h)
+    pa, pb = ctx.plane(w, h).fill_bytes(0x7f), ctx.plane(w, h).fill_bytes(0x7f)
+    ctx.resample_x_levels(a, pa, w, h, widths, columns, b, pb)
+    oa, ob = ctx.plane(w, h).fill_bytes(0x7f), ctx.plane(w, h).fill_bytes(0x7f)
+    ctx.resample_y_levels(pa, oa, h, widths, heights, columns, rows, pb, ob)
+    ga, gb = oa.download(), ob.download()
+    for lw, lh, r in zip(widths, heights, rows):
+        assert np.array_equal(ga[r:r + lh, :lw], oracle.resample(f0, w, h, lw, lh)[:lh, :lw]), (lw, lh)
+        assert np.array_equal(gb[r:r + lh, :lw], oracle.resample(f1, w, h, lw, lh)[:lh, :lw]), (lw, lh)
+    assert np.all(ga[row:, :].view(np.uint32) == 0x7f7f7f7f)  # nothing written below the last level
+    single = ctx.plane(w, h).fill_bytes(0x7f)  # one plane, one level
+    ctx.resample_y_levels(pa, single, h, widths[-1:], heights[-1:], columns[-1:], [0])
+    assert np.array_equal(single.download()[:heights[-1], :widths[-1]], oracle.resample(f0, w, h, widths[-1], heights[-1])[:heights[-1], :widths[-1]])
+    if levels > 1:
+        with pytest.raises(flow2d.Flow2DError):  # overlapping output regions
+            ctx.resample_y_levels(pa, oa, h, widths[:2], heights[:2], columns[:2], [0, 0])
+
+
 @pytest.mark.parametrize("hx,hy", [(1.0, 1.0), (1.25, 1.1), (7.3, 5.5)])
 @pytest.mark.parametrize("w,h,cw,ch", SIZES)
 def test_registration(ctx, oracle, w, h, cw, ch, hx, hy):

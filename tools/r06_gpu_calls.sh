@@ -157,7 +157,7 @@ call8() {  # lone pair latency again (forked / one stream taking turns), the med
         python3 -c "
 import json
 d=json.load(open('$OUT/call8_$wl.json')); r=d['roofline']
-print('%-22s pairs/s %8.1f  launch_ms %s  lone pair ms %s  (one stream, pipeline kernels: %s)  clock %s %s  valu frac %s at clock %s  hbm floor %s  memory-only %s compute-only %s' % ('$wl', d['pairs_per_s'], r.get('avg_launch_ms'), d.get('single_pair_latency_ms'), str(d.get('single_pair_latency_pipeline_kernels_ms')) + ' second stream: ' + str(d.get('single_pair_latency_second_stream_ms')), r.get('shader_clock_ghz'), r.get('shader_clock_ghz_per_xcd'), r.get('valu_issue_frac'), r.get('valu_issue_frac_at_clock'), r.get('hbm_floor_us'), r.get('memory_only_us'), r.get('compute_only_us')))"
+print('%-22s pairs/s %8.1f  launch_ms %s  lone pair ms %s  (one stream, pipeline kernels: %s)  clock %s %s  valu frac %s at clock %s  hbm floor %s  memory-only %s compute-only %s' % ('$wl', d['pairs_per_s'], r.get('avg_launch_ms'), d.get('single_pair_latency_ms'), str(d.get('single_pair_latency_pipeline_kernels_ms')), r.get('shader_clock_ghz'), r.get('shader_clock_ghz_per_xcd'), r.get('valu_issue_frac'), r.get('valu_issue_frac_at_clock'), r.get('hbm_floor_us'), r.get('memory_only_us'), r.get('compute_only_us')))"
     done
 }
 
@@ -192,6 +192,23 @@ call11() {  # per-sweep strips A/B, then the three lone-pair variants on context
     call10 > "$OUT/call10_per_sweep_rows_ab.txt" 2>&1 || { tail "$OUT/call10_per_sweep_rows_ab.txt"; return 1; }
     cat "$OUT/call10_per_sweep_rows_ab.txt"
     call8 2>&1 | grep -v "median\|passed"
+}
+
+call12() {  # stacked levels + one y-pass launch: kernel and flow tests, then the lone-pair lines
+    timeout -k 10 900 python3 -m pytest tests/test_gpu_kernels.py tests/test_gpu_flow.py tests/test_gpu_reference.py -x -q > "$OUT/call12_tests.log" 2>&1 || { tail -30 "$OUT/call12_tests.log"; return 1; }
+    tail -1 "$OUT/call12_tests.log"
+    call8 2>&1 | grep -v "median\|passed"
+}
+
+fuzz() {  # random pipelines against the oracle (AUTO, strips forced) and against the reference's own kernels; usage: fuzz <seed base> [cases auto] [cases strips] [cases reference]
+    local seed=${1:-600}
+    timeout -k 10 480 python3 tools/fuzz_parity.py ${2:-1500} $seed 0 0.3 > "$OUT/fuzz_auto_$seed.txt" 2>&1; tail -1 "$OUT/fuzz_auto_$seed.txt"
+    grep -c MISMATCH "$OUT/fuzz_auto_$seed.txt" && return 1
+    timeout -k 10 300 python3 tools/fuzz_parity.py ${3:-600} $((seed + 1)) 2 0.3 > "$OUT/fuzz_strips_$seed.txt" 2>&1; tail -1 "$OUT/fuzz_strips_$seed.txt"
+    grep -c MISMATCH "$OUT/fuzz_strips_$seed.txt" && return 1
+    timeout -k 10 300 python3 tools/fuzz_reference.py ${4:-400} $((seed + 2)) > "$OUT/fuzz_reference_$seed.txt" 2>&1; tail -1 "$OUT/fuzz_reference_$seed.txt"
+    grep -c MISMATCH "$OUT/fuzz_reference_$seed.txt" && return 1
+    return 0
 }
 
 "$@"
