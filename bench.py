@@ -1123,6 +1123,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-reference-baseline", action="store_true")
     ap.add_argument("--no-batch-leg", action="store_true")
+    ap.add_argument("--no-probe-builds", action="store_true", help="skip the memory-only / compute-only timing probes (child processes on ab/*.so)")
     ap.add_argument("--batch-leg-last", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--no-oracle-check", action="store_true",
                     help="skip comparing the first pair's flow with the CPU oracle (output_check.oracle)")
@@ -1264,7 +1265,7 @@ def main():
         clock_ghz = float(np.mean(clocks)) if clocks else None
         compulsory = float(w) * h * 4 * 8  # a fused pass reads f0, f1, u, v, du, dv and writes du, dv: eight planes once
         hbm_floor_us = compulsory / (copy_gbs * 1e9) * 1e6 if copy_gbs else None
-        probes = probe_builds(args, cfg) if rank == 0 and algorithm_used == 2 else {}
+        probes = probe_builds(args, cfg) if rank == 0 and algorithm_used == 2 and not args.no_probe_builds else {}
         kernel_name = {1: "Jacobi sweep kernel (%s)" % {0: "solve_2d", 1: "solve_2d_grad", 3: "solve_2d_log"}.get(
                            cfg["constancy"], "gradient-untiled"),
                        2: ("fused outer-iteration strip kernel (phi/ksi + %d red-black SOR iterations per launch)" % min(cfg["inner"], 2))

@@ -157,7 +157,7 @@ __device__ __forceinline__ float value_or_zero(float v, bool keep)
     return __int_as_float(__float_as_int(v) & -static_cast<int>(keep));
 }
 
-constexpr int kBlurAhead = 4;  // image rows in flight per lane: a wave has one load per row, and a row is a microsecond away
+constexpr int kBlurAhead = 4;  // (six or eight rows in flight are SLOWER: 36.6 -> 37-40 -> 40.4 us, profiles/r06_experiments)  image rows in flight per lane: a wave has one load per row, and a row is a microsecond away
 
 template <int R, int J>
 __device__ __forceinline__ void blur_step(float (&ring)[2 * R + 1], float (&next)[kBlurAhead], float* __restrict__ dst,
@@ -694,6 +694,8 @@ __global__ __launch_bounds__(256) void registration_kernel(const float* __restri
         uu[i] = u[c];
         vv[i] = v[c];
     }
+    // (all sixteen gathers of the thread's four rows issued before the first is used: no faster, 67.7 against 68.2-69.5 us at 4096^2 --
+    //  the kernel moves 4.9 TB/s as it is; profiles/r06_experiments)
 #pragma unroll
     for (int i = 0; i < kRegistrationRows; ++i) {
         const int gy = (blockIdx.y * kRegistrationRows + i) * kBlockY + threadIdx.y;
@@ -718,6 +720,128 @@ __global__ __launch_bounds__(256) void registration_kernel(const float* __restri
                     (dx) * (dy)*r1[x1];
         }
         out[c] = value;
+    }
+}
+
+}  // namespace
+
+namespace {
+// ---- the y passes of several levels in one launch (round 6) -----------------------------------------------------------
+// After flow2d_resample_x_levels the packed planes hold, for every level, the x-resampled rows at full height; each level's y
+// pass (resample_2d.cu:77-118) reads its column segment.  One launch per level cost a config-3 pair seven launches of 7-39 us,
+// most of them far too small to fill the device; here block rows [first_y[l], first_y[l + 1]) of the grid belong to level l and
+// run the body of resample_kernel<false> on that level's geometry: the same cell sums in the same order, the same bits.
+struct ResampleYLevels {
+    int count;
+    int out_w[FLOW2D_RESAMPLE_MAX_LEVELS], out_h[FLOW2D_RESAMPLE_MAX_LEVELS], col[FLOW2D_RESAMPLE_MAX_LEVELS];
+    int out_row[FLOW2D_RESAMPLE_MAX_LEVELS];   // first row of the level's plane region in the output planes
+    int first_block[FLOW2D_RESAMPLE_MAX_LEVELS + 1];  // the level's blocks in the one-dimensional grid (blocks_x[l] per block row)
+    int blocks_x[FLOW2D_RESAMPLE_MAX_LEVELS];
+    int rows_per_thread[FLOW2D_RESAMPLE_MAX_LEVELS];
+    int max_cells[FLOW2D_RESAMPLE_MAX_LEVELS];  // an upper bound of the cells of one output of the level
+    float delta[FLOW2D_RESAMPLE_MAX_LEVELS], normalization[FLOW2D_RESAMPLE_MAX_LEVELS];
+};
+
+// The outputs of one thread when every output has at most MAXC cells (the fine levels: a ratio of 2 has two cells per output, 4
+// four, 8 eight): ALL loads of the thread's rows first, then the sums -- in resample_kernel<false>'s order (first cell with its
+// fraction, the middle ones plain, the last with its fraction), so the same bits.  One output at a time left two loads in
+// flight per thread and the level-1 pass latency-bound at 2.6 TB/s.
+template <int MAXC, int ROWS>
+__device__ __forceinline__ void resample_y_rows(const float* __restrict__ base, float* __restrict__ out, int x, int block_y, int out_h,
+                                                int in_h, int pitch, float delta, float normalization)
+{
+    float v[ROWS][MAXC];
+    int cells[ROWS], ys[ROWS];
+    float first_f[ROWS], last_f[ROWS];
+#pragma unroll
+    for (int row = 0; row < ROWS; ++row) {
+        const int y = (block_y * ROWS + row) * kBlockY + static_cast<int>(threadIdx.y);
+        ys[row] = y;
+        const int yc = min(y, out_h - 1);  // (a thread below the level computes a valid row again and does not store it)
+        const float left_f = static_cast<float>(static_cast<unsigned>(yc)) * delta;
+        const float right_f = static_cast<float>(static_cast<unsigned>(yc) + 1u) * delta;
+        const int left_i = static_cast<int>(floorf(left_f));
+        const int right_i = min(in_h, static_cast<int>(ceilf(right_f)));
+        cells[row] = right_i - left_i;
+        first_f[row] = cells[row] == 1 ? delta : static_cast<float>(left_i + 1) - left_f;
+        last_f[row] = right_f - static_cast<float>(left_i + cells[row] - 1);
+#pragma unroll
+        for (int c = 0; c < MAXC; ++c) v[row][c] = base[static_cast<size_t>(min(left_i + c, in_h - 1)) * pitch];
+    }
+#pragma unroll
+    for (int row = 0; row < ROWS; ++row) {
+        float value = 0.f;
+        value += cells[row] >= 1 ? v[row][0] * first_f[row] : 0.f;
+#pragma unroll
+        for (int c = 1; c < MAXC; ++c) {
+            const float plain = value + v[row][c], last = value + v[row][c] * last_f[row];
+            value = c < cells[row] - 1 ? plain : (c == cells[row] - 1 ? last : value);
+        }
+        if (ys[row] < out_h) out[static_cast<size_t>(ys[row]) * pitch + x] = value * normalization;
+    }
+}
+
+__global__ __launch_bounds__(256) void resample_y_levels_kernel(const float* __restrict__ in_a, float* __restrict__ out_a,
+                                                                const float* __restrict__ in_b, float* __restrict__ out_b,
+                                                                int in_h, int pitch, ResampleYLevels lv, BatchArg batch)
+{
+    // which level this block belongs to: one batch of scalar loads and sixteen compares (a search loop is a chain of dependent
+    // scalar loads in front of every block), unused entries hold INT_MAX
+    int l = 0;
+#pragma unroll
+    for (int i = 1; i < FLOW2D_RESAMPLE_MAX_LEVELS; ++i) l += static_cast<int>(blockIdx.x) >= lv.first_block[i] ? 1 : 0;
+    const int out_w = lv.out_w[l], out_h = lv.out_h[l], rows_per_thread = lv.rows_per_thread[l];
+    const float delta = lv.delta[l], normalization = lv.normalization[l];
+    const float* __restrict__ in = (batch_plane(batch) ? in_b : in_a) + batch_offset(batch) + lv.col[l];
+    float* __restrict__ out = (batch_plane(batch) ? out_b : out_a) + batch_offset(batch) + static_cast<size_t>(lv.out_row[l]) * pitch;
+    const int block = static_cast<int>(blockIdx.x) - lv.first_block[l], blocks_x = lv.blocks_x[l];
+    const int block_y = block / blocks_x;
+    const int x = (block - block_y * blocks_x) * kBlockX + threadIdx.x;
+    if (x >= out_w) return;
+    const float* base = in + x;
+    // the fine levels: every load of the thread in flight at once (the level's largest cell count is known to the host)
+    const int max_cells = lv.max_cells[l];
+    if (rows_per_thread == 4 && max_cells <= 2) return resample_y_rows<2, 4>(base, out, x, block_y, out_h, in_h, pitch, delta, normalization);
+    if (rows_per_thread == 4 && max_cells <= 4) return resample_y_rows<4, 4>(base, out, x, block_y, out_h, in_h, pitch, delta, normalization);
+    if (rows_per_thread == 4 && max_cells <= 9) return resample_y_rows<9, 4>(base, out, x, block_y, out_h, in_h, pitch, delta, normalization);
+    if (rows_per_thread == 1 && max_cells <= 9) return resample_y_rows<9, 1>(base, out, x, block_y, out_h, in_h, pitch, delta, normalization);
+    for (int row = 0; row < rows_per_thread; ++row) {
+        const int y = (block_y * rows_per_thread + row) * kBlockY + threadIdx.y;
+        if (y >= out_h) return;
+        const float left_f = static_cast<float>(static_cast<unsigned>(y)) * delta;
+        const float right_f = static_cast<float>(static_cast<unsigned>(y) + 1u) * delta;
+        const int left_i = static_cast<int>(floorf(left_f));
+        const int right_i = min(in_h, static_cast<int>(ceilf(right_f)));
+        const int cells = right_i - left_i;
+        const size_t stride = pitch;
+        float value = 0.f;
+        // (the body of resample_kernel<false>: cells summed in order, only the first and the last carry a fraction)
+        if (cells == 1) {
+            value += base[static_cast<size_t>(left_i) * stride] * delta;
+        } else if (cells > 1) {
+            const int last = left_i + cells - 1;
+            value += base[static_cast<size_t>(left_i) * stride] * (static_cast<float>(left_i + 1) - left_f);
+            int k = left_i + 1;
+            for (; k + 32 <= last; k += 32) {
+                float v[32];
+#pragma unroll
+                for (int i = 0; i < 32; ++i) v[i] = base[static_cast<size_t>(k + i) * stride];
+#pragma unroll
+                for (int i = 0; i < 32; ++i) value += v[i];
+            }
+            for (; k < last; k += 8) {  // eight at a time, the last batch partly (its loads clamped, its additions skipped): no cell waits alone
+                float v[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) v[i] = base[static_cast<size_t>(min(k + i, last - 1)) * stride];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const float next = value + v[i];
+                    value = k + i < last ? next : value;
+                }
+            }
+            value += base[static_cast<size_t>(last) * stride] * (right_f - static_cast<float>(last));
+        }
+        out[static_cast<size_t>(y) * pitch + x] = value * normalization;
     }
 }
 
@@ -985,72 +1109,6 @@ int flow2d_resample_x_levels(flow2d_context* ctx, const float* input_a, float* p
     return FLOW2D_OK;
 }
 
-// ---- the y passes of several levels in one launch (round 6) -----------------------------------------------------------
-// After flow2d_resample_x_levels the packed planes hold, for every level, the x-resampled rows at full height; each level's y
-// pass (resample_2d.cu:77-118) reads its column segment.  One launch per level cost a config-3 pair seven launches of 7-39 us,
-// most of them far too small to fill the device; here block rows [first_y[l], first_y[l + 1]) of the grid belong to level l and
-// run the body of resample_kernel<false> on that level's geometry: the same cell sums in the same order, the same bits.
-struct ResampleYLevels {
-    int count;
-    int out_w[FLOW2D_RESAMPLE_MAX_LEVELS], out_h[FLOW2D_RESAMPLE_MAX_LEVELS], col[FLOW2D_RESAMPLE_MAX_LEVELS];
-    int out_row[FLOW2D_RESAMPLE_MAX_LEVELS];   // first row of the level's plane region in the output planes
-    int first_y[FLOW2D_RESAMPLE_MAX_LEVELS + 1];  // grid rows (blockIdx.y) of the level
-    int rows_per_thread[FLOW2D_RESAMPLE_MAX_LEVELS];
-    float delta[FLOW2D_RESAMPLE_MAX_LEVELS], normalization[FLOW2D_RESAMPLE_MAX_LEVELS];
-};
-
-__global__ __launch_bounds__(256) void resample_y_levels_kernel(const float* __restrict__ in_a, float* __restrict__ out_a,
-                                                                const float* __restrict__ in_b, float* __restrict__ out_b,
-                                                                int in_h, int pitch, ResampleYLevels lv, BatchArg batch)
-{
-    int l = 0;
-    while (l + 1 < lv.count && static_cast<int>(blockIdx.y) >= lv.first_y[l + 1]) ++l;
-    const int out_w = lv.out_w[l], out_h = lv.out_h[l], rows_per_thread = lv.rows_per_thread[l];
-    const float delta = lv.delta[l], normalization = lv.normalization[l];
-    const float* __restrict__ in = (batch_plane(batch) ? in_b : in_a) + batch_offset(batch) + lv.col[l];
-    float* __restrict__ out = (batch_plane(batch) ? out_b : out_a) + batch_offset(batch) + static_cast<size_t>(lv.out_row[l]) * pitch;
-    const int x = blockIdx.x * kBlockX + threadIdx.x;
-    if (x >= out_w) return;
-    const int block_y = static_cast<int>(blockIdx.y) - lv.first_y[l];
-    for (int row = 0; row < rows_per_thread; ++row) {
-        const int y = (block_y * rows_per_thread + row) * kBlockY + threadIdx.y;
-        if (y >= out_h) return;
-        const float left_f = static_cast<float>(static_cast<unsigned>(y)) * delta;
-        const float right_f = static_cast<float>(static_cast<unsigned>(y) + 1u) * delta;
-        const int left_i = static_cast<int>(floorf(left_f));
-        const int right_i = min(in_h, static_cast<int>(ceilf(right_f)));
-        const int cells = right_i - left_i;
-        const float* base = in + x;
-        const size_t stride = pitch;
-        float value = 0.f;
-        // (the body of resample_kernel<false>: cells summed in order, only the first and the last carry a fraction)
-        if (cells == 1) {
-            value += base[static_cast<size_t>(left_i) * stride] * delta;
-        } else if (cells > 1) {
-            const int last = left_i + cells - 1;
-            value += base[static_cast<size_t>(left_i) * stride] * (static_cast<float>(left_i + 1) - left_f);
-            int k = left_i + 1;
-            for (; k + 32 <= last; k += 32) {
-                float v[32];
-#pragma unroll
-                for (int i = 0; i < 32; ++i) v[i] = base[static_cast<size_t>(k + i) * stride];
-#pragma unroll
-                for (int i = 0; i < 32; ++i) value += v[i];
-            }
-            for (; k + 8 <= last; k += 8) {
-                float v[8];
-#pragma unroll
-                for (int i = 0; i < 8; ++i) v[i] = base[static_cast<size_t>(k + i) * stride];
-#pragma unroll
-                for (int i = 0; i < 8; ++i) value += v[i];
-            }
-            for (; k < last; ++k) value += base[static_cast<size_t>(k) * stride];
-            value += base[static_cast<size_t>(last) * stride] * (right_f - static_cast<float>(last));
-        }
-        out[static_cast<size_t>(y) * pitch + x] = value * normalization;
-    }
-}
-
 int flow2d_resample_y_levels(flow2d_context* ctx, const float* packed_a, float* output_a, const float* packed_b, float* output_b,
                              size_t in_height, size_t pitch_bytes, size_t level_count, const size_t* out_widths,
                              const size_t* out_heights, const size_t* column_offsets, const size_t* output_rows)
@@ -1066,7 +1124,8 @@ int flow2d_resample_y_levels(flow2d_context* ctx, const float* packed_a, float* 
     const size_t pitch = pitch_bytes / 4;
     ResampleYLevels lv{};
     lv.count = static_cast<int>(level_count);
-    unsigned grid_x = 1, grid_y = 0;
+    long blocks = 0;
+    for (size_t l = 0; l <= FLOW2D_RESAMPLE_MAX_LEVELS; ++l) lv.first_block[l] = 0x7fffffff;
     for (size_t l = 0; l < level_count; ++l) {
         if (out_widths[l] == 0 || out_heights[l] == 0 || out_heights[l] >= (1u << 30) || column_offsets[l] + out_widths[l] > pitch ||
             output_rows[l] >= (1u << 30))
@@ -1080,14 +1139,16 @@ int flow2d_resample_y_levels(flow2d_context* ctx, const float* packed_a, float* 
         const float out_n = static_cast<float>(out_heights[l]), in_n = static_cast<float>(in_height);
         lv.delta[l] = in_n / out_n, lv.normalization[l] = out_n / in_n;
         lv.rows_per_thread[l] = out_widths[l] * out_heights[l] >= (size_t)512 * 512 ? 4 : 1;
-        lv.first_y[l] = static_cast<int>(grid_y);
-        grid_y += static_cast<unsigned>(flow2d::div_up(flow2d::div_up(out_heights[l], lv.rows_per_thread[l]), kBlockY));
-        grid_x = std::max(grid_x, static_cast<unsigned>(flow2d::div_up(out_widths[l], kBlockX)));
+        // cells of output g = ceil((g + 1) delta) - floor(g delta) in float arithmetic: at most ceil(delta) + 1 (+1 for the roundings)
+        lv.max_cells[l] = lv.delta[l] == std::floor(lv.delta[l]) && lv.delta[l] < 1e6f ? static_cast<int>(lv.delta[l])
+                                                                                      : static_cast<int>(std::min(std::ceil(lv.delta[l]) + 2.f, 1e9f));
+        lv.first_block[l] = static_cast<int>(blocks);
+        lv.blocks_x[l] = static_cast<int>(flow2d::div_up(out_widths[l], kBlockX));
+        blocks += static_cast<long>(lv.blocks_x[l]) * static_cast<long>(flow2d::div_up(flow2d::div_up(out_heights[l], lv.rows_per_thread[l]), kBlockY));
+        if (blocks >= 0x7fffffffl) return FLOW2D_ERR_UNSUPPORTED;
     }
-    lv.first_y[level_count] = static_cast<int>(grid_y);
-    if (grid_y > 65535u) return FLOW2D_ERR_UNSUPPORTED;
     const unsigned planes = pair ? 2 : 1;
-    resample_y_levels_kernel<<<dim3(grid_x, grid_y, flow2d::batch_z(ctx, planes)), dim3(kBlockX, kBlockY), 0, ctx->stream>>>(
+    resample_y_levels_kernel<<<dim3(static_cast<unsigned>(blocks), 1, flow2d::batch_z(ctx, planes)), dim3(kBlockX, kBlockY), 0, ctx->stream>>>(
         packed_a, output_a, packed_b, output_b, static_cast<int>(in_height), static_cast<int>(pitch), lv, flow2d::batch_arg(ctx, planes));
     FLOW2D_CHECK_LAUNCH();
     return FLOW2D_OK;

@@ -639,15 +639,16 @@ int launch_phi_ksi(flow2d_context* ctx, const float* f0, const float* f1, const 
 
 // levels of 8 Mpixel and more (below, the ten planes sit in the Infinity Cache and the short-lived waves of the tile forms are faster)
 static bool sweep_streams(size_t w, size_t h) { return w >= 2 * kSweepValid && h >= 8 && w * h >= kSweepStreamMinPixels; }
-// (rows per strip, round 6: 16 / 32 / 64 rows take 155.6 / 152.7-155.8 / 165-167 us per 4096^2 sweep and fetch 718 / 655 / 626 MB --
-//  the halo rows of a strip are re-read by its neighbour -- for 537 MB of algorithmic reads: 32 costs no time and moves 9 % less,
-//  64 leaves too few waves per SIMD; profiles/r06_experiments/per_sweep_strip_rows_ab.txt)
+// (rows per strip, round 6: 16 / 32 / 64 rows fetch 718 / 655 / 626 MB per 4096^2 sweep -- the halo rows of a strip are re-read by
+//  its neighbour -- for 537 MB of algorithmic reads, and take 155.6 / 152.7-155.8 / 165-167 us on one box, 158-161 / 162-165 us on
+//  another (8192^2: 555-573 / 569-602 us): the bytes 32 rows save come out of the caches, the time they cost does not -- 16 stays;
+//  profiles/r06_experiments/per_sweep_strip_rows_ab*.txt)
 static unsigned sweep_strip_rows()
 {
 #ifdef FLOW2D_DEV_BUILD  // (developer builds: strip height override, a multiple of 16)
     if (const char* e = std::getenv("FLOW2D_SWEEP_ROWS")) return std::max(16, std::atoi(e) / 16 * 16);
 #endif
-    return 32;
+    return 16;
 }
 static XcdTiles sweep_stream_tiles(size_t w, size_t h, int constancy)
 {
@@ -730,7 +731,12 @@ int launch_sor_iteration(flow2d_context* ctx, int constancy, const float* f0, co
     }
     for (int colour = 0; colour < 2; ++colour) {
         if (sweep_streams(w, h)) {
-            // (round 5) the half-sweep as a streaming strip kernel, in place: the same strips as the Jacobi form
+            // (round 5) the half-sweep as a streaming strip kernel, in place: the same strips as the Jacobi form.
+            // Invariant of the in-place form (tdu == du, tdv == dv): the halo lanes and halo rows of a strip load pixels
+            // of the colour being relaxed that a NEIGHBOURING wave stores in this launch -- formally a race, in effect none: a
+            // relaxed pixel's update reads its four neighbours, which have the OTHER colour and are only read in this launch, and
+            // its own old value, which the owning wave loads itself; own-colour values from halo lanes / rows are dead (the kernel's
+            // du / dv pointers carry no __restrict__, so the compiler may not merge or hoist those loads across the stores).
             const XcdTiles tiles = sweep_stream_tiles(w, h, constancy);
             const SweepPlanes planes{f0, f1, u, v, du, dv, phi, ksi};
             const dim3 grid(xcd_grid(tiles));

@@ -170,6 +170,10 @@ static FusedPlan fused_plan_search(const flow2d_context* ctx, size_t w, size_t h
         const double ri_real = ((double)h + 2.0 * halo - 2.0 * halo / kEdgeCost) / ((double)(ny - 2) + 2.0 / kEdgeCost);
         long re = (long)std::floor((ri_real + halo) / kEdgeCost - halo);
         if (re < 1 || 2 * re >= (long)h) continue;
+        // (the kernel sends a strip to the border body when it ends within halo + 4 rows of the image's last row -- its interior
+        //  body prefetches unclamped --, so with border strips that short the second strip from the bottom would run the border
+        //  body at interior length and outlast the plan's estimate: ADVICE r05)
+        if (re <= (long)inner + 1 + 3) continue;
         const long ri = ((long)h - 2 * re + (ny - 3)) / (ny - 2);
         if (ri < re) continue;
         const long ny_edge = ((long)h + re - 1) / re;

@@ -9,7 +9,7 @@ for rep in 1 2; do
     for wl in $WLS; do
         for so in $LIBS; do
             FLOW2D_HIP_LIB="$R/$so" timeout -k 10 300 python3 bench.py --workload $wl --no-pmc --no-oracle-check --no-host-entry-leg \
-                --no-cpu-baseline --no-reference-baseline --no-batch-leg 2>/dev/null |
+                --no-cpu-baseline --no-reference-baseline --no-batch-leg --no-probe-builds 2>/dev/null |
                 python3 -c "
 import json,sys
 d=json.loads(sys.stdin.read())

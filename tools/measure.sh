@@ -31,10 +31,10 @@ print('$wl', 'value', d['value'], 'pairs/s', d['pairs_per_s'], 'single', d['pair
         for wl in $WLS; do
             rm -rf "$OUT/trace_$wl"
             (cd /tmp && timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_$wl" -- \
-                python3 "$R/bench.py" --workload $wl --no-pmc --no-oracle-check --no-host-entry-leg --no-cpu-baseline --no-reference-baseline --no-batch-leg --steps 6 --warmup 2 --pipeline 1 --step-group 1 --no-graph \
+                python3 "$R/bench.py" --workload $wl --no-pmc --no-oracle-check --no-host-entry-leg --no-cpu-baseline --no-reference-baseline --no-batch-leg --no-probe-builds --steps 6 --warmup 2 --pipeline 1 --step-group 1 --no-graph \
                 > "$OUT/${ROUND}_${wl}_bench_line_under_rocprof.json" 2> "$OUT/trace_$wl.err") || { tail -5 "$OUT/trace_$wl.err"; exit 1; }
-            python3 tools/summarize_trace.py "$OUT"/trace_$wl/*/*kernel_trace.csv 40 > "$OUT/${ROUND}_${wl}_by_grid.txt"
-            cp "$OUT"/trace_$wl/*/*kernel_stats.csv "$OUT/${ROUND}_${wl}_kernel_stats.csv"
+            python3 tools/summarize_trace.py "$(ls -S "$OUT"/trace_$wl/*/*kernel_trace.csv | head -1)" 40 > "$OUT/${ROUND}_${wl}_by_grid.txt"
+            cp "$(ls -S "$OUT"/trace_$wl/*/*kernel_stats.csv | head -1)" "$OUT/${ROUND}_${wl}_kernel_stats.csv"
             rm -rf "$OUT/trace_$wl"
             head -4 "$OUT/${ROUND}_${wl}_by_grid.txt"
         done ;;
@@ -42,9 +42,9 @@ print('$wl', 'value', d['value'], 'pairs/s', d['pairs_per_s'], 'single', d['pair
         export TMPDIR=/tmp
         rm -rf "$OUT/trace_default"
         (cd /tmp && timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_default" -- \
-            python3 "$R/bench.py" --no-pmc > "$OUT/${ROUND}_default_command_bench_line_under_rocprof.json" 2> "$OUT/trace_default.err") || { tail -5 "$OUT/trace_default.err"; exit 1; }
-        python3 tools/summarize_trace.py "$OUT"/trace_default/*/*kernel_trace.csv 30 > "$OUT/${ROUND}_default_command_by_grid.txt"
-        cp "$OUT"/trace_default/*/*kernel_stats.csv "$OUT/${ROUND}_default_command_kernel_stats.csv"
+            python3 "$R/bench.py" --no-pmc --no-probe-builds > "$OUT/${ROUND}_default_command_bench_line_under_rocprof.json" 2> "$OUT/trace_default.err") || { tail -5 "$OUT/trace_default.err"; exit 1; }
+        python3 tools/summarize_trace.py "$(ls -S "$OUT"/trace_default/*/*kernel_trace.csv | head -1)" 30 > "$OUT/${ROUND}_default_command_by_grid.txt"
+        cp "$(ls -S "$OUT"/trace_default/*/*kernel_stats.csv | head -1)" "$OUT/${ROUND}_default_command_kernel_stats.csv"
         rm -rf "$OUT/trace_default"
         head -5 "$OUT/${ROUND}_default_command_by_grid.txt" ;;
     esac

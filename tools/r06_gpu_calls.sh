@@ -211,4 +211,41 @@ fuzz() {  # random pipelines against the oracle (AUTO, strips forced) and agains
     return 0
 }
 
+call13() {  # per-sweep strips of 16 / 32 rows again, 4096^2 and 8192^2, twice round (the 8192^2 line of the measurement pass read slower with 32)
+    /bin/true
+    for rep in 1 2; do
+        for rows in 16 32; do
+            for n in 4096 8192; do
+                echo "== $n^2, strips of $rows rows"
+                FLOW2D_SWEEP_ROWS=$rows FLOW2D_HIP_LIB=$(lib dev2) timeout -k 10 120 python3 tools/time_per_sweep.py $n $n 2>&1 | grep -E "grey|gradient" || return 1
+            done
+        done
+    done
+}
+
+call14() {  # the y pass of all levels with every load of a thread in flight: tests, then its time in the traces of configs 3, 5, 4, 2
+    timeout -k 10 900 python3 -m pytest tests/test_gpu_kernels.py tests/test_gpu_flow.py tests/test_gpu_fused.py -x -q > "$OUT/call14_tests.log" 2>&1 || { tail -30 "$OUT/call14_tests.log"; return 1; }
+    tail -1 "$OUT/call14_tests.log"
+    WLS="cfg3_4096_gradient cfg5_8192_grey cfg4_1080p_batch cfg2_1024_grey" ROUND=r06b bash tools/measure.sh trace > "$OUT/call14_trace.log" 2>&1 || { tail "$OUT/call14_trace.log"; return 1; }
+    grep -h "resample_y_levels\|fused_outer_kernel<5, 1, true, false, false>     131072" "$OUT"/r06b_*_by_grid.txt
+}
+
+call15() {  # the y pass of all levels level by level; blur prefetch depth and registration gather order A/B
+    timeout -k 10 120 python3 tools/time_y_levels.py 4096 7 || return 1
+    timeout -k 10 120 python3 tools/time_y_levels.py 8192 11 || return 1
+    for rep in 1 2; do
+        for v in ops_base ops_b6 ops_b8 ops_reg; do
+            echo "== $v"
+            FLOW2D_HIP_LIB=$(lib $v) timeout -k 10 120 python3 tools/time_ops.py 4096 2>&1 | grep -E "gaussian|registration" || return 1
+        done
+    done
+}
+
+call16() {  # y-levels kernel with a flat grid, one batch of scalar loads, no lone cells: tests and its time level by level
+    timeout -k 10 600 python3 -m pytest tests/test_gpu_kernels.py -x -q -k "resample or registration or gauss or convolution" > "$OUT/call16_tests.log" 2>&1 || { tail -30 "$OUT/call16_tests.log"; return 1; }
+    tail -1 "$OUT/call16_tests.log"
+    timeout -k 10 120 python3 tools/time_y_levels.py 4096 7 || return 1
+    timeout -k 10 120 python3 tools/time_y_levels.py 8192 11 || return 1
+}
+
 "$@"
