@@ -248,4 +248,16 @@ call16() {  # y-levels kernel with a flat grid, one batch of scalar loads, no lo
     timeout -k 10 120 python3 tools/time_y_levels.py 8192 11 || return 1
 }
 
+call17() {  # up-sampling kernel with all loads of a thread in flight: tests, then against the previous commit's library
+    timeout -k 10 600 python3 -m pytest tests/test_gpu_kernels.py tests/test_gpu_reference.py -x -q -k "resample" > "$OUT/call17_tests.log" 2>&1 || { tail -30 "$OUT/call17_tests.log"; return 1; }
+    tail -1 "$OUT/call17_tests.log"
+    for rep in 1 2; do
+        for so in ab/ops_base.so cuda-flow2d_amd/csrc/libflow2d_hip.so; do
+            echo "== $so"
+            FLOW2D_HIP_LIB="$R/$so" timeout -k 10 120 python3 tools/time_ops.py 4096 2>&1 | grep -E "x and y from" || return 1
+            FLOW2D_HIP_LIB="$R/$so" timeout -k 10 120 python3 tools/time_ops.py 2048 2>&1 | grep -E "x and y from" || return 1
+        done
+    done
+}
+
 "$@"
