@@ -281,12 +281,15 @@ int launch_fused_outer(flow2d_context* ctx, int constancy, const float* f0, cons
     // A context that runs alone (flow2d_context_set_lone) and a launch of at most one workgroup per CU -- one wave per SIMD: nothing
     // to share issue turns with -- take the build with packed arithmetic: fewer, wider instructions (the same IEEE operations).
     const bool packed_build = ctx->lone && (long)plan.blocks * (long)instances_per_launch <= (long)(ctx->num_cus > 0 ? ctx->num_cus : 256);
+    rc = 1;
     if (packed_build && constancy == FLOW2D_CONSTANCY_GRADIENT)
         rc = pow2 ? fused_launch_g1_p1_k(in, grid, ctx->stream, a) : fused_launch_g1_p0_k(in, grid, ctx->stream, a);
     else if (packed_build && constancy == FLOW2D_CONSTANCY_GRADIENT_UNTILED)
         rc = pow2 ? fused_launch_g2_p1_k(in, grid, ctx->stream, a) : fused_launch_g2_p0_k(in, grid, ctx->stream, a);
     else if (packed_build && constancy != FLOW2D_CONSTANCY_LOG_DERIVATIVES)
         rc = pow2 ? fused_launch_g0_p1_k(in, grid, ctx->stream, a) : fused_launch_g0_p0_k(in, grid, ctx->stream, a);
+    if (rc == 0)  // (the packed build ran; it holds no kernels for continued sweeps: those fall through to the pipeline's build)
+        ;
     else if (constancy == FLOW2D_CONSTANCY_GRADIENT)
         rc = pow2 ? fused_launch_g1_p1(in, grid, ctx->stream, a) : fused_launch_g1_p0(in, grid, ctx->stream, a);
     else if (constancy == FLOW2D_CONSTANCY_GRADIENT_UNTILED)

@@ -20,7 +20,12 @@ namespace flow2d {
 int FLOW2D_FUSED_INSTANCE_NAME(FLOW2D_FUSED_INSTANCE_GRAD, FLOW2D_FUSED_INSTANCE_POW2)(int inner, dim3 grid, hipStream_t stream,
                                                                                    const FusedArgs& a)
 {
+#ifdef FLOW2D_FUSED_INSTANCE_LONE  // (ten kernels instead of twenty: a launch that continues an outer iteration's sweeps takes the pipeline's build)
+    if (a.continue_sweeps) return 1;
+    return launch_for_inner_cont<FLOW2D_FUSED_INSTANCE_GRAD, FLOW2D_FUSED_INSTANCE_POW2 != 0, false>(inner, grid, stream, a);
+#else
     return launch_for_inner<FLOW2D_FUSED_INSTANCE_GRAD, FLOW2D_FUSED_INSTANCE_POW2 != 0>(inner, grid, stream, a);
+#endif
 }
 
 }  // namespace flow2d
