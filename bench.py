@@ -729,15 +729,18 @@ def host_entry_leg(job, batch, torch, steps):
     # device-resident region's above 512^2 (4096^2, groups of 8 / 2: 273 / 322 pairs/s; 1024^2, 32 / 8: 2 966 / 3 724; 584 x 388
     # is launch-bound either way: 32 / 8: 2 122 / 1 769)
     N = job.step_group if w * h <= 512 * 512 else min(job.step_group, 8 if w * h <= 1024 * 1024 else 4 if w * h <= 2048 * 2048 else 2)
-    n_sets = 2 * job.n_lanes * N
+    n_sets = 2 * max(job.n_lanes, job.args.host_entry_lanes or 0, 6) * N
     steps = max(N, steps // N * N)
     outs = [([flow2d.HostImage(w, h, True) for _ in range(G)], [flow2d.HostImage(w, h, True) for _ in range(G)])
             for _ in range(n_sets)]
     images = f0s + f1s + [q for us, vs in outs for q in us + vs]
     pinned = all(q.pinned for q in images)
     # (the host-image entry takes whole lock-step groups only: a smaller group needs a batch object of its own)
-    own_runner = job.step_group > 1 and N != job.step_group
-    runner = flow2d.OpticalFlowBatch(w, h, cfg["constancy"], lanes=job.n_lanes, device=job.local_rank, group_size=N) if own_runner else job.runner
+    # (with copies inside the bracket a lane spends a third of its cycle transferring: six lanes keep four computing -- 4096^2,
+    #  4 / 6 / 8 lanes: 305 / 318-319 / 297-299 pairs/s, round 6; small frames are launch-bound and keep the region's lanes)
+    host_lanes = job.args.host_entry_lanes or (6 if w * h >= 2048 * 2048 and job.n_lanes == 4 else job.n_lanes)
+    own_runner = (job.step_group > 1 and N != job.step_group) or host_lanes != job.n_lanes
+    runner = flow2d.OpticalFlowBatch(w, h, cfg["constancy"], lanes=host_lanes, device=job.local_rank, group_size=N) if own_runner else job.runner
     runner.use_graph(not job.args.no_graph)
 
     def call(c):
@@ -745,7 +748,7 @@ def host_entry_leg(job, batch, torch, steps):
         us = [q for j in range(N) for q in outs[(c * N + j) % n_sets][0]]
         vs = [q for j in range(N) for q in outs[(c * N + j) % n_sets][1]]
         # one entry (a pair, or a lock-step group) per call, calls rotate over the lanes; lanes mode: the pairs spread from lane 0
-        runner.compute_flow_batch(f0s * N, f1s * N, us, vs, job.params, first_lane=(c % job.n_lanes) if job.rotate else 0)
+        runner.compute_flow_batch(f0s * N, f1s * N, us, vs, job.params, first_lane=(c % host_lanes) if job.rotate else 0)
 
     def barrier():
         batch.barrier()
@@ -772,7 +775,7 @@ def host_entry_leg(job, batch, torch, steps):
             "bracket": "host Data2D frames in -> host Data2D flows out (upload, pyramid, download), as the reference's "
                        "own timer brackets ComputeFlow",
             "host_path": "OpticalFlowBatch2D::ComputeFlowBatch (C++): upload, pyramid (graph replay), download on each of "
-                         "%d lanes' own stream; the lanes overlap" % job.n_lanes,
+                         "%d lanes' own stream; the lanes overlap" % host_lanes,
             "host_memory": "page-locked Data2D" if pinned else "pageable Data2D (pinned allocation failed)",
             "pcie_bytes_per_pair": bytes_per_pair,
             "pcie_gbs_each_way": round(pairs / job.world * bytes_per_pair / 2 / elapsed / 1e9, 2),
@@ -1123,6 +1126,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-reference-baseline", action="store_true")
     ap.add_argument("--no-batch-leg", action="store_true")
+    ap.add_argument("--host-entry-lanes", type=int, default=0, help=argparse.SUPPRESS)  # (developer A/B: lanes of the host-entry leg's own runner)
     ap.add_argument("--no-probe-builds", action="store_true", help="skip the memory-only / compute-only timing probes (child processes on ab/*.so)")
     ap.add_argument("--batch-leg-last", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--no-oracle-check", action="store_true",

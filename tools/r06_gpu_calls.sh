@@ -260,4 +260,16 @@ call17() {  # up-sampling kernel with all loads of a thread in flight: tests, th
     done
 }
 
+call18() {  # lanes of the host-entry leg (uploads and downloads inside the bracket): 4 (as the device-resident region) / 6 / 8
+    for rep in 1 2; do
+        for lanes in 4 6 8; do
+            timeout -k 10 300 python3 bench.py --no-pmc --no-oracle-check --no-cpu-baseline --no-reference-baseline --no-batch-leg --no-probe-builds --host-entry-lanes $lanes 2>"$OUT/call18.err" |
+                python3 -c "
+import json,sys
+d=json.loads(sys.stdin.read()); h=d['host_entry']
+print('host-entry lanes $lanes: incl. H<->D %.1f pairs/s (%.1f GB/s each way), device-resident %.1f' % (h['pairs_per_s'], h['pcie_gbs_each_way'], d['pairs_per_s']))" || { tail -5 "$OUT/call18.err"; return 1; }
+        done
+    done
+}
+
 "$@"
