@@ -287,3 +287,36 @@ def test_launch_order_is_a_permutation_of_the_plan(ctx, inner):
         if (w, h, inst, inner) == (4096, 4096, 1, 5):
             side = [int(((order[k::8, 0] == 0) | (order[k::8, 0] == blocks_x - 1)).sum()) for k in range(8)]
             assert sum(side) == 62 and max(side) - min(side) <= 1, side
+
+
+def test_clock_probe_reports_a_plausible_clock_per_xcd(flow2d, ctx):
+    """flow2d_clock_probe_start / _read: one sleeping wave per XCD brackets a stretch of time with the constant 100 MHz clock and the
+    shader clock -- the figure bench.py puts beside the strip kernel's launch time (the chip holds 1.6-2.4 GHz depending on the
+    power the running kernels draw).  Alone on the device the probe sees the idle-to-boost range on every XCD a wave landed on."""
+    probe = flow2d.Context(0)
+    try:
+        probe.clock_probe_start(300.0)
+        ghz = probe.clock_probe_read()
+    finally:
+        probe.close()
+    seen = [g for g in ghz if g > 0]
+    assert len(ghz) == 8 and len(seen) >= 4, ghz       # eight workgroups dealt over the XCDs
+    assert all(0.1 < g < 3.0 for g in seen), ghz
+    with pytest.raises(flow2d.Flow2DError):
+        ctx.clock_probe_start(0.0)
+
+
+@pytest.mark.parametrize("constancy", [0, 1])
+def test_lone_context_uses_the_packed_build_with_the_same_bits(flow2d, ctx, oracle, constancy):
+    """flow2d_context_set_lone: a strip launch of at most one workgroup per CU takes the build of the strip kernel with packed
+    arithmetic (no partner wave to share issue turns with) -- the same IEEE operations, so the same bits as the pipeline's build
+    and the oracle, including a launch that continues an outer iteration's sweeps (no packed kernels for those: falls through)."""
+    w, h = 1024, 512   # 20 strips wide, few strips per column: under one workgroup per CU
+    f0, f1, u, v, _, _ = level_fields(oracle, w, h, 21)
+    results = []
+    for lone in (False, True):
+        ctx.set_lone(lone)
+        for inner in (5, 8):
+            a, b, odu, odv = fused_vs_oracle(ctx, oracle, f0, f1, u, v, w, h, w, h, np.float32(1.0), np.float32(1.0), 35.0, 2, inner, constancy)
+            assert np.array_equal(bits(a), bits(odu)) and np.array_equal(bits(b), bits(odv)), (lone, inner)
+    ctx.set_lone(False)
