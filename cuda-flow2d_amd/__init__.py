@@ -115,6 +115,7 @@ def hip_lib():
         L.flow2d_gaussian_blur.argtypes = [vp, vp, vp, sz, sz, sz, C.POINTER(f), i]
         L.flow2d_median_2d.argtypes = [vp, vp, sz, sz, sz, sz, vp]
         L.flow2d_registration_2d.argtypes = [vp, vp, vp, vp, vp, sz, sz, sz, f, f, vp]
+        L.flow2d_upsample_registration_2d.argtypes = [vp, vp, vp, sz, sz, vp, vp, vp, vp, sz, sz, sz, f, f, vp]
         L.flow2d_resample_x.argtypes = [vp, vp, vp, sz, sz, sz, sz]
         L.flow2d_resample_y.argtypes = [vp, vp, vp, sz, sz, sz, sz]
         L.flow2d_add_2d_pair.argtypes = [vp, vp, vp, vp, vp, sz, sz, sz]
@@ -365,6 +366,13 @@ class Context:
         _check(hip_lib().flow2d_resample_xy_pair(self.handle, src.ptr, dst.ptr, src_b.ptr if src_b else None,
                                                  dst_b.ptr if dst_b else None, in_w, in_h, out_w, out_h, src.pitch),
                "flow2d_resample_xy_pair")
+
+    def upsample_registration(self, u, v, in_w, in_h, out_u, out_v, f0, f1, w, h, hx, hy, out):
+        """(u, v) of the previous level resampled to w x h into out_u / out_v and f1 warped by them into `out`: one launch.
+        u = v = None with in_w = in_h = 0 (the coarsest level): out_u = out_v = 0 and the warp by that."""
+        _check(hip_lib().flow2d_upsample_registration_2d(self.handle, u.ptr if u else None, v.ptr if v else None, in_w, in_h, out_u.ptr,
+                                                         out_v.ptr, f0.ptr, f1.ptr,
+                                                         w, h, f0.pitch, hx, hy, out.ptr), "flow2d_upsample_registration_2d")
 
     def resample_x_levels(self, src, packed, in_w, h, widths, columns, src_b=None, packed_b=None):
         """x pass for several output widths in one trip over `src`; level l lands in columns[l] .. of `packed`."""

@@ -7,6 +7,7 @@
 // All arithmetic follows the reference's operation order (no FMA contraction) -- see each kernel.
 #include <algorithm>
 #include <cmath>
+#include <type_traits>
 #include <utility>
 
 #include "common.hpp"
@@ -313,29 +314,29 @@ struct ResampleXY {
     float delta_x, norm_x, delta_y, norm_y;
 };
 
-__global__ __launch_bounds__(256) void resample_xy_kernel(const float* __restrict__ in_a, float* __restrict__ out_a,
-                                                          const float* __restrict__ in_b, float* __restrict__ out_b,
-                                                          int out_w, int out_h, int in_w, int in_h, int pitch,
-                                                          ResampleXY k, BatchArg batch)
+// the x cells of one output column (resample_2d.cu:46-55): worked out once per thread
+struct ResampleXCells {
+    int left_i, cells_x;
+    float first_x, last_x;
+};
+__device__ __forceinline__ ResampleXCells resample_x_cells(int x, int in_w, const ResampleXY& k)
 {
-    const float* __restrict__ in = (batch_plane(batch) ? in_b : in_a) + batch_offset(batch);
-    float* __restrict__ out = (batch_plane(batch) ? out_b : out_a) + batch_offset(batch);
-    const int x = blockIdx.x * kBlockX + threadIdx.x;
-    if (x >= out_w) return;
-    // the x cells of this output column (resample_2d.cu:46-55)
     const float left_f = static_cast<float>(static_cast<unsigned>(x)) * k.delta_x;
     const float right_f = static_cast<float>(static_cast<unsigned>(x) + 1u) * k.delta_x;
-    const int left_i = static_cast<int>(floorf(left_f));
-    const int cells_x = min(in_w, static_cast<int>(ceilf(right_f))) - left_i;
-    const float first_x = cells_x == 1 ? k.delta_x : static_cast<float>(left_i + 1) - left_f;
-    const float last_x = cells_x == 1 ? k.delta_x : right_f - static_cast<float>(left_i + cells_x - 1);
-    // a thread walks kResampleXYRows output rows of its column (a wave that lives for one output each spends its time
-    // being launched: 80 -> 51 us for the two 4096^2 flow planes; all thirty-two loads of the eight rows issued before the first is
-    // used: 51 -> 61 us, round 6 -- the inputs are cache hits, the kernel is bound by its stores)
-    for (int i = 0; i < kResampleXYRows; ++i) {
-    const int y = (blockIdx.y * kResampleXYRows + i) * kBlockY + threadIdx.y;
-    if (y >= out_h) return;
-    // the y pass of resample_2d.cu:77-118 over x-pass values computed on the spot
+    ResampleXCells c;
+    c.left_i = static_cast<int>(floorf(left_f));
+    c.cells_x = min(in_w, static_cast<int>(ceilf(right_f))) - c.left_i;
+    c.first_x = c.cells_x == 1 ? k.delta_x : static_cast<float>(c.left_i + 1) - left_f;
+    c.last_x = c.cells_x == 1 ? k.delta_x : right_f - static_cast<float>(c.left_i + c.cells_x - 1);
+    return c;
+}
+
+// output (column of `c`, row y): the y pass of resample_2d.cu:77-118 over x-pass values computed on the spot
+__device__ __forceinline__ float resample_xy_value(const float* __restrict__ in, const ResampleXCells& c, int y, int in_w, int in_h,
+                                                   int pitch, const ResampleXY& k)
+{
+    const int left_i = c.left_i, cells_x = c.cells_x;
+    const float first_x = c.first_x, last_x = c.last_x;
     const float top_f = static_cast<float>(static_cast<unsigned>(y)) * k.delta_y;
     const float bottom_f = static_cast<float>(static_cast<unsigned>(y) + 1u) * k.delta_y;
     const int top_i = static_cast<int>(floorf(top_f));
@@ -373,7 +374,26 @@ __global__ __launch_bounds__(256) void resample_xy_kernel(const float* __restric
             value += (x_pass * k.norm_x) * frac;
         }
     }
-    out[static_cast<size_t>(y) * pitch + x] = value * k.norm_y;
+    return value * k.norm_y;
+}
+
+__global__ __launch_bounds__(256) void resample_xy_kernel(const float* __restrict__ in_a, float* __restrict__ out_a,
+                                                          const float* __restrict__ in_b, float* __restrict__ out_b,
+                                                          int out_w, int out_h, int in_w, int in_h, int pitch,
+                                                          ResampleXY k, BatchArg batch)
+{
+    const float* __restrict__ in = (batch_plane(batch) ? in_b : in_a) + batch_offset(batch);
+    float* __restrict__ out = (batch_plane(batch) ? out_b : out_a) + batch_offset(batch);
+    const int x = blockIdx.x * kBlockX + threadIdx.x;
+    if (x >= out_w) return;
+    const ResampleXCells c = resample_x_cells(x, in_w, k);
+    // a thread walks kResampleXYRows output rows of its column (a wave that lives for one output each spends its time
+    // being launched: 80 -> 51 us for the two 4096^2 flow planes; all thirty-two loads of the eight rows issued before the first is
+    // used: 51 -> 61 us, round 6 -- the inputs are cache hits, the kernel is bound by its stores)
+    for (int i = 0; i < kResampleXYRows; ++i) {
+        const int y = (blockIdx.y * kResampleXYRows + i) * kBlockY + threadIdx.y;
+        if (y >= out_h) return;
+        out[static_cast<size_t>(y) * pitch + x] = resample_xy_value(in, c, y, in_w, in_h, pitch, k);
     }
 }
 
@@ -675,6 +695,26 @@ __global__ __launch_bounds__(256) void resample_x_levels_pow2_kernel(const float
 //  kRegistrationRows pixels of its column: their flow values are requested together, then the four frame values each.)
 constexpr int kRegistrationRows = 4;
 
+// one pixel of registration_2d.cu:34-73 (c = its offset in the planes)
+__device__ __forceinline__ float registered_value(const float* __restrict__ f0, const float* __restrict__ f1, int gx, int gy, size_t c,
+                                                  float uu, float vv, int w, int h, int pitch, float inv_hx, float inv_hy)
+{
+    const float x_f = static_cast<float>(gx) + (uu * inv_hx);
+    const float y_f = static_cast<float>(gy) + (vv * inv_hy);
+    if ((x_f < 0.f) || (x_f > static_cast<float>(w - 1)) || (y_f < 0.f) || (y_f > static_cast<float>(h - 1)) || isnan(x_f) ||
+        isnan(y_f))
+        return f0[c];
+    const int x = static_cast<int>(floorf(x_f));
+    const int y = static_cast<int>(floorf(y_f));
+    const float dx = x_f - static_cast<float>(x);
+    const float dy = y_f - static_cast<float>(y);
+    const int x1 = min(w - 1, x + 1);
+    const int y1 = min(h - 1, y + 1);
+    const float* r0 = f1 + static_cast<size_t>(y) * pitch;
+    const float* r1 = f1 + static_cast<size_t>(y1) * pitch;
+    return (1.f - dx) * (1.f - dy) * r0[x] + (dx) * (1.f - dy) * r0[x1] + (1.f - dx) * (dy)*r1[x] + (dx) * (dy)*r1[x1];
+}
+
 __global__ __launch_bounds__(256) void registration_kernel(const float* __restrict__ f0, const float* __restrict__ f1,
                                                            const float* __restrict__ u, const float* __restrict__ v,
                                                            int w, int h, int pitch, float inv_hx, float inv_hy,
@@ -702,25 +742,84 @@ __global__ __launch_bounds__(256) void registration_kernel(const float* __restri
         const int gy = (blockIdx.y * kRegistrationRows + i) * kBlockY + threadIdx.y;
         if (gy >= h) return;
         const size_t c = static_cast<size_t>(gy) * pitch + gx;
-        const float x_f = static_cast<float>(gx) + (uu[i] * inv_hx);
-        const float y_f = static_cast<float>(gy) + (vv[i] * inv_hy);
-        float value;
-        if ((x_f < 0.f) || (x_f > static_cast<float>(w - 1)) || (y_f < 0.f) || (y_f > static_cast<float>(h - 1)) ||
-            isnan(x_f) || isnan(y_f)) {
-            value = f0[c];
-        } else {
-            const int x = static_cast<int>(floorf(x_f));
-            const int y = static_cast<int>(floorf(y_f));
-            const float dx = x_f - static_cast<float>(x);
-            const float dy = y_f - static_cast<float>(y);
-            const int x1 = min(w - 1, x + 1);
-            const int y1 = min(h - 1, y + 1);
-            const float* r0 = f1 + static_cast<size_t>(y) * pitch;
-            const float* r1 = f1 + static_cast<size_t>(y1) * pitch;
-            value = (1.f - dx) * (1.f - dy) * r0[x] + (dx) * (1.f - dy) * r0[x1] + (1.f - dx) * (dy)*r1[x] +
-                    (dx) * (dy)*r1[x1];
+        out[c] = registered_value(f0, f1, gx, gy, c, uu[i], vv[i], w, h, pitch, inv_hx, inv_hy);
+    }
+}
+
+// The flow of the previous level brought to this level's size AND frame 1 warped by it, in one launch (round 6;
+// optical_flow_2d.cpp:320-345 followed by :351-365): a thread evaluates (u, v) of its pixels exactly as resample_xy_kernel does,
+// stores them and hands them to the warp of the same pixels instead of a second kernel reading them back -- one launch and 8 bytes
+// per pixel less at every level but the coarsest; the same operations on the same values, the same bits.
+// DOUBLE: the level is exactly twice the previous one in both directions (every level of a 0.5 pyramid over power-of-two frames, the fine
+// levels of most others).  Then delta = 0.5 and every output has ONE cell in either direction -- g * 0.5 and (g + 1) * 0.5 are exact,
+// ceil((g + 1) / 2) - floor(g / 2) = 1 for every g -- so of the general form's four loads per plane and pixel only the first one counts,
+// and the four rows of a thread, taken ADJACENT here (4j .. 4j + 3; h is even: whole pairs are inside the level or below it), share two
+// input rows: 4 loads instead of 32 in front of the thread's sixteen gathers (4096^2: 120 -> see profiles/r06_experiments).  The value
+// goes through the general form's operations for one cell -- ((0 + a * delta_x) * norm_x, 0 + that * delta_y, * norm_y) -- bit for bit.
+// ZERO: the coarsest level -- no previous flow: (u, v) = 0 is stored and warped by (the reference fills both planes with two memsets
+// of the whole container first, optical_flow_2d.cpp:307-318; what lies outside the level's region of a plane is never read).
+enum { kUpsampleGeneral = 0, kUpsampleDouble = 1, kUpsampleZero = 2 };
+template <int MODE>
+__global__ __launch_bounds__(256) void upsample_registration_kernel(const float* __restrict__ in_u, const float* __restrict__ in_v,
+                                                                    float* __restrict__ out_u, float* __restrict__ out_v,
+                                                                    const float* __restrict__ f0, const float* __restrict__ f1,
+                                                                    float* __restrict__ warped, int w, int h, int in_w, int in_h,
+                                                                    int pitch, ResampleXY k, float inv_hx, float inv_hy, BatchArg batch)
+{
+    in_u += batch_offset(batch);
+    in_v += batch_offset(batch);
+    out_u += batch_offset(batch);
+    out_v += batch_offset(batch);
+    f0 += batch_offset(batch);
+    f1 += batch_offset(batch);
+    warped += batch_offset(batch);
+    const int gx = blockIdx.x * kBlockX + threadIdx.x;
+    if (gx >= w) return;
+    constexpr bool DOUBLE = MODE == kUpsampleDouble;
+    const ResampleXCells cells = resample_x_cells(gx, in_w, k);
+    float uu[kRegistrationRows], vv[kRegistrationRows];
+    int rows[kRegistrationRows];
+    if (MODE == kUpsampleZero) {
+#pragma unroll
+        for (int i = 0; i < kRegistrationRows; ++i) {
+            rows[i] = (blockIdx.y * kRegistrationRows + i) * kBlockY + threadIdx.y;
+            uu[i] = vv[i] = 0.f;
         }
-        out[c] = value;
+    } else if (DOUBLE) {
+        static_assert(kRegistrationRows == 4, "two input rows per thread");
+        const int base = (blockIdx.y * kBlockY + threadIdx.y) * kRegistrationRows;
+        float a[2], b[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const size_t at = static_cast<size_t>(min(base + 2 * j, h - 1) >> 1) * pitch + cells.left_i;
+            a[j] = in_u[at];
+            b[j] = in_v[at];
+        }
+#pragma unroll
+        for (int i = 0; i < kRegistrationRows; ++i) {
+            rows[i] = base + i;
+            const float xu = 0.f + a[i >> 1] * k.delta_x, xv = 0.f + b[i >> 1] * k.delta_x;
+            const float yu = 0.f + (xu * k.norm_x) * k.delta_y, yv = 0.f + (xv * k.norm_x) * k.delta_y;
+            uu[i] = yu * k.norm_y;
+            vv[i] = yv * k.norm_y;
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < kRegistrationRows; ++i) {
+            rows[i] = (blockIdx.y * kRegistrationRows + i) * kBlockY + threadIdx.y;
+            const int gy = min(rows[i], h - 1);  // (below the level: a valid row again)
+            uu[i] = resample_xy_value(in_u, cells, gy, in_w, in_h, pitch, k);
+            vv[i] = resample_xy_value(in_v, cells, gy, in_w, in_h, pitch, k);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < kRegistrationRows; ++i) {
+        const int gy = rows[i];
+        if (gy >= h) return;
+        const size_t c = static_cast<size_t>(gy) * pitch + gx;
+        out_u[c] = uu[i];
+        out_v[c] = vv[i];
+        warped[c] = registered_value(f0, f1, gx, gy, c, uu[i], vv[i], w, h, pitch, inv_hx, inv_hy);
     }
 }
 
@@ -1229,5 +1328,50 @@ int flow2d_registration_2d(flow2d_context* ctx, const float* frame_0, const floa
     FLOW2D_CHECK_LAUNCH();
     return FLOW2D_OK;
 }
+
+// flow_u / flow_v of the previous level (in_width x in_height) resampled to width x height into out_u / out_v -- the bits of
+// flow2d_resample_xy_pair -- and frame_1 warped by them into `output` -- the bits of flow2d_registration_2d: one launch.
+// flow_u = flow_v = NULL with in_width = in_height = 0 (the coarsest level): out_u = out_v = 0 over width x height, warped by that.
+int flow2d_upsample_registration_2d(flow2d_context* ctx, const float* flow_u, const float* flow_v, size_t in_width, size_t in_height,
+                                    float* out_u, float* out_v, const float* frame_0, const float* frame_1, size_t width, size_t height,
+                                    size_t pitch_bytes, float hx, float hy, float* output)
+{
+    FLOW2D_ENTER(ctx);
+    const bool zero = !flow_u && !flow_v && in_width == 0 && in_height == 0;  // the coarsest level: no previous flow
+    if ((!zero && (!flow2d::plane_args_ok(flow_u, in_width, in_height, pitch_bytes) || !flow2d::plane_args_ok(flow_v, in_width, in_height, pitch_bytes))) ||
+        !flow2d::plane_args_ok(out_u, width, height, pitch_bytes) || !flow2d::plane_args_ok(out_v, width, height, pitch_bytes) ||
+        !flow2d::plane_args_ok(frame_0, width, height, pitch_bytes) || !flow2d::plane_args_ok(frame_1, width, height, pitch_bytes) ||
+        !flow2d::plane_args_ok(output, width, height, pitch_bytes) || !(hx > 0.f) || !(hy > 0.f))
+        return FLOW2D_ERR_INVALID_ARGUMENT;
+    const float* reads[] = {flow_u, flow_v, frame_0, frame_1};
+    const float* writes[] = {out_u, out_v, output};
+    for (int i = 0; i < 3; ++i) {
+        for (const float* r : reads)
+            if (writes[i] == r) return FLOW2D_ERR_INVALID_ARGUMENT;
+        for (int j = i + 1; j < 3; ++j)
+            if (writes[i] == writes[j]) return FLOW2D_ERR_INVALID_ARGUMENT;
+    }
+    dim3 grid = grid_for(width, flow2d::div_up(height, kRegistrationRows));
+    grid.z = flow2d::batch_z(ctx, 1);
+    const ResampleXY k = zero ? ResampleXY{1.f, 1.f, 1.f, 1.f}
+                              : ResampleXY{static_cast<float>(in_width) / static_cast<float>(width),
+                                           static_cast<float>(width) / static_cast<float>(in_width),
+                                           static_cast<float>(in_height) / static_cast<float>(height),
+                                           static_cast<float>(height) / static_cast<float>(in_height)};
+    auto launch = [&](auto mode) {
+        upsample_registration_kernel<decltype(mode)::value><<<grid, dim3(kBlockX, kBlockY), 0, ctx->stream>>>(
+            flow_u, flow_v, out_u, out_v, frame_0, frame_1, output, (int)width, (int)height, (int)in_width, (int)in_height,
+            (int)(pitch_bytes / 4), k, 1.f / hx, 1.f / hy, flow2d::batch_arg(ctx, 1));
+    };
+    if (zero)
+        launch(std::integral_constant<int, kUpsampleZero>{});
+    else if (width == 2 * in_width && height == 2 * in_height)
+        launch(std::integral_constant<int, kUpsampleDouble>{});
+    else
+        launch(std::integral_constant<int, kUpsampleGeneral>{});
+    FLOW2D_CHECK_LAUNCH();
+    return FLOW2D_OK;
+}
+
 
 }  // extern "C"

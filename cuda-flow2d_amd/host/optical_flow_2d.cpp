@@ -775,74 +775,43 @@ bool OpticalFlow2D::RunPyramid(OperationParameters& params)
             Release(temp);
         }
 
-        // flow: zero at the coarsest level, otherwise previous level -> this level (no magnitude scaling)
-        if (prev_size.width == 0) {
-            const size_t row_bytes = dev_container_size_.width * sizeof(float);
-            flow2d_memset_2d(context_, AsPlane(flow_u), dev_container_size_.pitch, 0, row_bytes, dev_container_size_.height);
-            flow2d_memset_2d(context_, AsPlane(flow_v), dev_container_size_.pitch, 0, row_bytes, dev_container_size_.height);
-        } else {  // u and v of the previous level in one resample call
-            DevicePtr temp = Acquire(), temp_b = Acquire();
-            op.Clear();
-            op.PushValuePtr("dev_input", &flow_u);
-            op.PushValuePtr("dev_output", &flow_du);
-            op.PushValuePtr("dev_temp", &temp);
-            op.PushValuePtr("dev_input_b", &flow_v);
-            op.PushValuePtr("dev_output_b", &flow_dv);
-            op.PushValuePtr("dev_temp_b", &temp_b);
-            op.PushValuePtr("data_size", &prev_size);
-            op.PushValuePtr("resample_size", &current_size);
-            cuop_resample_.Execute(op);
-            failed |= cuop_resample_.TakeFailure();
-            std::swap(flow_u, flow_du);
-            std::swap(flow_v, flow_dv);
-            Release(temp_b);
-            Release(temp);
-        }
+        // flow: zero at the coarsest level, otherwise previous level -> this level (no magnitude scaling).  Round 6: both ride with
+        // the warp of the level (flow2d_upsample_registration_2d: the resample and the registration operators' arithmetic on the
+        // same values in one launch -- (u, v) handed on in registers instead of through their planes; at the coarsest level the
+        // zeros, over the level's region instead of two memsets of the whole container).
+        const bool upsample = prev_size.width != 0;
+        // backward registration of `level_1` by the level's flow into `output` (after bringing the flow to the level's size)
+        auto warp = [&](DevicePtr level_0, DevicePtr level_1, DevicePtr output) {
+            int err;
+            if (upsample) {
+                err = flow2d_upsample_registration_2d(context_, AsPlane(flow_u), AsPlane(flow_v), prev_size.width, prev_size.height,
+                                                      AsPlane(flow_du), AsPlane(flow_dv), AsPlane(level_0), AsPlane(level_1),
+                                                      current_size.width, current_size.height, dev_container_size_.pitch, hx, hy,
+                                                      AsPlane(output));
+                std::swap(flow_u, flow_du);
+                std::swap(flow_v, flow_dv);
+            } else {
+                err = flow2d_upsample_registration_2d(context_, nullptr, nullptr, 0, 0, AsPlane(flow_u), AsPlane(flow_v), AsPlane(level_0),
+                                                      AsPlane(level_1), current_size.width, current_size.height,
+                                                      dev_container_size_.pitch, hx, hy, AsPlane(output));
+            }
+            if (CheckFlow2DError(err, "flow2d_upsample_registration_2d")) failed = true;
+        };
 
         DevicePtr solve_frame_0 = frame_0_res;  // what the solver reads as frame 0 of this level
         DevicePtr solve_frame_1 = 0;            // ... and as (warped) frame 1: frame_1_res unless set
         if (stacked) {  // the level planes stay where the y pass of all levels put them; the warp writes the plane kept for it
             const size_t at = level > 0 ? level_row[static_cast<size_t>(level)] * dev_container_size_.pitch : 0;
             DevicePtr level_0 = (level > 0 ? frame_0_res : frame_0) + at, level_1 = (level > 0 ? frame_1_res : frame_1) + at;
-            op.Clear();
-            op.PushValuePtr("dev_frame_0", &level_0);
-            op.PushValuePtr("dev_frame_1", &level_1);
-            op.PushValuePtr("dev_flow_u", &flow_u);
-            op.PushValuePtr("dev_flow_v", &flow_v);
-            op.PushValuePtr("dev_output", &level_warp_plane_);
-            op.PushValuePtr("data_size", &current_size);
-            op.PushValuePtr("hx", &hx);
-            op.PushValuePtr("hy", &hy);
-            cuop_register_.Execute(op);
-            failed |= cuop_register_.TakeFailure();
+            warp(level_0, level_1, level_warp_plane_);
             solve_frame_0 = level_0;
             solve_frame_1 = level_warp_plane_;
         } else if (sequence) {  // the level planes are kept for the next pair: warp into the pool plane, read the rest
-            op.Clear();
-            op.PushValuePtr("dev_frame_0", &sequence_level[0]);
-            op.PushValuePtr("dev_frame_1", &sequence_level[1]);
-            op.PushValuePtr("dev_flow_u", &flow_u);
-            op.PushValuePtr("dev_flow_v", &flow_v);
-            op.PushValuePtr("dev_output", &frame_1_res);
-            op.PushValuePtr("data_size", &current_size);
-            op.PushValuePtr("hx", &hx);
-            op.PushValuePtr("hy", &hy);
-            cuop_register_.Execute(op);
-            failed |= cuop_register_.TakeFailure();
+            warp(sequence_level[0], sequence_level[1], frame_1_res);
             solve_frame_0 = sequence_level[0];
         } else {  // backward registration of frame 1 by the current flow; the warped frame replaces it
             DevicePtr temp = Acquire();
-            op.Clear();
-            op.PushValuePtr("dev_frame_0", &frame_0_res);
-            op.PushValuePtr("dev_frame_1", &frame_1_res);
-            op.PushValuePtr("dev_flow_u", &flow_u);
-            op.PushValuePtr("dev_flow_v", &flow_v);
-            op.PushValuePtr("dev_output", &temp);
-            op.PushValuePtr("data_size", &current_size);
-            op.PushValuePtr("hx", &hx);
-            op.PushValuePtr("hy", &hy);
-            cuop_register_.Execute(op);
-            failed |= cuop_register_.TakeFailure();
+            warp(frame_0_res, frame_1_res, temp);
             std::swap(frame_1_res, temp);
             Release(temp);
         }

@@ -199,6 +199,17 @@ FLOW2D_API int flow2d_registration_2d(flow2d_context* ctx, const float* frame_0,
                                       const float* flow_u, const float* flow_v, size_t width, size_t height,
                                       size_t pitch_bytes, float hx, float hy, float* output);
 
+/* The flow of the previous pyramid level resampled to this level's size (the bits of flow2d_resample_xy_pair into out_u / out_v)
+ * and frame_1 warped by it (the bits of flow2d_registration_2d into `output`) in one launch: replaces the
+ * CudaOperationResample2D::Execute + CudaOperationRegistration2D::Execute pair of optical_flow_2d.cpp:320-365 at every
+ * level; at the coarsest one -- flow_u = flow_v = NULL, in_width = in_height = 0 -- out_u = out_v = 0 over width x height (the two
+ * whole-plane memsets of optical_flow_2d.cpp:307-318) and frame_1 warped by that.  Written planes must be distinct from each other
+ * and from every plane read. */
+FLOW2D_API int flow2d_upsample_registration_2d(flow2d_context* ctx, const float* flow_u, const float* flow_v, size_t in_width,
+                                               size_t in_height, float* out_u, float* out_v, const float* frame_0,
+                                               const float* frame_1, size_t width, size_t height, size_t pitch_bytes, float hx,
+                                               float hy, float* output);
+
 /* resample_x / resample_y (src/kernels/resample_2d.cu:34-75,77-118): area-weighted 1-D resample. */
 FLOW2D_API int flow2d_resample_x(flow2d_context* ctx, const float* input, float* output, size_t out_width,
                                  size_t out_height, size_t in_width, size_t pitch_bytes);

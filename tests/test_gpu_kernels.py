@@ -168,6 +168,56 @@ def test_registration(ctx, oracle, w, h, cw, ch, hx, hy):
     assert np.array_equal(out.download(w, h), oracle.registration(f0, f1, u, v, w, h, hx, hy))
 
 
+@pytest.mark.parametrize("w,h,ow,oh,hx,hy", [(37, 20, 100, 70, 1.0, 1.0), (33, 17, 34, 18, 2.0, 2.0), (50, 35, 100, 70, 1.25, 1.1),
+                                             (512, 270, 1024, 540, 4.0, 4.0), (231, 130, 461, 260, 7.3, 5.5), (2, 3, 257, 130, 1.0, 1.0),
+                                             (100, 70, 37, 20, 3.0, 3.5), (2047, 9, 2049, 10, 1.0, 1.0), (64, 64, 64, 64, 1.0, 1.0),
+                                             (33, 17, 66, 34, 2.0, 2.0), (1000, 3, 2000, 6, 1.0, 1.0), (1, 1, 2, 2, 1.0, 1.0),
+                                             (1024, 1024, 2048, 2048, 2.0, 2.0)])
+def test_upsample_registration(ctx, flow2d, oracle, w, h, ow, oh, hx, hy):
+    """The previous level's flow resampled to the level's size and frame 1 warped by it in ONE launch: (u, v) are the bits of the
+    two-pass resample (resample_2d.cu:34-118), the warped frame the bits of registration_2d.cu:34-73 fed with them -- NaN and far
+    out-of-range displacements (frame 0's value) included; nothing outside the level is written.  (Levels exactly twice the previous
+    one take a form of their own: one load per plane for a 2 x 2 block of outputs.)"""
+    cw, ch = max(w, ow) + 3, max(h, oh) + 2
+    _, _, u, v, *_ = level_fields(oracle, w, h, 9, flow_scale=4.0)
+    u[0, 0] = np.nan
+    v[h - 1, w - 1] = 1e9
+    u[h // 2, w // 2] = -1e9
+    f0, f1, *_ = level_fields(oracle, ow, oh, 10)
+    pu, pv, p0, p1 = up(ctx, u, cw, ch), up(ctx, v, cw, ch), up(ctx, f0, cw, ch), up(ctx, f1, cw, ch)
+    ou, ov, out = (ctx.plane(cw, ch).fill_bytes(0x7f) for _ in range(3))
+    ctx.upsample_registration(pu, pv, w, h, ou, ov, p0, p1, ow, oh, hx, hy, out)
+    want_u = oracle.resample(in_container(u, cw, ch), w, h, ow, oh)[:oh, :ow]
+    want_v = oracle.resample(in_container(v, cw, ch), w, h, ow, oh)[:oh, :ow]
+    assert np.array_equal(ou.download(ow, oh), want_u, equal_nan=True)
+    assert np.array_equal(ov.download(ow, oh), want_v, equal_nan=True)
+    want = oracle.registration(f0, f1, np.ascontiguousarray(want_u), np.ascontiguousarray(want_v), ow, oh, hx, hy)
+    assert np.array_equal(out.download(ow, oh), want)
+    for plane in (ou, ov, out):
+        got = plane.download()
+        assert np.all(got[oh:, :].view(np.uint32) == 0x7f7f7f7f) and np.all(got[:, ow:].view(np.uint32) == 0x7f7f7f7f)
+    # the two launches it replaces
+    tu, tv, tout = (ctx.plane(cw, ch) for _ in range(3))
+    ctx.resample_xy(pu, tu, w, h, ow, oh, pv, tv)
+    ctx.registration(p0, p1, tu, tv, ow, oh, hx, hy, tout)
+    assert np.array_equal(out.download(ow, oh), tout.download(ow, oh))
+    # the coarsest level's form: no previous flow, zeros stored over the level's region (only) and warped by
+    zu, zv, zout = (ctx.plane(cw, ch).fill_bytes(0x7f) for _ in range(3))
+    ctx.upsample_registration(None, None, 0, 0, zu, zv, p0, p1, ow, oh, hx, hy, zout)
+    zeros = np.zeros((oh, ow), np.float32)
+    for plane in (zu, zv):
+        got = plane.download()
+        assert np.all(got[:oh, :ow].view(np.uint32) == 0)
+        assert np.all(got[oh:, :].view(np.uint32) == 0x7f7f7f7f) and np.all(got[:, ow:].view(np.uint32) == 0x7f7f7f7f)
+    assert np.array_equal(zout.download(ow, oh).view(np.uint32), oracle.registration(f0, f1, zeros, zeros, ow, oh, hx, hy).view(np.uint32))
+    with pytest.raises(flow2d.Flow2DError):  # no previous flow, but a previous size
+        ctx.upsample_registration(None, None, w, h, zu, zv, p0, p1, ow, oh, hx, hy, zout)
+    with pytest.raises(flow2d.Flow2DError):  # a written plane that is also read
+        ctx.upsample_registration(pu, pv, w, h, pu, ov, p0, p1, ow, oh, hx, hy, out)
+    with pytest.raises(flow2d.Flow2DError):  # two written planes that are one
+        ctx.upsample_registration(pu, pv, w, h, ou, ou, p0, p1, ow, oh, hx, hy, out)
+
+
 @pytest.mark.parametrize("hx,hy", [(1.0, 1.0), (1.25, 1.1)])
 @pytest.mark.parametrize("w,h,cw,ch", SIZES)
 def test_phi_ksi_and_sweeps(ctx, flow2d, oracle, w, h, cw, ch, hx, hy):

@@ -272,4 +272,28 @@ print('host-entry lanes $lanes: incl. H<->D %.1f pairs/s (%.1f GB/s each way), d
     done
 }
 
+# whole-pipeline rate and lone-pair latency of the tree exported from the previous commit (ab/prev_tree: git archive HEAD + the current HIP
+# library, host library built there) against the working tree, twice round
+ab_trees() {
+    for rep in 1 2; do
+        for wl in "$@"; do
+            for tree in ab/prev_tree .; do
+                (cd "$R/$tree" && timeout -k 10 300 python3 bench.py --workload $wl --no-pmc --no-oracle-check --no-host-entry-leg --no-cpu-baseline \
+                    --no-reference-baseline --no-batch-leg --no-probe-builds 2>/dev/null) |
+                    python3 -c "
+import json,sys
+d=json.loads(sys.stdin.read())
+print('%-22s %-14s pairs/s %8.1f  ms/step %7.3f  single_pair_ms %s' % ('$wl', '$tree', d['pairs_per_s'], d['ms_per_step'], d.get('single_pair_latency_ms')))" || return 1
+            done
+        done
+    done
+}
+
+call19() {  # the previous level's flow up-sampled and frame 1 warped by it in one launch: tests, the two kernels against the one, whole pipelines
+    timeout -k 10 900 python3 -m pytest tests/test_gpu_kernels.py tests/test_gpu_flow.py tests/test_gpu_reference.py -x -q > "$OUT/call19_tests.log" 2>&1 || { tail -30 "$OUT/call19_tests.log"; return 1; }
+    tail -1 "$OUT/call19_tests.log"
+    for n in 4096 2048 512; do timeout -k 10 120 python3 tools/time_ops.py $n 2>&1 | grep -E "registration" || return 1; done
+    ab_trees cfg2_1024_grey cfg3_4096_grey cfg4_1080p_batch
+}
+
 "$@"

@@ -46,6 +46,12 @@ def main():
         ("resample x and y from 1/2 (two planes, one launch)", lambda: ctx.resample_xy(a, out, n // 2, n // 2, n, n, b, tmp), 2.5),
         ("median 5 of a + b (two planes)", lambda: ctx.add_median(a, b, n, n, 5, out, c, d, tmp), 6),
     ]
+    if hasattr(ctx, "upsample_registration"):  # (u, v) from 1/2 and the warp by them, one launch; c, d hold a flow of a few pixels
+        e, g = ctx.plane(n, n), ctx.plane(n, n)
+        rows.append(("resample x and y from 1/2, then registration (two launches)",
+                     lambda: (ctx.resample_xy(c, out, n // 2, n // 2, n, n, d, tmp), ctx.registration(a, b, out, tmp, n, n, 1.0, 1.0, e)), 6.5))
+        rows.append(("up-sampling + registration (one launch)",
+                     lambda: ctx.upsample_registration(c, d, n // 2, n // 2, out, tmp, a, b, n, n, 1.0, 1.0, g), 4.5))
     # the x pass of every level of a 0.5 pyramid for both frames in one trip (flow2d_resample_x_levels), then the y passes of
     # the coarsest levels out of the packed plane (long chains of rows, a handful of outputs)
     widths, w = [], n
