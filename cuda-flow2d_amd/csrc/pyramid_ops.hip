@@ -300,7 +300,7 @@ __global__ __launch_bounds__(256) void resample_kernel(const float* __restrict__
     }
 }
 
-// Both passes in one launch, for up-sampling (the flow of the previous pyramid level, optical_flow_2d.cpp:320-345): every
+// Both passes in one launch, for up-sampling (the flow of the previous pyramid level, optical_flow_2d.cpp:314-338): every
 // output evaluates the x pass for the one or two input rows of its y cells -- the same left-to-right cell sum, the same
 // normalisation, rounded to float like the temp plane the reference stores it in -- and then the y pass over those
 // values.  Same operations in the same order as resample_kernel<true> into a temp followed by resample_kernel<false>,
@@ -747,7 +747,7 @@ __global__ __launch_bounds__(256) void registration_kernel(const float* __restri
 }
 
 // The flow of the previous level brought to this level's size AND frame 1 warped by it, in one launch (round 6;
-// optical_flow_2d.cpp:320-345 followed by :351-365): a thread evaluates (u, v) of its pixels exactly as resample_xy_kernel does,
+// optical_flow_2d.cpp:314-338 followed by :341-362): a thread evaluates (u, v) of its pixels exactly as resample_xy_kernel does,
 // stores them and hands them to the warp of the same pixels instead of a second kernel reading them back -- one launch and 8 bytes
 // per pixel less at every level but the coarsest; the same operations on the same values, the same bits.
 // DOUBLE: the level is exactly twice the previous one in both directions (every level of a 0.5 pyramid over power-of-two frames, the fine
@@ -757,7 +757,7 @@ __global__ __launch_bounds__(256) void registration_kernel(const float* __restri
 // input rows: 4 loads instead of 32 in front of the thread's sixteen gathers (4096^2: 120 -> see profiles/r06_experiments).  The value
 // goes through the general form's operations for one cell -- ((0 + a * delta_x) * norm_x, 0 + that * delta_y, * norm_y) -- bit for bit.
 // ZERO: the coarsest level -- no previous flow: (u, v) = 0 is stored and warped by (the reference fills both planes with two memsets
-// of the whole container first, optical_flow_2d.cpp:307-318; what lies outside the level's region of a plane is never read).
+// of the whole container first, optical_flow_2d.cpp:308-313; what lies outside the level's region of a plane is never read).
 enum { kUpsampleGeneral = 0, kUpsampleDouble = 1, kUpsampleZero = 2 };
 template <int MODE>
 __global__ __launch_bounds__(256) void upsample_registration_kernel(const float* __restrict__ in_u, const float* __restrict__ in_v,

@@ -201,9 +201,9 @@ FLOW2D_API int flow2d_registration_2d(flow2d_context* ctx, const float* frame_0,
 
 /* The flow of the previous pyramid level resampled to this level's size (the bits of flow2d_resample_xy_pair into out_u / out_v)
  * and frame_1 warped by it (the bits of flow2d_registration_2d into `output`) in one launch: replaces the
- * CudaOperationResample2D::Execute + CudaOperationRegistration2D::Execute pair of optical_flow_2d.cpp:320-365 at every
+ * CudaOperationResample2D::Execute + CudaOperationRegistration2D::Execute pair of optical_flow_2d.cpp:314-362 at every
  * level; at the coarsest one -- flow_u = flow_v = NULL, in_width = in_height = 0 -- out_u = out_v = 0 over width x height (the two
- * whole-plane memsets of optical_flow_2d.cpp:307-318) and frame_1 warped by that.  Written planes must be distinct from each other
+ * whole-plane memsets of optical_flow_2d.cpp:308-313) and frame_1 warped by that.  Written planes must be distinct from each other
  * and from every plane read. */
 FLOW2D_API int flow2d_upsample_registration_2d(flow2d_context* ctx, const float* flow_u, const float* flow_v, size_t in_width,
                                                size_t in_height, float* out_u, float* out_v, const float* frame_0,
@@ -219,7 +219,7 @@ FLOW2D_API int flow2d_resample_y(flow2d_context* ctx, const float* input, float*
 /* Two-plane forms of the three launchers the pyramid calls once for u and once for v (or once per frame) with
  * identical geometry: one launch does what two calls of the single-plane entry do, plane set `a` and plane set
  * `b` independently and with the same results (the second set rides in grid.z).  They replace the back-to-back
- * launch pairs of optical_flow_2d.cpp:284-303 (frames), :320-345 (flow resample), :480-500 (add), :505-530 (median);
+ * launch pairs of optical_flow_2d.cpp:284-303 (frames), :314-338 (flow resample), :480-500 (add), :505-530 (median);
  * on the coarse levels a launch costs more than its work.  The four output planes must be distinct. */
 FLOW2D_API int flow2d_add_2d_pair(flow2d_context* ctx, float* operand_0_a, const float* operand_1_a,
                                   float* operand_0_b, const float* operand_1_b, size_t width, size_t height,
