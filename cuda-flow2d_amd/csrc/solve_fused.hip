@@ -249,6 +249,10 @@ int launch_fused_outer(flow2d_context* ctx, int constancy, const float* f0, cons
                 0, plan.blocks, 0, 0, static_cast<unsigned long long>(ctx->batch_stride_floats),
                 nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
                 ctx->fused_fallbacks};
+    // The first outer iteration of a level starts from du = dv = 0: the kernel loads the increment planes all the same (no branch
+    // around two loads in every row step) and selects the zero -- so let those loads go to (u, v), whose lines the same step has just
+    // fetched, instead of dragging two planes of stale data through HBM (a 4096^2 launch 583 -> 450 MB; round 6).
+    if (zero_increment) a.du = u, a.dv = v;
 #ifdef FLOW2D_DEV_BUILD
     if (probe::kStamps) a.stamps = stamp_buffer(), a.stamp_count = stamp_counter(), a.stalls = stall_buffer();
     const size_t plane_floats = h * (pitch_bytes / 4);
