@@ -766,8 +766,10 @@ __global__ __launch_bounds__(256) void upsample_registration_kernel(const float*
                                                                     float* __restrict__ warped, int w, int h, int in_w, int in_h,
                                                                     int pitch, ResampleXY k, float inv_hx, float inv_hy, BatchArg batch)
 {
-    in_u += batch_offset(batch);
-    in_v += batch_offset(batch);
+    if (MODE != kUpsampleZero) {  // (no previous flow at the coarsest level: null planes)
+        in_u += batch_offset(batch);
+        in_v += batch_offset(batch);
+    }
     out_u += batch_offset(batch);
     out_v += batch_offset(batch);
     f0 += batch_offset(batch);

@@ -296,4 +296,15 @@ call19() {  # the previous level's flow up-sampled and frame 1 warped by it in o
     ab_trees cfg2_1024_grey cfg3_4096_grey cfg4_1080p_batch
 }
 
+call20() {  # the memory-side kernels (blur, medians, resample, warp) and the LDS tiles without the SLP vectoriser (noslp) / without packed fp32 and through the priority filter (nopk)
+    for rep in 1 2; do
+        for so in cuda-flow2d_amd/csrc/libflow2d_hip.so ab/noslp.so ab/nopk.so; do
+            echo "== $so"
+            FLOW2D_HIP_LIB="$R/$so" timeout -k 10 120 python3 tools/time_ops.py 4096 2>&1 | grep -E "^median|gaussian|registration \(one|levels|median 5 of" || return 1
+            for n in 512 256 64; do FLOW2D_HIP_LIB="$R/$so" timeout -k 10 120 python3 tools/time_sweep.py $n $n 2 2>&1 | grep "level solve" || return 1; done
+        done
+    done
+    WLS="cfg3_4096_gradient cfg2_1024_grey cfg4_1080p_batch" bash tools/ab_bench.sh cuda-flow2d_amd/csrc/libflow2d_hip.so ab/noslp.so ab/nopk.so
+}
+
 "$@"
