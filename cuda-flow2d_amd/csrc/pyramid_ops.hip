@@ -715,9 +715,16 @@ __device__ __forceinline__ float registered_value(const float* __restrict__ f0, 
     const float dy = y_f - static_cast<float>(y);
     const int x1 = min(w - 1, x + 1);
     const int y1 = min(h - 1, y + 1);
-    const float* r0 = f1 + static_cast<size_t>(y) * pitch;
-    const float* r1 = f1 + static_cast<size_t>(y1) * pitch;
-    return (1.f - dx) * (1.f - dy) * r0[x] + (dx) * (1.f - dy) * r0[x1] + (1.f - dx) * (dy)*r1[x] + (dx) * (dy)*r1[x1];
+    // x and x1 lie in the column pair (xb, xb + 1) with xb = min(x, w - 2): each row's two values come as ONE eight-byte gather (the
+    // target takes dword-aligned dwordx2 loads) instead of two -- the kernel is bound by its gathers' address processing, not by bytes
+    // (round 6: registration alone 69 -> 63 us at 4096^2, the one-launch warp 23 -> 18 us at 2048^2).  (w = 1: xb = 0 and the second column is row padding, never selected.)
+    const int xb = max(min(x, w - 2), 0);
+    const float* r0 = f1 + static_cast<size_t>(y) * pitch + xb;
+    const float* r1 = f1 + static_cast<size_t>(y1) * pitch + xb;
+    const float a0 = r0[0], a1 = r0[1], b0 = r1[0], b1 = r1[1];
+    const bool x_second = x != xb, x1_second = x1 != xb;
+    const float r0x = x_second ? a1 : a0, r0x1 = x1_second ? a1 : a0, r1x = x_second ? b1 : b0, r1x1 = x1_second ? b1 : b0;
+    return (1.f - dx) * (1.f - dy) * r0x + (dx) * (1.f - dy) * r0x1 + (1.f - dx) * (dy)*r1x + (dx) * (dy)*r1x1;
 }
 
 __global__ __launch_bounds__(256) void registration_kernel(const float* __restrict__ f0, const float* __restrict__ f1,

@@ -168,6 +168,25 @@ def test_registration(ctx, oracle, w, h, cw, ch, hx, hy):
     assert np.array_equal(out.download(w, h), oracle.registration(f0, f1, u, v, w, h, hx, hy))
 
 
+@pytest.mark.parametrize("w,h", [(1, 1), (1, 7), (2, 1), (2, 9), (3, 3), (63, 5), (64, 2), (65, 3), (129, 4)])
+def test_registration_narrow_levels(ctx, oracle, w, h):
+    """The warp's gathers come in column pairs (x, x + 1) clamped into the level: widths of one, two and three columns, displacements
+    that land in the last column and beyond, widths around the wave size."""
+    rng = np.random.default_rng(w * 100 + h)
+    f0 = rng.normal(0, 1, (h, w)).astype(np.float32)
+    f1 = rng.normal(0, 1, (h, w)).astype(np.float32)
+    u = rng.uniform(-1.5 * w, 1.5 * w, (h, w)).astype(np.float32)
+    v = rng.uniform(-1.5 * h, 1.5 * h, (h, w)).astype(np.float32)
+    u[0, w - 1] = 0.0                       # exactly the last column
+    u[h - 1, 0] = np.float32(w - 1)         # from the first column onto the last
+    v[h - 1, 0] = 0.0
+    cw, ch = w + 5, h + 3
+    planes = [up(ctx, a, cw, ch, 5.0) for a in (f0, f1, u, v)]
+    out = ctx.plane(cw, ch).fill_bytes(0x7f)
+    ctx.registration(*planes, w, h, 1.0, 1.0, out)
+    assert np.array_equal(out.download(w, h), oracle.registration(f0, f1, u, v, w, h, 1.0, 1.0))
+
+
 @pytest.mark.parametrize("w,h,ow,oh,hx,hy", [(37, 20, 100, 70, 1.0, 1.0), (33, 17, 34, 18, 2.0, 2.0), (50, 35, 100, 70, 1.25, 1.1),
                                              (512, 270, 1024, 540, 4.0, 4.0), (231, 130, 461, 260, 7.3, 5.5), (2, 3, 257, 130, 1.0, 1.0),
                                              (100, 70, 37, 20, 3.0, 3.5), (2047, 9, 2049, 10, 1.0, 1.0), (64, 64, 64, 64, 1.0, 1.0),
