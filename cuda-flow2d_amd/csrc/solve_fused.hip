@@ -150,8 +150,14 @@ static FusedPlan fused_plan_search(const flow2d_context* ctx, size_t w, size_t h
     // is saturated by the other lanes' launches and the redundant rows are vector instructions somebody waits for.  Weights
     // 0 / 1 / 2 / 3 on one box (profiles/r04_experiments/plan_work_weight_ab.txt): config 2 3 993-4 103 / 4 107-4 120 / 4 199-4 211 /
     // 4 220-4 266 pairs/s, rub1-rub2 1 535-1 540 / 1 586-1 591 / 1 622-1 630 / 1 622-1 625, configs 3, 4, 5 unchanged; a lone 1080p
-    // pair 1.10 / 1.09 / 1.11 / 1.14 ms, a lone 1024^2 pair 0.67 / 0.65 / 0.65 / 0.67 ms: two.
+    // pair 1.10 / 1.09 / 1.11 / 1.14 ms, a lone 1024^2 pair 0.67 / 0.65 / 0.65 / 0.67 ms: two.  Round 6, far beyond (where a 4096^2
+    // launch turns into half a round of twice as long strips): 2 / 6 / 24 / 100 -> config 3 350-351 / 349-350 / 347-348 / 333-335,
+    // config 5 100.1-100.3 / 100.6-100.7 / 100.0-100.5 / 97.2-97.6 pairs/s, a lone config-3 pair 3.46-3.50 / 3.65-3.69 / 3.92-3.94 / 4.88 ms.
+#ifdef FLOW2D_DEV_BUILD
+    static const double bias = std::getenv("FLOW2D_PLAN_BIAS") ? std::atof(std::getenv("FLOW2D_PLAN_BIAS")) : 2.0;
+#else
     const double bias = 2.0;
+#endif
     auto rounds = [&](long blocks, double slowest) {
         const long full = blocks / cap, rem = blocks % cap;
         return full * 2.0 * slowest + (rem == 0 ? 0.0 : (rem <= cus ? 1.3 * slowest : 2.0 * slowest)) +
