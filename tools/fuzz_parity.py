@@ -1,6 +1,8 @@
 """Developer tool: random whole-pipeline configurations, product (single pairs and lock-step groups) against the CPU
 oracle, bit for bit.  usage (GPU box): python tools/fuzz_parity.py [cases] [seed] [solver algorithm: 0 auto, 2 fused strips
-on every level, ...] [share of cases in the opt-in red-black SOR mode, default 0.2: omega drawn from (0.3, 1.95)]"""
+on every level, ...] [share of cases in the opt-in red-black SOR mode, default 0.2: omega drawn from (0.3, 1.95)]
+[share of cases on a 0.5 pyramid over a frame of up to 1400 x 1000 rounded to a multiple of 32 -- every level exactly twice the next:
+the doubling form of the one-launch warp, the power-of-two x passes; default 0, which leaves the random stream of earlier campaigns as it was]"""
 import importlib
 import os
 import sys
@@ -18,6 +20,7 @@ def main():
     rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
     algorithm = int(sys.argv[3]) if len(sys.argv) > 3 else 0
     sor_share = float(sys.argv[4]) if len(sys.argv) > 4 else 0.2
+    halving_share = float(sys.argv[5]) if len(sys.argv) > 5 else 0.0
     ctx = F.Context(0)
     bad = 0
     t0 = time.time()
@@ -28,6 +31,9 @@ def main():
              int(rng.integers(1, 9)), float(np.float32(10.0 ** rng.uniform(-1.0, 2.0))), 0.001, 0.001,
              int(rng.choice([1, 3, 5, 7])), float(rng.choice([0.0, 0.45, 1.0, 1.5, 2.9])))
         G = int(rng.choice([1, 1, 2, 3, 5]))
+        if halving_share > 0.0 and rng.uniform() < halving_share:
+            w, h = 32 * int(rng.integers(1, 44)), 32 * int(rng.integers(1, 32))
+            p = (p[0], 0.5) + p[2:]
         omega = float(np.float32(rng.uniform(0.3, 1.95))) if rng.uniform() < sor_share else 0.0
         pairs = [O.synthetic_pair(w, h, float(rng.uniform(-3, 3)), float(rng.uniform(-3, 3)), seed=int(rng.integers(1 << 30)),
                                   noise=bool(rng.integers(2))) for _ in range(G)]

@@ -307,4 +307,13 @@ call20() {  # the memory-side kernels (blur, medians, resample, warp) and the LD
     WLS="cfg3_4096_gradient cfg2_1024_grey cfg4_1080p_batch" bash tools/ab_bench.sh cuda-flow2d_amd/csrc/libflow2d_hip.so ab/noslp.so ab/nopk.so
 }
 
+fuzz_halving() {  # random pipelines on 0.5 pyramids over frames of multiples of 32 (every level exactly twice the next) against the oracle; usage: fuzz_halving <seed> [cases auto] [cases strips]
+    local seed=${1:-800}
+    timeout -k 10 560 python3 tools/fuzz_parity.py ${2:-400} $seed 0 0.3 1.0 > "$OUT/fuzz_halving_auto_$seed.txt" 2>&1; tail -1 "$OUT/fuzz_halving_auto_$seed.txt"
+    grep -c MISMATCH "$OUT/fuzz_halving_auto_$seed.txt" && return 1
+    timeout -k 10 400 python3 tools/fuzz_parity.py ${3:-200} $((seed + 1)) 2 0.3 1.0 > "$OUT/fuzz_halving_strips_$seed.txt" 2>&1; tail -1 "$OUT/fuzz_halving_strips_$seed.txt"
+    grep -c MISMATCH "$OUT/fuzz_halving_strips_$seed.txt" && return 1
+    return 0
+}
+
 "$@"
