@@ -472,8 +472,9 @@ class Job:
         self.grouped = not self.single and args.batch_mode == "groups"
         self.group = cfg["pairs_per_rank"] if self.grouped else 1
         # Single-pair workloads up to 4096^2 (configs 2 and 3): consecutive STEPS are handed to the batch entry `step_group` at a time
-        # as independent pairs in planes of their own, and the C++ object forms a lock-step group of them itself
-        # (OpticalFlowBatch2D::ComputeFlowBatchDeviceGrouped: gather, one launch per kernel for the group, hand back).
+        # as independent pairs, every one with a plane set of its own, and the C++ object forms a lock-step group of them itself
+        # (OpticalFlowBatch2D::ComputeFlowBatchDeviceGrouped: one launch per kernel for the group; pairs that sit one container
+        # apart -- how the sets are allocated below -- run in place, others are gathered and handed back).
         # A step is still one pair's whole pyramid; K steps are K pairs.
         self.step_group = 1
         if self.single:
@@ -508,9 +509,26 @@ class Job:
             # pairs are in flight, not copies of one
             ids = [self.owned[0] + world * j for j in range(self.n_lanes * self.step_group)]
             more = workload_pairs(workload, cfg, ids[1:], world)
-            for j, (a, b) in enumerate([frames[0]] + more):
-                self.sets.append((c.plane(w, h, a), c.plane(w, h, b), c.plane(w, h), c.plane(w, h), [ids[j]]))
-            del more
+            pairs_all = [frames[0]] + more
+            if args.scattered_groups:  # every plane an allocation of its own: the object gathers a group's frames and hands its flows back
+                for j, (a, b) in enumerate(pairs_all):
+                    self.sets.append((c.plane(w, h, a), c.plane(w, h, b), c.plane(w, h), c.plane(w, h), [ids[j]]))
+            else:
+                # a lane's step_group pairs one below the other in four allocations (frame 0, frame 1, u, v), every pair still a plane
+                # set of its own to the batch entry: pairs that sit one container apart are a group as they lie, and the object
+                # runs the pyramid on them in place (round 6: the gather / hand-back copies were 4-6 % of a group's time)
+                S = self.step_group
+                assert self.runner.group_stride == self.runner.pitch * h
+                self.tall = []
+                for lane in range(self.n_lanes):
+                    mine = pairs_all[lane * S:(lane + 1) * S]
+                    tall = (c.plane(w, h * S, np.vstack([q[0] for q in mine])), c.plane(w, h * S, np.vstack([q[1] for q in mine])),
+                            c.plane(w, h * S), c.plane(w, h * S))
+                    self.tall.append(tall)
+                    for k in range(S):
+                        at = k * self.runner.group_stride
+                        self.sets.append(tuple(_Borrowed(c, t.ptr + at, t.pitch, w, h) for t in tall) + ([ids[lane * S + k]],))
+            del more, pairs_all
         elif self.rotate:
             stacked = (np.vstack([f[0] for f in frames]), np.vstack([f[1] for f in frames]))
             for lane in range(self.n_lanes):
@@ -1137,6 +1155,10 @@ def main():
                     help="independent pairs in flight per GPU when a step holds a single pair: consecutive steps go to "
                          "alternating streams so one pair's launch-bound coarse levels overlap the next pair's fine levels")
     ap.add_argument("--max-lanes", type=int, default=4, help="upper bound on the lanes (streams) per GPU")
+    ap.add_argument("--scattered-groups", action="store_true",
+                    help="single-pair workloads with step groups: every plane of every pair an allocation of its own (the object gathers a "
+                         "group's frames into staging containers and hands the flows back: two device copies per group) instead of a lane's "
+                         "pairs one below the other in four allocations, which the object runs in place")
     ap.add_argument("--step-group", type=int, default=0,
                     help="single-pair workloads: consecutive steps handed to the batch entry this many at a time, which "
                          "forms a lock-step group of them (0 = automatic: 32 up to 1024^2, 16 up to 2048^2, 8 up to 4096^2, else 1; the "
@@ -1362,6 +1384,10 @@ def main():
                 "host_path": "OpticalFlowBatch2D::ComputeFlowBatchDevice (C++): one call per step",
                 "streams_per_gpu": n_lanes, "hip_graph_replay": not args.no_graph,
                 "steps_per_lock_step_group": step_group,
+                "group_planes": None if step_group <= 1 else
+                                ("every plane an allocation of its own: gathered and handed back by the object (two device copies per group)"
+                                 if args.scattered_groups else
+                                 "a lane's pairs one container apart in four allocations (frame 0, frame 1, u, v): a group as laid out, run in place"),
                 "batch_mode": ("lock-step group" if args.batch_mode == "groups" else "lanes") if cfg["pairs_per_rank"] > 1 else None,
                 "timed_region": "graph-replayed steps only; output check, roofline sample, batch leg and baselines follow it",
             },

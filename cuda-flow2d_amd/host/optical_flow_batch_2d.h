@@ -45,7 +45,8 @@ public:
 
     // Lock-step groups formed by the object itself (group_size > 1): `count` INDEPENDENT pairs, every plane a container
     // of its own (any allocation of this device, ContainerSize()); consecutive runs of up to GroupSize() pairs become
-    // one group each (OpticalFlow2D::ComputeFlowGroupDevice: gather, one launch per kernel for the group, hand back),
+    // one group each (OpticalFlow2D::ComputeFlowGroupDevice: gather, one launch per kernel for the group, hand back -- or, when
+    // the run's planes already sit GroupStrideBytes() apart in all four roles, the pyramid on them in place, no copies),
     // group k on lane (first_lane + k) mod lanes.  The last group may be smaller.  Mid-size frames (1024^2, 1080p) gain
     // a third in throughput over one pair per lane; each pair's flow is bit-identical to its own ComputeFlowDevice.
     bool ComputeFlowBatchDeviceGrouped(size_t count, const DevicePtr* dev_frames_0, const DevicePtr* dev_frames_1,

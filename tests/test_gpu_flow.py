@@ -724,6 +724,80 @@ def test_groups_formed_from_scattered_planes(flow2d, oracle, constancy, sigma):
         c.close()
 
 
+@pytest.mark.parametrize("constancy", [0, 1])
+def test_groups_run_in_place_when_the_pairs_sit_one_container_apart(flow2d, oracle, constancy):
+    """ComputeFlowBatchDeviceGrouped with eleven pairs whose planes lie one below the other in four allocations per group of four
+    (4 + 4 + 3), handed over pair by pair like independent planes: a run of pairs exactly GroupStrideBytes() apart in all four roles
+    is a group as it lies -- the pyramid runs on the caller's planes, nothing is gathered or handed back (round 6).  Every pair
+    equals the oracle, eager and replayed, frames untouched; a run with ONE role out of step (the u planes of a group swapped) still
+    goes through the staging containers, to the same flows."""
+    w, h, G, n = 208, 144, 4, 11
+    p = (3, 0.5, 2, 5, 35.0, 0.001, 0.001, 5, 1.5)
+    pairs = [oracle.synthetic_pair(w, h, 1.0 + 0.25 * k, -0.5 + 0.2 * k, seed=320 + k, noise=True) for k in range(n)]
+    want = [oracle.compute_flow(f0, f1, *p, constancy)[:2] for f0, f1 in pairs]
+    c = flow2d.Context(0)
+    batch = flow2d.OpticalFlowBatch(w, h, constancy, lanes=2, group_size=G)
+    try:
+        stride = batch.group_stride
+        groups = [pairs[i:i + G] for i in range(0, n, G)]
+        tall = []
+        for g in groups:  # (the last group's allocation is four pairs tall too: its fourth slot stays unused)
+            pad = g + [g[-1]] * (G - len(g))
+            tall.append([c.plane(w, h * G, np.vstack([q[0] for q in pad])), c.plane(w, h * G, np.vstack([q[1] for q in pad])),
+                         c.plane(w, h * G), c.plane(w, h * G)])
+        c.synchronize()
+        assert tall[0][0].pitch * h == stride
+
+        def pointers(role, swap_first_two_of_group=None):
+            out = []
+            for gi, g in enumerate(groups):
+                ptrs = [tall[gi][role].ptr + k * stride for k in range(len(g))]
+                if swap_first_two_of_group == gi:
+                    ptrs[0], ptrs[1] = ptrs[1], ptrs[0]
+                out += ptrs
+            return out
+
+        def flows():
+            us, vs = [], []
+            for gi, g in enumerate(groups):
+                u, v = tall[gi][2].download(), tall[gi][3].download()
+                us += [u[k * h:(k + 1) * h] for k in range(len(g))]
+                vs += [v[k * h:(k + 1) * h] for k in range(len(g))]
+            return us, vs
+
+        for graph in (False, True, True):
+            batch.use_graph(graph)
+            for t in tall:
+                t[2].fill_bytes(0x7f), t[3].fill_bytes(0x7f)
+            c.synchronize()
+            batch.compute_flow_batch_device_grouped(pointers(0), pointers(1), pointers(2), pointers(3), batch.params(*p))
+            batch.synchronize()
+            us, vs = flows()
+            for k in range(n):
+                assert np.array_equal(us[k], want[k][0]) and np.array_equal(vs[k], want[k][1]), (graph, k)
+            # the unused fourth slot of the last group was not written
+            assert np.all(tall[-1][2].download()[len(groups[-1]) * h:].view(np.uint32) == 0x7f7f7f7f)
+            for gi, g in enumerate(groups):
+                f0, f1 = tall[gi][0].download(), tall[gi][1].download()
+                for k, q in enumerate(g):
+                    assert np.array_equal(f0[k * h:(k + 1) * h], q[0]) and np.array_equal(f1[k * h:(k + 1) * h], q[1])
+        # group 1's u planes out of step: pair 4 writes where pair 5's u lies and the other way round
+        batch.use_graph(True)
+        for t in tall:
+            t[2].fill_bytes(0x7f), t[3].fill_bytes(0x7f)
+        c.synchronize()
+        batch.compute_flow_batch_device_grouped(pointers(0), pointers(1), pointers(2, swap_first_two_of_group=1), pointers(3),
+                                                batch.params(*p))
+        batch.synchronize()
+        us, vs = flows()
+        us[4], us[5] = us[5], us[4]
+        for k in range(n):
+            assert np.array_equal(us[k], want[k][0]) and np.array_equal(vs[k], want[k][1]), ("out of step", k)
+    finally:
+        batch.close()
+        c.close()
+
+
 def test_scattered_group_larger_than_one_gather_launch(flow2d, oracle):
     """Groups of more than 32 scattered pairs need more planes than one flow2d_copy_planes launch names (64): the gather
     and the hand-back are issued in chunks.  40 small pairs as ONE lock-step group, every pair against the oracle.
