@@ -481,8 +481,9 @@ class Job:
             # (round 5, profiles/r05_experiments/step_group_sweeps.txt: 584 x 388 8 / 16 / 32 / 64 -> 1 707 / 1 973 / 2 340 / 2 007 pairs/s,
             #  1024^2 4 391 / 4 711 / 4 890 / 4 512, 4096^2 2 / 4 / 8 -> 332 / 338 / 345 at the driver's 20 steps and 340 / 345 / 348 at 100,
             #  8192^2 1 / 2 -> 96.4 / 94.3: the small kernels and coarse levels of a group share launches, and every launch of a
-            #  graph costs its stream 4-5 us)
-            self.step_group = args.step_group if args.step_group > 0 else (32 if w * h <= 1024 * 1024 else 16 if w * h <= 2048 * 2048 else 8 if w * h <= 4096 * 4096 else 1)
+            #  graph costs its stream 4-5 us.  Round 6, groups in place -- no gather / hand-back copies: 8192^2 1 / 2 -> 98.3-98.6 / 99.2-99.3,
+            #  4096^2 4 / 8 / 16 -> 352 / 356 / 357, 1024^2 16 / 32 / 64 -> 5 087 / 5 180 / 4 790)
+            self.step_group = args.step_group if args.step_group > 0 else (32 if w * h <= 1024 * 1024 else 16 if w * h <= 2048 * 2048 else 8 if w * h <= 4096 * 4096 else 2 if w * h <= 8192 * 8192 else 1)
         self.pending = []
         self.rotate = self.single or self.grouped  # a step is one entry; steps rotate over the lanes
         self.n_lanes = max(1, min(args.max_lanes, args.pipeline if self.rotate else cfg["pairs_per_rank"] * args.pipeline))
@@ -1161,7 +1162,7 @@ def main():
                          "pairs one below the other in four allocations, which the object runs in place")
     ap.add_argument("--step-group", type=int, default=0,
                     help="single-pair workloads: consecutive steps handed to the batch entry this many at a time, which "
-                         "forms a lock-step group of them (0 = automatic: 32 up to 1024^2, 16 up to 2048^2, 8 up to 4096^2, else 1; the "
+                         "forms a lock-step group of them (0 = automatic: 32 up to 1024^2, 16 up to 2048^2, 8 up to 4096^2, 2 up to 8192^2, else 1; the "
                          "finest level of a 4096^2 group still runs one launch per pair)")
     ap.add_argument("--batch-mode", choices=["groups", "lanes"], default="groups",
                     help="batched workloads: all pairs of a step as one lock-step group (every kernel launched once for "
